@@ -1,0 +1,73 @@
+"""ctypes binding of the C ABI declared in include/finc.h (libfinc_hip.so).
+
+Fails loudly: a missing library is an ImportError-like RuntimeError at first use,
+never a silent fallback.
+"""
+import ctypes
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libfinc_hip.so")
+
+OK = 0
+ALGO = {"auto": 0, "strict": 1, "mfma": 2}
+
+# every symbol include/finc.h declares (tests/test_abi.py checks the list against the header)
+SYMBOLS = [
+    "finc_version", "finc_status_string", "finc_last_hip_error", "finc_canonicalize_weights_f32",
+    "finc_check_invariant_f32", "finc_workspace_bytes", "finc_inverse_algo_for", "finc_forward_algo_for",
+    "finc_inverse_f32", "finc_forward_f32", "finc_pack_inverse_weights_f32", "finc_pack_forward_weights_f32",
+    "finc_inverse_packed_f32", "finc_forward_packed_f32", "finc_backward_f32",
+]
+
+_lib = None
+
+
+class FincError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FincError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(or `make -C fincflow_amd/csrc`).  fincflow_amd has no CPU / PyTorch fallback.")
+    L = ctypes.CDLL(LIB_PATH)
+    vp, i, u, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_uint, ctypes.c_size_t
+    L.finc_version.restype = i
+    L.finc_status_string.restype = ctypes.c_char_p
+    L.finc_status_string.argtypes = [i]
+    L.finc_last_hip_error.restype = ctypes.c_char_p
+    L.finc_canonicalize_weights_f32.argtypes = [vp, vp, i, i, i, i, u, vp]
+    L.finc_check_invariant_f32.argtypes = [vp, i, i, i, i, vp]
+    L.finc_workspace_bytes.restype = sz
+    L.finc_workspace_bytes.argtypes = [i, i, i, i]
+    L.finc_inverse_algo_for.argtypes = [i, i, i, i, i]
+    L.finc_forward_algo_for.argtypes = [i, i, i, i, i]
+    run = [vp, vp, vp, i, i, i, i, i, i, i, u, i, vp, sz, vp]
+    L.finc_inverse_f32.argtypes = run
+    L.finc_forward_f32.argtypes = run
+    L.finc_pack_inverse_weights_f32.argtypes = [vp, vp, i, i, i, i, vp]
+    L.finc_pack_forward_weights_f32.argtypes = [vp, vp, i, i, i, i, vp]
+    runp = [vp, vp, vp, i, i, i, i, i, i, i, u, vp]
+    L.finc_inverse_packed_f32.argtypes = runp
+    L.finc_forward_packed_f32.argtypes = runp
+    L.finc_backward_f32.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, i, i, u, vp]
+    for name in SYMBOLS:
+        getattr(L, name)  # AttributeError here = header and library out of sync
+    _lib = L
+    return L
+
+
+def check(status, what):
+    if status != OK:
+        L = lib()
+        msg = L.finc_status_string(status).decode()
+        if status == 5:
+            msg += ": " + L.finc_last_hip_error().decode()
+        if status in (1, 2, 7):
+            raise ValueError(f"{what}: {msg}")
+        raise FincError(f"{what}: {msg}")

@@ -1,0 +1,224 @@
+// extern "C" surface of libfinc_hip.so -- see include/finc.h for the contract
+// and the reference interfaces each entry point replaces.
+#include "finc_common.h"
+
+#include <string.h>
+
+namespace {
+
+thread_local char g_hip_error[256] = "no error";
+
+__global__ void canonicalize_kernel(const float *__restrict__ ws, float *__restrict__ wc, int G, int Cq, int KH,
+                                    int KW, unsigned orient)
+{
+    const int total = G * Cq * Cq * KH * KW;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int kw = idx % KW;
+        const int kh = (idx / KW) % KH;
+        const int rest = idx / (KW * KH); // (g*Cq + oc)*Cq + ic
+        const int g = rest / (Cq * Cq);
+        const unsigned o = finc_group_orient(orient, g);
+        const int sh = (o & FINC_FLIP_H) ? KH - 1 - kh : kh;
+        const int sw = (o & FINC_FLIP_W) ? KW - 1 - kw : kw;
+        wc[idx] = ws[(rest * KH + sh) * KW + sw];
+    }
+}
+
+// flag[0] = 0 if the corner tap is unit lower triangular in every group, else 1 + first bad index
+__global__ void invariant_kernel(const float *__restrict__ wc, int G, int Cq, int KH, int KW, int *flag)
+{
+    const int total = G * Cq * Cq;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += gridDim.x * blockDim.x) {
+        const int kc = idx % Cq;
+        const int c = (idx / Cq) % Cq;
+        if (kc < c) continue;
+        const float v = wc[((size_t)idx * KH + (KH - 1)) * KW + (KW - 1)];
+        const bool ok = (kc == c) ? (v == 1.0f) : (v == 0.0f);
+        if (!ok) atomicMax(flag, 1 + idx);
+    }
+}
+
+int check_shape(int B, int G, int Cq, int H, int W, int KH, int KW)
+{
+    if (B <= 0 || G <= 0 || Cq <= 0 || H <= 0 || W <= 0 || KH <= 0 || KW <= 0) return FINC_ERR_BAD_DIMS;
+    if (G > FINC_MAX_GROUPS || Cq > FINC_MAX_CQ || KH > 15 || KW > 15) return FINC_ERR_BAD_DIMS;
+    if ((size_t)B * G * Cq * H * W >= ((size_t)1 << 40)) return FINC_ERR_BAD_DIMS;
+    if ((size_t)Cq * H * W >= ((size_t)1 << 31)) return FINC_ERR_BAD_DIMS; // per-group offsets are 32-bit in-kernel
+    return FINC_OK;
+}
+
+inline bool misaligned(const void *p) { return ((uintptr_t)p & 3u) != 0; }
+
+} // namespace
+
+void finc_set_hip_error(hipError_t e)
+{
+    strncpy(g_hip_error, hipGetErrorString(e), sizeof(g_hip_error) - 1);
+    g_hip_error[sizeof(g_hip_error) - 1] = 0;
+}
+
+extern "C" {
+
+int finc_version(void) { return 100; }
+
+const char *finc_status_string(int status)
+{
+    switch (status) {
+    case FINC_OK: return "ok";
+    case FINC_ERR_NULL_POINTER: return "null pointer argument";
+    case FINC_ERR_BAD_DIMS: return "bad dimensions";
+    case FINC_ERR_UNSUPPORTED: return "requested algorithm does not support this shape";
+    case FINC_ERR_WORKSPACE: return "workspace missing or too small";
+    case FINC_ERR_LAUNCH: return "HIP call failed";
+    case FINC_ERR_INVARIANT: return "corner tap is not unit lower triangular (layers/conv.py:63-70 invariant)";
+    case FINC_ERR_ALIGNMENT: return "pointer not aligned for fp32";
+    default: return "unknown status";
+    }
+}
+
+const char *finc_last_hip_error(void) { return g_hip_error; }
+
+int finc_canonicalize_weights_f32(const float *w_stored, float *w_canon, int G, int Cq, int KH, int KW,
+                                  unsigned orient, finc_stream_t stream)
+{
+    if (!w_stored || !w_canon) return FINC_ERR_NULL_POINTER;
+    if (int e = check_shape(1, G, Cq, 1, 1, KH, KW)) return e;
+    if (w_stored == w_canon) return FINC_ERR_BAD_DIMS;
+    const int total = G * Cq * Cq * KH * KW;
+    int blocks = (total + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(canonicalize_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_stored, w_canon, G,
+                       Cq, KH, KW, orient);
+    FINC_CHECK_LAUNCH();
+    return FINC_OK;
+}
+
+int finc_check_invariant_f32(const float *w_canon, int G, int Cq, int KH, int KW, finc_stream_t stream)
+{
+    if (!w_canon) return FINC_ERR_NULL_POINTER;
+    if (int e = check_shape(1, G, Cq, 1, 1, KH, KW)) return e;
+    hipStream_t st = (hipStream_t)stream;
+    int *d_flag = nullptr;
+    FINC_HIP_TRY(hipMalloc(&d_flag, sizeof(int)));
+    int h_flag = 0;
+    hipError_t e = hipMemsetAsync(d_flag, 0, sizeof(int), st);
+    if (e == hipSuccess) {
+        int blocks = (G * Cq * Cq + 255) / 256;
+        hipLaunchKernelGGL(invariant_kernel, dim3(blocks), dim3(256), 0, st, w_canon, G, Cq, KH, KW, d_flag);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(&h_flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    hipError_t e2 = hipFree(d_flag);
+    if (e != hipSuccess) { finc_set_hip_error(e); return FINC_ERR_LAUNCH; }
+    if (e2 != hipSuccess) { finc_set_hip_error(e2); return FINC_ERR_LAUNCH; }
+    return h_flag == 0 ? FINC_OK : FINC_ERR_INVARIANT;
+}
+
+size_t finc_workspace_bytes(int G, int Cq, int KH, int KW)
+{
+    if (G <= 0 || Cq <= 0 || KH <= 0 || KW <= 0) return 256;
+    size_t n = finc_mfma_packed_bytes(G, Cq, KH, KW);
+    return n < 256 ? 256 : n;
+}
+
+int finc_inverse_algo_for(int Cq, int H, int W, int KH, int KW)
+{
+    return finc_mfma_supported(Cq, H, W, KH, KW, false) ? FINC_ALGO_MFMA : FINC_ALGO_STRICT;
+}
+
+int finc_forward_algo_for(int Cq, int H, int W, int KH, int KW)
+{
+    return finc_mfma_supported(Cq, H, W, KH, KW, true) ? FINC_ALGO_MFMA : FINC_ALGO_STRICT;
+}
+
+static int run(const float *in, const float *w_canon, float *out, int B, int G, int Cq, int H, int W, int KH,
+               int KW, unsigned orient, int algo, void *workspace, size_t workspace_bytes, finc_stream_t stream,
+               bool forward)
+{
+    if (!in || !w_canon || !out) return FINC_ERR_NULL_POINTER;
+    if (int e = check_shape(B, G, Cq, H, W, KH, KW)) return e;
+    if (misaligned(in) || misaligned(w_canon) || misaligned(out)) return FINC_ERR_ALIGNMENT;
+    if (in == out) return FINC_ERR_BAD_DIMS;
+    FincShape s{B, G, Cq, H, W, KH, KW, orient};
+    hipStream_t st = (hipStream_t)stream;
+    if (algo == FINC_ALGO_AUTO)
+        algo = forward ? finc_forward_algo_for(Cq, H, W, KH, KW) : finc_inverse_algo_for(Cq, H, W, KH, KW);
+    if (algo == FINC_ALGO_STRICT)
+        return forward ? finc_launch_forward_generic(in, w_canon, out, s, st)
+                       : finc_launch_inverse_strict(in, w_canon, out, s, st);
+    if (algo != FINC_ALGO_MFMA) return FINC_ERR_UNSUPPORTED;
+    if (!finc_mfma_supported(Cq, H, W, KH, KW, forward)) return FINC_ERR_UNSUPPORTED;
+    if (!workspace || workspace_bytes < finc_mfma_packed_bytes(G, Cq, KH, KW)) return FINC_ERR_WORKSPACE;
+    if (int e = finc_mfma_pack(w_canon, workspace, G, Cq, KH, KW, forward, st)) return e;
+    return finc_mfma_launch(in, workspace, out, s, forward, st);
+}
+
+int finc_inverse_f32(const float *z, const float *w_canon, float *x, int B, int G, int Cq, int H, int W, int KH,
+                     int KW, unsigned orient, int algo, void *workspace, size_t workspace_bytes, finc_stream_t stream)
+{
+    return run(z, w_canon, x, B, G, Cq, H, W, KH, KW, orient, algo, workspace, workspace_bytes, stream, false);
+}
+
+int finc_forward_f32(const float *x, const float *w_canon, float *z, int B, int G, int Cq, int H, int W, int KH,
+                     int KW, unsigned orient, int algo, void *workspace, size_t workspace_bytes, finc_stream_t stream)
+{
+    return run(x, w_canon, z, B, G, Cq, H, W, KH, KW, orient, algo, workspace, workspace_bytes, stream, true);
+}
+
+static int pack(const float *w_canon, void *packed, int G, int Cq, int KH, int KW, finc_stream_t stream, bool forward)
+{
+    if (!w_canon || !packed) return FINC_ERR_NULL_POINTER;
+    if (int e = check_shape(1, G, Cq, 1, 1, KH, KW)) return e;
+    if (finc_mfma_packed_bytes(G, Cq, KH, KW) == 0) return FINC_ERR_UNSUPPORTED;
+    return finc_mfma_pack(w_canon, packed, G, Cq, KH, KW, forward, (hipStream_t)stream);
+}
+
+int finc_pack_inverse_weights_f32(const float *w_canon, void *packed, int G, int Cq, int KH, int KW,
+                                  finc_stream_t stream)
+{
+    return pack(w_canon, packed, G, Cq, KH, KW, stream, false);
+}
+
+int finc_pack_forward_weights_f32(const float *w_canon, void *packed, int G, int Cq, int KH, int KW,
+                                  finc_stream_t stream)
+{
+    return pack(w_canon, packed, G, Cq, KH, KW, stream, true);
+}
+
+static int run_packed(const float *in, const void *packed, float *out, int B, int G, int Cq, int H, int W, int KH,
+                      int KW, unsigned orient, finc_stream_t stream, bool forward)
+{
+    if (!in || !packed || !out) return FINC_ERR_NULL_POINTER;
+    if (int e = check_shape(B, G, Cq, H, W, KH, KW)) return e;
+    if (misaligned(in) || misaligned(out)) return FINC_ERR_ALIGNMENT;
+    if (in == out) return FINC_ERR_BAD_DIMS;
+    if (!finc_mfma_supported(Cq, H, W, KH, KW, forward)) return FINC_ERR_UNSUPPORTED;
+    FincShape s{B, G, Cq, H, W, KH, KW, orient};
+    return finc_mfma_launch(in, packed, out, s, forward, (hipStream_t)stream);
+}
+
+int finc_inverse_packed_f32(const float *z, const void *packed, float *x, int B, int G, int Cq, int H, int W, int KH,
+                            int KW, unsigned orient, finc_stream_t stream)
+{
+    return run_packed(z, packed, x, B, G, Cq, H, W, KH, KW, orient, stream, false);
+}
+
+int finc_forward_packed_f32(const float *x, const void *packed, float *z, int B, int G, int Cq, int H, int W, int KH,
+                            int KW, unsigned orient, finc_stream_t stream)
+{
+    return run_packed(x, packed, z, B, G, Cq, H, W, KH, KW, orient, stream, true);
+}
+
+int finc_backward_f32(const float *grad_z, const float *x, const float *w_canon, float *grad_x, float *grad_w_canon,
+                      int B, int G, int Cq, int H, int W, int KH, int KW, unsigned orient, finc_stream_t stream)
+{
+    if (!grad_z) return FINC_ERR_NULL_POINTER;
+    if (grad_x && !w_canon) return FINC_ERR_NULL_POINTER;
+    if (grad_w_canon && !x) return FINC_ERR_NULL_POINTER;
+    if (int e = check_shape(B, G, Cq, H, W, KH, KW)) return e;
+    FincShape s{B, G, Cq, H, W, KH, KW, orient};
+    return finc_launch_backward_generic(grad_z, x, w_canon, grad_x, grad_w_canon, s, (hipStream_t)stream);
+}
+
+} // extern "C"

@@ -1,0 +1,51 @@
+// Shared host/device helpers for libfinc_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include "../../include/finc.h"
+
+#define FINC_FLIP_W 1u
+#define FINC_FLIP_H 2u
+
+__host__ __device__ inline unsigned finc_group_orient(unsigned orient, int g) { return (orient >> (2 * g)) & 3u; }
+
+// canonical (h,w) of a group -> offset inside one H*W plane
+__device__ inline int finc_pix(int H, int W, unsigned o, int h, int w)
+{
+    int hh = (o & FINC_FLIP_H) ? H - 1 - h : h;
+    int ww = (o & FINC_FLIP_W) ? W - 1 - w : w;
+    return hh * W + ww;
+}
+
+// Recorded by every failing HIP call; read through finc_last_hip_error().
+void finc_set_hip_error(hipError_t e);
+
+#define FINC_HIP_TRY(expr)                     \
+    do {                                       \
+        hipError_t _e = (expr);                \
+        if (_e != hipSuccess) {                \
+            finc_set_hip_error(_e);            \
+            return FINC_ERR_LAUNCH;            \
+        }                                      \
+    } while (0)
+
+#define FINC_CHECK_LAUNCH() FINC_HIP_TRY(hipGetLastError())
+
+struct FincShape {
+    int B, G, Cq, H, W, KH, KW;
+    unsigned orient;
+};
+
+// ---- generic (reference-order) kernels: finc_generic.hip ----
+int finc_launch_inverse_strict(const float *z, const float *wc, float *x, const FincShape &s, hipStream_t st);
+int finc_launch_forward_generic(const float *x, const float *wc, float *z, const FincShape &s, hipStream_t st);
+int finc_launch_backward_generic(const float *gz, const float *x, const float *wc, float *gx, float *gw,
+                                 const FincShape &s, hipStream_t st);
+
+// ---- MFMA wavefront kernels: finc_mfma.hip ----
+bool finc_mfma_supported(int Cq, int H, int W, int KH, int KW, bool forward);
+size_t finc_mfma_packed_bytes(int G, int Cq, int KH, int KW);
+int finc_mfma_pack(const float *wc, void *packed, int G, int Cq, int KH, int KW, bool forward, hipStream_t st);
+int finc_mfma_launch(const float *in, const void *packed, float *out, const FincShape &s, bool forward, hipStream_t st);

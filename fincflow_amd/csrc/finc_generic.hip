@@ -1,0 +1,227 @@
+// Reference-order kernels: correct for every shape, the universal fallback and
+// the bit-exactness anchor.  Compiled with -ffp-contract=off.
+//
+//  * inverse_strict: one workgroup per (image, group) walks the H+W-1
+//    anti-diagonals with a workgroup barrier where the reference has a kernel
+//    launch + cudaDeviceSynchronize (cinc_cuda_kernel_level2.cu:98-130).  One
+//    thread owns one pixel of the diagonal and runs the reference's term order
+//    kh -> kw -> kc (cinc_cuda_kernel_level2.cu:59-72) with a separate fp32
+//    multiply and subtract per term, so the result is bit-identical to the
+//    fp32 CPU restatement (utils/solve_mc.py:29-44).
+//  * forward_generic / backward_generic: direct evaluation, one output per thread.
+#include "finc_common.h"
+
+namespace {
+
+constexpr int STRICT_MAX_BLOCK = 256;
+
+__global__ void inverse_strict_kernel(const float *__restrict__ z, const float *__restrict__ wc, float *x, int G,
+                                      int Cq, int H, int W, int KH, int KW, unsigned orient)
+{
+    extern __shared__ __attribute__((aligned(16))) float own[]; // [Cq][blockDim.x]: this pixel's solved channels
+    const int bg = blockIdx.x;
+    const int g = bg % G;
+    const unsigned o = finc_group_orient(orient, g);
+    const size_t HW = (size_t)H * W;
+    const size_t off = (size_t)bg * Cq * HW; // == (b*G*Cq + g*Cq) * HW
+    const float *zg = z + off;
+    float *xg = x + off;
+    const float *wg = wc + (size_t)g * Cq * Cq * KH * KW;
+    const int tid = threadIdx.x, nt = blockDim.x;
+
+    for (int d = 0; d < H + W - 1; ++d) {
+        const int h_lo = d - (W - 1) > 0 ? d - (W - 1) : 0;
+        const int h_hi = d < H - 1 ? d : H - 1;
+        const int len = h_hi - h_lo + 1;
+        for (int base = 0; base < len; base += nt) {
+            const int idx = base + tid;
+            if (idx < len) {
+                const int h = h_lo + idx, w = d - h;
+                const int p = finc_pix(H, W, o, h, w);
+                for (int c = 0; c < Cq; ++c) {
+                    float acc = zg[(size_t)c * HW + p];
+                    for (int kh = 0; kh < KH; ++kh) {
+                        if (h - kh < 0) break;
+                        for (int kw = 0; kw < KW; ++kw) {
+                            if (w - kw < 0) break;
+                            const float *wrow = wg + (((size_t)c * Cq) * KH + (KH - 1 - kh)) * KW + (KW - 1 - kw);
+                            if (kh == 0 && kw == 0) {
+                                for (int kc = 0; kc < c; ++kc) { // kc == c skipped, kc > c: zero taps
+                                    float xv = own[kc * nt + tid];
+                                    float wv = wrow[(size_t)kc * KH * KW];
+                                    acc = __fsub_rn(acc, __fmul_rn(xv, wv));
+                                }
+                            } else {
+                                const int pn = finc_pix(H, W, o, h - kh, w - kw);
+                                for (int kc = 0; kc < Cq; ++kc) {
+                                    float xv = xg[(size_t)kc * HW + pn];
+                                    float wv = wrow[(size_t)kc * KH * KW];
+                                    acc = __fsub_rn(acc, __fmul_rn(xv, wv));
+                                }
+                            }
+                        }
+                    }
+                    own[c * nt + tid] = acc;
+                    xg[(size_t)c * HW + p] = acc;
+                }
+            }
+        }
+        __syncthreads(); // this diagonal's stores become visible to the workgroup
+    }
+}
+
+__global__ void forward_generic_kernel(const float *__restrict__ x, const float *__restrict__ wc,
+                                       float *__restrict__ z, int B, int G, int Cq, int H, int W, int KH, int KW,
+                                       unsigned orient)
+{
+    const size_t HW = (size_t)H * W;
+    const size_t total = (size_t)B * G * Cq * HW;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int pw = (int)(idx % W);
+        const int ph = (int)((idx / W) % H);
+        const size_t ch = idx / HW; // b*G*Cq + g*Cq + oc
+        const int oc = (int)(ch % Cq);
+        const int g = (int)((ch / Cq) % G);
+        const unsigned o = finc_group_orient(orient, g);
+        const int h = (o & FINC_FLIP_H) ? H - 1 - ph : ph; // canonical coordinates of this output
+        const int w = (o & FINC_FLIP_W) ? W - 1 - pw : pw;
+        const float *xg = x + (ch - oc) * HW;
+        const float *wo = wc + ((size_t)(g * Cq + oc) * Cq) * KH * KW;
+        float acc = 0.f;
+        for (int ic = 0; ic < Cq; ++ic)
+            for (int a = 0; a < KH && a <= h; ++a)
+                for (int b = 0; b < KW && b <= w; ++b)
+                    acc = fmaf(xg[(size_t)ic * HW + finc_pix(H, W, o, h - a, w - b)],
+                               wo[((size_t)ic * KH + (KH - 1 - a)) * KW + (KW - 1 - b)], acc);
+        z[idx] = acc;
+    }
+}
+
+// grad_x[b,i,h,w] = sum_{o,a,b} wc[o,i,KH-1-a,KW-1-b] * gz[b,o,h+a,w+b]   (canonical coordinates)
+__global__ void backward_input_kernel(const float *__restrict__ gz, const float *__restrict__ wc,
+                                      float *__restrict__ gx, int B, int G, int Cq, int H, int W, int KH, int KW,
+                                      unsigned orient)
+{
+    const size_t HW = (size_t)H * W;
+    const size_t total = (size_t)B * G * Cq * HW;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int pw = (int)(idx % W);
+        const int ph = (int)((idx / W) % H);
+        const size_t ch = idx / HW;
+        const int ic = (int)(ch % Cq);
+        const int g = (int)((ch / Cq) % G);
+        const unsigned o = finc_group_orient(orient, g);
+        const int h = (o & FINC_FLIP_H) ? H - 1 - ph : ph;
+        const int w = (o & FINC_FLIP_W) ? W - 1 - pw : pw;
+        const float *gg = gz + (ch - ic) * HW;
+        const float *wgp = wc + (size_t)g * Cq * Cq * KH * KW;
+        float acc = 0.f;
+        for (int oc = 0; oc < Cq; ++oc)
+            for (int a = 0; a < KH && h + a < H; ++a)
+                for (int b = 0; b < KW && w + b < W; ++b)
+                    acc = fmaf(gg[(size_t)oc * HW + finc_pix(H, W, o, h + a, w + b)],
+                               wgp[(((size_t)oc * Cq + ic) * KH + (KH - 1 - a)) * KW + (KW - 1 - b)], acc);
+        gx[idx] = acc;
+    }
+}
+
+// One workgroup per (g, o, i): all KH*KW taps of grad_w_canon[g*Cq+o][i], reduced over (b,h,w).
+// The corner tap of entries with i >= o is masked to 0 (PaddedConv2d.reset_gradients, layers/conv.py:98-99).
+constexpr int BW_BLOCK = 256;
+constexpr int BW_MAX_TAPS = 49;
+__global__ void backward_weight_kernel(const float *__restrict__ gz, const float *__restrict__ x,
+                                       float *__restrict__ gw, int B, int G, int Cq, int H, int W, int KH, int KW,
+                                       unsigned orient)
+{
+    __shared__ float red[BW_BLOCK];
+    const int i = blockIdx.x % Cq;
+    const int oc = (blockIdx.x / Cq) % Cq;
+    const int g = blockIdx.x / (Cq * Cq);
+    const unsigned o = finc_group_orient(orient, g);
+    const size_t HW = (size_t)H * W;
+    const int ntap = KH * KW;
+    float acc[BW_MAX_TAPS];
+#pragma unroll
+    for (int t = 0; t < BW_MAX_TAPS; ++t) acc[t] = 0.f;
+    const size_t n = (size_t)B * HW;
+    for (size_t e = threadIdx.x; e < n; e += BW_BLOCK) {
+        const int b = (int)(e / HW);
+        const int r = (int)(e % HW);
+        const int h = r / W, w = r % W; // canonical coordinates of the grad_z sample
+        const size_t plane = ((size_t)b * G + g) * Cq;
+        const float gv = gz[(plane + oc) * HW + finc_pix(H, W, o, h, w)];
+        const float *xp = x + (plane + i) * HW;
+#pragma unroll 1
+        for (int kh = 0; kh < KH; ++kh) {
+            const int a = KH - 1 - kh;
+            if (h - a < 0) continue;
+            for (int kw = 0; kw < KW; ++kw) {
+                const int bb = KW - 1 - kw;
+                if (w - bb < 0) continue;
+                acc[kh * KW + kw] = fmaf(gv, xp[finc_pix(H, W, o, h - a, w - bb)], acc[kh * KW + kw]);
+            }
+        }
+    }
+    for (int t = 0; t < ntap; ++t) {
+        red[threadIdx.x] = acc[t];
+        __syncthreads();
+        for (int s = BW_BLOCK / 2; s > 0; s >>= 1) {
+            if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            const bool masked = (t == ntap - 1) && (i >= oc);
+            gw[(((size_t)(g * Cq + oc) * Cq + i) * ntap) + t] = masked ? 0.f : red[0];
+        }
+        __syncthreads();
+    }
+}
+
+} // namespace
+
+int finc_launch_inverse_strict(const float *z, const float *wc, float *x, const FincShape &s, hipStream_t st)
+{
+    int diag = s.H < s.W ? s.H : s.W;
+    int block = ((diag + 63) / 64) * 64;
+    if (block > STRICT_MAX_BLOCK) block = STRICT_MAX_BLOCK;
+    while (block > 64 && (size_t)block * s.Cq * sizeof(float) > 60 * 1024) block -= 64;
+    size_t lds = (size_t)block * s.Cq * sizeof(float);
+    if (lds > 64 * 1024) return FINC_ERR_UNSUPPORTED;
+    hipLaunchKernelGGL(inverse_strict_kernel, dim3(s.B * s.G), dim3(block), lds, st, z, wc, x, s.G, s.Cq, s.H, s.W,
+                       s.KH, s.KW, s.orient);
+    FINC_CHECK_LAUNCH();
+    return FINC_OK;
+}
+
+int finc_launch_forward_generic(const float *x, const float *wc, float *z, const FincShape &s, hipStream_t st)
+{
+    size_t total = (size_t)s.B * s.G * s.Cq * s.H * s.W;
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 256 * 32) blocks = 256 * 32;
+    hipLaunchKernelGGL(forward_generic_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, wc, z, s.B, s.G, s.Cq,
+                       s.H, s.W, s.KH, s.KW, s.orient);
+    FINC_CHECK_LAUNCH();
+    return FINC_OK;
+}
+
+int finc_launch_backward_generic(const float *gz, const float *x, const float *wc, float *gx, float *gw,
+                                 const FincShape &s, hipStream_t st)
+{
+    if (gx) {
+        size_t total = (size_t)s.B * s.G * s.Cq * s.H * s.W;
+        size_t blocks = (total + 255) / 256;
+        if (blocks > 256 * 32) blocks = 256 * 32;
+        hipLaunchKernelGGL(backward_input_kernel, dim3((unsigned)blocks), dim3(256), 0, st, gz, wc, gx, s.B, s.G,
+                           s.Cq, s.H, s.W, s.KH, s.KW, s.orient);
+        FINC_CHECK_LAUNCH();
+    }
+    if (gw) {
+        if (s.KH * s.KW > BW_MAX_TAPS) return FINC_ERR_UNSUPPORTED;
+        hipLaunchKernelGGL(backward_weight_kernel, dim3(s.G * s.Cq * s.Cq), dim3(BW_BLOCK), 0, st, gz, x, gw, s.B,
+                           s.G, s.Cq, s.H, s.W, s.KH, s.KW, s.orient);
+        FINC_CHECK_LAUNCH();
+    }
+    return FINC_OK;
+}

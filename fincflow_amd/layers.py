@@ -1,0 +1,213 @@
+"""Drop-in modules for the reference's hot-path layers.
+
+Same constructor signatures, attribute names, state-dict keys and
+forward -> (out, logdet) / reverse protocol as
+
+  * fastflow/layers/flowlayer.py:8-30      FlowLayer (ABC)
+  * fastflow/layers/conv.py:21-221          PaddedConv2d
+  * fastflow/fastflow.py:13-100             FastFlowUnit
+
+so a reference `FlowSequential` (layers/flowsequential.py:21-44,89-115) or
+`FastFlowStep` (fastflow_cifar_multi_gpu.py:224-256) can hold them unchanged.
+The arithmetic runs in libfinc_hip.so; there is no CPU path.
+"""
+from abc import ABCMeta, abstractmethod
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+class FlowLayer(nn.Module, metaclass=ABCMeta):
+    """layers/flowlayer.py:8-30."""
+
+    @abstractmethod
+    def forward(self, input, context=None):
+        pass
+
+    @abstractmethod
+    def reverse(self, input, context=None):
+        pass
+
+    @abstractmethod
+    def logdet(self, input, context=None):
+        pass
+
+    def reconstruct_forward(self, input, context=None):
+        return self.forward(input)
+
+    def reconstruct_reverse(self, input, context=None):
+        return self.reverse(input)
+
+
+class PaddedConv2d(FlowLayer):
+    """One-corner zero-padded, bias-free, unit-triangular conv (layers/conv.py:21-221).
+
+    `self.conv.weight` is stored flipped per `order` exactly like the reference
+    (layers/conv.py:72-79), so reference checkpoints load with `load_state_dict`.
+    """
+
+    def __init__(self, in_channels, out_channels, kernel_size, bias=False, order='TL'):
+        super().__init__()
+        assert len(kernel_size) == 2
+        assert order in {'TL', 'TR', 'BL', 'BR'}, 'unknown order: {}'.format(order)
+        if bias:
+            raise NotImplementedError("bias=True is never used on the FInC hot path (fastflow.py:24-27)")
+        if in_channels != out_channels:
+            raise ValueError("an invertible conv needs in_channels == out_channels")
+        self.kernel_size = kernel_size
+        self.order = order
+        K_H, K_W = kernel_size[0], kernel_size[1]
+        # (left, right, top, bottom), layers/conv.py:41-55
+        self.pad = {'TL': (K_W - 1, 0, K_H - 1, 0), 'TR': (0, K_W - 1, K_H - 1, 0),
+                    'BL': (K_W - 1, 0, 0, K_H - 1), 'BR': (0, K_W - 1, 0, K_H - 1)}[order]
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size, bias=False)  # parameter holder only
+        self._cache = ops.PackedWeights()
+        self.reset_parameters()
+
+    @property
+    def _orient(self):
+        return ops.ORDER_BITS[self.order]
+
+    def _flip(self, t):
+        if self.order == 'TR':
+            return torch.flip(t, [3])
+        if self.order == 'BL':
+            return torch.flip(t, [2])
+        if self.order == 'BR':
+            return torch.flip(t, [2, 3])
+        return t
+
+    def reset_parameters(self):
+        """layers/conv.py:63-79."""
+        nn.init.normal_(self.conv.weight.data, mean=0.0, std=0.05)
+        self.mask = self.get_mask()
+        w = self.conv.weight.data
+        for c_out in range(w.shape[0]):
+            w[c_out, c_out, -1, -1] = 1.0
+            w[c_out, c_out + 1:, -1, -1] = 0.0
+        self.conv.weight.data = self._flip(w).contiguous()
+
+    def get_mask(self):
+        """layers/conv.py:81-96."""
+        mask = torch.ones_like(self.conv.weight.data)
+        for c_out in range(mask.shape[0]):
+            mask[c_out, c_out:, -1, -1] = 0.0
+        return self._flip(mask).contiguous()
+
+    def reset_gradients(self):
+        """layers/conv.py:98-99.  The HIP backward already writes masked gradients; kept for the runner's
+        `model.apply(clear_grad)` (train/experiment.py:16-18)."""
+        if self.conv.weight.grad is not None:
+            self.conv.weight.grad = self.conv.weight.grad * self.mask.to(self.conv.weight.grad.device)
+
+    def forward(self, x, context=None, compute_expensive=None):
+        out = ops.conv_forward(x, self.conv.weight, 1, self._orient)
+        return out, 0.0
+
+    def reverse(self, x, context=None, compute_expensive=None):
+        with torch.no_grad():
+            y = self._cache.inverse(x.contiguous(), [self.conv.weight], 1, self._orient)
+        return y, 0
+
+    def logdet(self, x=None, context=None):
+        return 0.0
+
+
+class FastFlowUnit(nn.Module):
+    """Four PaddedConv2d (TL, TR, BL, BR), one per channel quarter (fastflow.py:13-100), evaluated as ONE
+    grouped launch in each direction."""
+
+    def __init__(self, in_channels, out_channels, kernel_size):
+        super().__init__()
+        if isinstance(kernel_size, int) or len(kernel_size) == 1:
+            kernel_size = (kernel_size, kernel_size) if isinstance(kernel_size, int) else (kernel_size[0],) * 2
+        assert in_channels % 4 == 0, "Input channels have to be a multiple of 4"
+        out_channels = in_channels // 4  # fastflow.py:21: the argument is overridden
+        self.conv_tl = PaddedConv2d(out_channels, out_channels, kernel_size, order='TL')
+        self.conv_tr = PaddedConv2d(out_channels, out_channels, kernel_size, order='TR')
+        self.conv_bl = PaddedConv2d(out_channels, out_channels, kernel_size, order='BL')
+        self.conv_br = PaddedConv2d(out_channels, out_channels, kernel_size, order='BR')
+        self._cache = ops.PackedWeights()
+
+    def _weights(self):
+        return [self.conv_tl.conv.weight, self.conv_tr.conv.weight, self.conv_bl.conv.weight,
+                self.conv_br.conv.weight]
+
+    def forward(self, x, context=None):
+        w = torch.cat(self._weights(), dim=0)
+        out = ops.conv_forward(x, w, 4, ops.ORIENT_FASTFLOW)
+        return out, 0.0
+
+    def reverse(self, x, context=None):
+        return self.reverse_level2(x)
+
+    def reverse_level2(self, x):
+        """fastflow.py:78-100 without the 6 flip/cat/zeros copies: the kernel indexes the flipped pixel."""
+        with torch.no_grad():
+            return self._cache.inverse(x.contiguous(), self._weights(), 4, ops.ORIENT_FASTFLOW)
+
+    def reverse_level1(self, x):
+        """fastflow.py:57-76: one solve per group."""
+        chunks = torch.chunk(x, 4, dim=1)
+        outs = [m.reverse(c.contiguous())[0] for m, c in
+                zip((self.conv_tl, self.conv_tr, self.conv_bl, self.conv_br), chunks)]
+        return torch.cat(outs, dim=1)
+
+
+class StandardNormal(nn.Module):
+    """Base density with the runner's interface (train/losses.py:17-45): log_prob(z) -> [B], sample(n)."""
+
+    def __init__(self, size):
+        super().__init__()
+        self.size = tuple(size)
+        self.register_buffer("_anchor", torch.zeros(1))
+
+    def log_prob(self, z, context=None):
+        return -0.5 * (z ** 2 + torch.log(torch.tensor(2 * torch.pi, device=z.device))).flatten(1).sum(1)
+
+    def sample(self, n_samples, context=None):
+        return torch.randn(n_samples, *self.size, device=self._anchor.device), None
+
+
+class FlowSequential(nn.Module):
+    """Protocol-compatible stand-in for layers/flowsequential.py:9-115 (the reference file cannot travel to
+    the GPU box and hard-imports wandb + a cuDNN-only extension).  Only what the hot path's callers use."""
+
+    def __init__(self, base_distribution, *modules):
+        super().__init__()
+        self.base_distribution = base_distribution
+        for i, module in enumerate(modules):
+            self.add_module(str(i), module)
+        self.sequence_modules = modules
+
+    def __iter__(self):
+        yield from self.sequence_modules
+
+    def forward(self, input, context=None, compute_expensive=False):
+        logdet = 0
+        for module in self:
+            output, layer_logdet = module(input, context)
+            logdet += layer_logdet
+            input = output
+        logprob = self.base_distribution.log_prob(input)
+        return output, logprob + logdet
+
+    def log_prob(self, input, context=None, compute_expensive=True):
+        return self.forward(input, context, compute_expensive)[1]
+
+    def sample(self, n_samples, context=None, compute_expensive=False, also_true_inverse=False):
+        z, _ = self.base_distribution.sample(n_samples, context)
+        input = z
+        for module in reversed(self.sequence_modules):
+            output = module.reverse(input, context)
+            input = output[0] if isinstance(output, tuple) else output
+        return input
+
+    def reconstruct(self, input, context=None, compute_expensive=False):
+        z = self.forward(input, context)[0]
+        for module in reversed(self.sequence_modules):
+            output = module.reverse(z, context)
+            z = output[0] if isinstance(output, tuple) else output
+        return z

@@ -1,0 +1,204 @@
+"""Host-side operators over the C ABI (include/finc.h).
+
+`inverse(input, kernel, output)` mirrors the reference's one native op
+(fastflow/utils/fastflow_cuda_inverse/cinc_cuda_level2.cpp:19-32): same name,
+same argument meaning, same in-place-and-return-alias behaviour, same
+RuntimeError for non-device / non-contiguous tensors.  `finc_inverse` /
+`finc_forward` are the orientation-aware calls FastFlowUnit uses (no flips, no
+chunk/cat copies: fastflow.py:78-100 collapses into one launch).
+"""
+import torch
+
+from . import _lib
+
+ORDER_BITS = {"TL": 0, "TR": 1, "BL": 2, "BR": 3}
+ORIENT_FASTFLOW = 0xE4  # TL,TR,BL,BR (fastflow.py:24-27)
+
+_workspaces = {}
+
+
+def _stream_ptr(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def _require_device(t, name):
+    # same conditions, same exception type as CHECK_INPUT (cinc_cuda_level2.cpp:15-17)
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a CUDA tensor (fincflow_amd has no CPU fallback)")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} must be contiguous")
+    if t.dtype != torch.float32:
+        raise ValueError(f"{name} must be float32, got {t.dtype}")
+
+
+def _workspace(device, nbytes):
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    ws = _workspaces.get(key)
+    if ws is None or ws.numel() < nbytes:
+        ws = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _workspaces[key] = ws
+    return ws
+
+
+def _dims(act, w, G):
+    if act.dim() != 4 or w.dim() != 4:
+        raise ValueError("expected activations [B,C,H,W] and weights [G*Cq,Cq,KH,KW]")
+    B, C, H, W = act.shape
+    if C % G != 0:
+        raise ValueError(f"channels {C} not divisible by groups {G}")
+    Cq = C // G
+    if w.shape[0] != C or w.shape[1] != Cq:
+        raise ValueError(f"weights {tuple(w.shape)} do not match C={C}, Cq={Cq}")
+    if act.device != w.device:
+        raise ValueError("activations and weights on different devices")
+    return B, Cq, H, W, w.shape[2], w.shape[3]
+
+
+def canonicalize(w_stored, G, orient):
+    """State-dict form -> TL-canonical (fastflow.py:79-84).  The flip is an involution, so the same call
+    maps canonical gradients back to stored form."""
+    _require_device(w_stored, "weights")
+    out = torch.empty_like(w_stored)
+    Cq = w_stored.shape[0] // G
+    with torch.cuda.device(w_stored.device):
+        st = _lib.lib().finc_canonicalize_weights_f32(w_stored.data_ptr(), out.data_ptr(), G, Cq, w_stored.shape[2],
+                                                      w_stored.shape[3], orient, _stream_ptr(w_stored))
+    _lib.check(st, "finc_canonicalize_weights_f32")
+    return out
+
+
+def check_invariant(w_canon, G):
+    """Raises if the corner tap is not unit lower triangular (layers/conv.py:63-70).  Synchronises."""
+    _require_device(w_canon, "weights")
+    with torch.cuda.device(w_canon.device):
+        st = _lib.lib().finc_check_invariant_f32(w_canon.data_ptr(), G, w_canon.shape[0] // G, w_canon.shape[2],
+                                                 w_canon.shape[3], _stream_ptr(w_canon))
+    _lib.check(st, "finc_check_invariant_f32")
+
+
+def _run(fn_name, act, w_canon, G, orient, algo, out):
+    _require_device(act, "input")
+    _require_device(w_canon, "kernel")
+    B, Cq, H, W, KH, KW = _dims(act, w_canon, G)
+    if out is None:
+        out = torch.empty_like(act)
+    else:
+        _require_device(out, "output")
+        if out.shape != act.shape or out.device != act.device:
+            raise ValueError("output must match input in shape and device")
+    if act.numel() == 0:
+        return out
+    L = _lib.lib()
+    nbytes = L.finc_workspace_bytes(G, Cq, KH, KW)
+    with torch.cuda.device(act.device):
+        ws = _workspace(act.device, nbytes)
+        st = getattr(L, fn_name)(act.data_ptr(), w_canon.data_ptr(), out.data_ptr(), B, G, Cq, H, W, KH, KW, orient,
+                                 _lib.ALGO[algo], ws.data_ptr(), ws.numel(), _stream_ptr(act))
+    _lib.check(st, fn_name)
+    return out
+
+
+def finc_inverse(z, w_canon, G=4, orient=ORIENT_FASTFLOW, algo="auto", out=None):
+    """x = inverse(z) for G groups with per-group orientation; one asynchronous launch on the current stream."""
+    return _run("finc_inverse_f32", z, w_canon, G, orient, algo, out)
+
+
+def finc_forward(x, w_canon, G=4, orient=ORIENT_FASTFLOW, algo="auto", out=None):
+    """z = forward(x); the layer's logdet is identically 0 (layers/conv.py:106)."""
+    return _run("finc_forward_f32", x, w_canon, G, orient, algo, out)
+
+
+def finc_backward(grad_z, x, w_canon, G, orient, need_gx=True, need_gw=True):
+    _require_device(grad_z, "grad_output")
+    B, Cq, H, W, KH, KW = _dims(grad_z, w_canon, G)
+    gx = torch.empty_like(grad_z) if need_gx else None
+    gw = torch.empty_like(w_canon) if need_gw else None
+    if grad_z.numel() == 0:
+        if gw is not None:
+            gw.zero_()
+        return gx, gw
+    with torch.cuda.device(grad_z.device):
+        st = _lib.lib().finc_backward_f32(grad_z.data_ptr(), x.data_ptr() if x is not None else None,
+                                          w_canon.data_ptr(), gx.data_ptr() if gx is not None else None,
+                                          gw.data_ptr() if gw is not None else None, B, G, Cq, H, W, KH, KW, orient,
+                                          _stream_ptr(grad_z))
+    _lib.check(st, "finc_backward_f32")
+    return gx, gw
+
+
+def inverse(input, kernel, output):
+    """Drop-in for the reference extension's `inverse` (cinc_cuda_level2.cpp:19-32).
+
+    input  [B,C,H,W]        already flipped to TL-canonical per group by the caller (fastflow.py:85-90)
+    kernel [G*Cq,Cq,KH,KW]  TL-canonical (fastflow.py:79-84); G = kernel.shape[0] // kernel.shape[1]
+    output [B,C,H,W]        written in place; a one-element list aliasing it is returned.
+    """
+    for t, n in ((input, "input"), (kernel, "kernel"), (output, "output")):
+        _require_device(t, n)
+    G = kernel.shape[0] // kernel.shape[1]
+    finc_inverse(input, kernel, G=G, orient=0, out=output)
+    return [output]
+
+
+class PackedWeights:
+    """Sampling-time cache for one weight version: the TL-canonical bank (fastflow.py:79-84, done once instead of
+    every call), its invariant check, and the packed MFMA fragments (finc_pack_inverse_weights_f32), so that a
+    sampling step is exactly one kernel launch (finc_inverse_packed_f32).  Rebuilt when a source tensor changes."""
+
+    def __init__(self):
+        self.key = None
+        self.w_canon = None
+        self.packed_inv = None
+
+    def get(self, weights, G, orient):
+        key = tuple((w.data_ptr(), w._version) for w in weights) + (orient,)
+        if key != self.key:
+            ws = torch.cat([w.detach() for w in weights], dim=0).contiguous()
+            self.w_canon = canonicalize(ws, G, orient)
+            check_invariant(self.w_canon, G)
+            self.packed_inv = None
+            self.key = key
+        return self.w_canon
+
+    def inverse(self, z, weights, G, orient, out=None):
+        w_canon = self.get(weights, G, orient)
+        _require_device(z, "input")
+        B, Cq, H, W, KH, KW = _dims(z, w_canon, G)
+        L = _lib.lib()
+        if z.numel() == 0 or L.finc_inverse_algo_for(Cq, H, W, KH, KW) != _lib.ALGO["mfma"]:
+            return finc_inverse(z, w_canon, G, orient, out=out)
+        with torch.cuda.device(z.device):
+            if self.packed_inv is None:
+                self.packed_inv = torch.empty(L.finc_workspace_bytes(G, Cq, KH, KW), dtype=torch.uint8, device=z.device)
+                _lib.check(L.finc_pack_inverse_weights_f32(w_canon.data_ptr(), self.packed_inv.data_ptr(), G, Cq, KH, KW,
+                                                           _stream_ptr(z)), "finc_pack_inverse_weights_f32")
+            if out is None:
+                out = torch.empty_like(z)
+            _lib.check(L.finc_inverse_packed_f32(z.data_ptr(), self.packed_inv.data_ptr(), out.data_ptr(), B, G, Cq, H, W,
+                                                 KH, KW, orient, _stream_ptr(z)), "finc_inverse_packed_f32")
+        return out
+
+
+class _FincConvFunction(torch.autograd.Function):
+    """The autograd.Function underneath FastFlowUnit / PaddedConv2d.forward.  Backward applies the
+    corner-tap mask in-kernel, so `model.apply(clear_grad)` (train/experiment.py:16-18) is a no-op on it."""
+
+    @staticmethod
+    def forward(ctx, x, w_stored, G, orient):
+        w_canon = canonicalize(w_stored.contiguous(), G, orient)
+        ctx.save_for_backward(x, w_canon)
+        ctx.G, ctx.orient = G, orient
+        return finc_forward(x.contiguous(), w_canon, G, orient)
+
+    @staticmethod
+    def backward(ctx, grad_z):
+        x, w_canon = ctx.saved_tensors
+        gx, gw = finc_backward(grad_z.contiguous(), x.contiguous(), w_canon, ctx.G, ctx.orient,
+                               need_gx=ctx.needs_input_grad[0], need_gw=ctx.needs_input_grad[1])
+        if gw is not None:
+            gw = canonicalize(gw, ctx.G, ctx.orient)  # canonical -> stored orientation
+        return gx, gw, None, None
+
+
+def conv_forward(x, w_stored, G, orient):
+    return _FincConvFunction.apply(x, w_stored, G, orient)

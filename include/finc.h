@@ -1,0 +1,140 @@
+/*
+ * finc.h -- C ABI of the MI355X-native FInC Flow hot path (libfinc_hip.so).
+ *
+ * This is the drop-in boundary.  It replaces the reference's one native entry
+ * point
+ *
+ *     m.def("inverse", &cinc_inverse_level2)            cinc_cuda_level2.cpp:30-32
+ *     std::vector<Tensor> cinc_inverse_level2(Tensor input  [B,C,H,W],
+ *                                             Tensor kernel [G*Cq,Cq,KH,KW],
+ *                                             Tensor output [B,C,H,W])   :19-28
+ *
+ * and the cuDNN convolution behind PaddedConv2d.forward (layers/conv.py:102-107)
+ * with plain-pointer functions: no torch types, no global state besides a
+ * per-process table of kernel attributes.  Every function is stream-ordered
+ * and asynchronous unless its comment says otherwise; every pointer is a
+ * DEVICE pointer unless its name starts with `h_`.
+ *
+ * Data layout (the reference's own, fastflow.py:78-100):
+ *   activations  fp32 NCHW contiguous, C = G*Cq; group g owns channels
+ *                [g*Cq, (g+1)*Cq).
+ *   w_canon      fp32 [G*Cq][Cq][KH][KW], TL-canonical -- exactly the `kernel`
+ *                tensor of the reference op (fastflow.py:79-84).
+ *   w_stored     the same shape in state-dict form: each group's bank flipped
+ *                per its order (layers/conv.py:72-79).
+ *   orient       2 bits per group g at bits [2g, 2g+1]: bit0 = W-flipped (TR),
+ *                bit1 = H-flipped (BL), both = BR.  FastFlowUnit = 0xE4
+ *                (TL,TR,BL,BR; fastflow.py:24-27).  The reference flips the
+ *                activation chunks in PyTorch around the op (fastflow.py:85-100);
+ *                here the kernels index the flipped pixel directly, so the
+ *                caller passes the un-flipped tensors.
+ *
+ * Invariant (layers/conv.py:63-70): w_canon[c][c][KH-1][KW-1] == 1 and
+ * w_canon[c][kc>c][KH-1][KW-1] == 0.  finc_check_invariant_f32 verifies it.
+ */
+#ifndef FINC_H
+#define FINC_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void *finc_stream_t; /* a hipStream_t; NULL = the default stream */
+
+enum finc_status {
+    FINC_OK = 0,
+    FINC_ERR_NULL_POINTER = 1,
+    FINC_ERR_BAD_DIMS = 2,     /* non-positive dims, G > 16, Cq > FINC_MAX_CQ ... */
+    FINC_ERR_UNSUPPORTED = 3,  /* the requested algo has no instantiation for this shape */
+    FINC_ERR_WORKSPACE = 4,    /* workspace NULL or smaller than finc_workspace_bytes() */
+    FINC_ERR_LAUNCH = 5,       /* a HIP call failed; see finc_last_hip_error() */
+    FINC_ERR_INVARIANT = 6,    /* unit-lower-triangular corner tap violated */
+    FINC_ERR_ALIGNMENT = 7     /* a pointer is not 4-byte (fp32) aligned */
+};
+
+enum finc_algo {
+    FINC_ALGO_AUTO = 0,   /* fastest kernel that supports the shape */
+    FINC_ALGO_STRICT = 1, /* reference visitation + term order; inverse is bit-exact with the
+                             fp32 CPU restatement (cinc_cuda_kernel_level2.cu:59-72)        */
+    FINC_ALGO_MFMA = 2    /* wavefront-per-(image,group) MFMA kernel; FINC_ERR_UNSUPPORTED
+                             when the shape has no instantiation                             */
+};
+
+#define FINC_MAX_GROUPS 16
+#define FINC_MAX_CQ 256
+#define FINC_ORIENT_FASTFLOW 0xE4u
+
+int finc_version(void);
+const char *finc_status_string(int status);
+/* hipGetErrorString of the last failing HIP call on this thread (never NULL). */
+const char *finc_last_hip_error(void);
+
+/* Replaces fastflow.py:79-84 (four torch.flip + cat).  w_stored -> w_canon; may not alias. */
+int finc_canonicalize_weights_f32(const float *w_stored, float *w_canon, int G, int Cq, int KH, int KW,
+                                  unsigned orient, finc_stream_t stream);
+
+/* SYNCHRONOUS (one 4-byte D2H copy on `stream`).  Returns FINC_OK or FINC_ERR_INVARIANT.
+ * Call once per weight version, not per step. */
+int finc_check_invariant_f32(const float *w_canon, int G, int Cq, int KH, int KW, finc_stream_t stream);
+
+/* Scratch the AUTO/MFMA algos need (packed filter fragments); 0 is never returned. */
+size_t finc_workspace_bytes(int G, int Cq, int KH, int KW);
+
+/* Which algo FINC_ALGO_AUTO resolves to for this shape (FINC_ALGO_STRICT or FINC_ALGO_MFMA). */
+int finc_inverse_algo_for(int Cq, int H, int W, int KH, int KW);
+int finc_forward_algo_for(int Cq, int H, int W, int KH, int KW);
+
+/*
+ * x = inverse(z): the reference op `inverse(input=z, kernel=w_canon, output=x)`
+ * (cinc_cuda_level2.cpp:19-28 -> cinc_cuda_kernel_level2.cu:77-136) including the
+ * chunk flips FastFlowUnit.reverse_level2 wraps around it (fastflow.py:85-100).
+ * Unlike the reference: `x` need not be zero-filled, B is not limited to 1024,
+ * one launch per call instead of (H+W-1)*Cq launches + device syncs.
+ * z and x may not alias.
+ */
+int finc_inverse_f32(const float *z, const float *w_canon, float *x, int B, int G, int Cq, int H, int W,
+                     int KH, int KW, unsigned orient, int algo, void *workspace, size_t workspace_bytes,
+                     finc_stream_t stream);
+
+/*
+ * z = forward(x): FastFlowUnit.forward (fastflow.py:31-50) = per group
+ * F.pad on one corner + bias-free cross-correlation (layers/conv.py:102-107),
+ * without the pad/chunk/cat copies.  logdet of this layer is identically 0
+ * (layers/conv.py:106,220-221), so nothing is written for it.
+ * x and z may not alias.
+ */
+int finc_forward_f32(const float *x, const float *w_canon, float *z, int B, int G, int Cq, int H, int W,
+                     int KH, int KW, unsigned orient, int algo, void *workspace, size_t workspace_bytes,
+                     finc_stream_t stream);
+
+/*
+ * Split form of the two calls above for callers that run many steps on one
+ * weight version (sampling): pack once, then launch with the packed buffer.
+ * `packed` must hold finc_workspace_bytes() bytes.
+ */
+int finc_pack_inverse_weights_f32(const float *w_canon, void *packed, int G, int Cq, int KH, int KW,
+                                  finc_stream_t stream);
+int finc_pack_forward_weights_f32(const float *w_canon, void *packed, int G, int Cq, int KH, int KW,
+                                  finc_stream_t stream);
+int finc_inverse_packed_f32(const float *z, const void *packed, float *x, int B, int G, int Cq, int H, int W,
+                            int KH, int KW, unsigned orient, finc_stream_t stream);
+int finc_forward_packed_f32(const float *x, const void *packed, float *z, int B, int G, int Cq, int H, int W,
+                            int KH, int KW, unsigned orient, finc_stream_t stream);
+
+/*
+ * Backward of the forward conv (replaces autograd through cuDNN,
+ * layers/conv.py:105, plus PaddedConv2d.reset_gradients, layers/conv.py:98-99).
+ *   grad_x = conv_transpose(grad_z, w)      (same corner geometry, mirrored)
+ *   grad_w_canon[o][i][kh][kw] = sum_{b,h,w} grad_z[b,o,h,w] * x[b,i,h-(KH-1-kh),w-(KW-1-kw)]
+ * with the corner-tap mask applied in-kernel (masked entries are written as 0).
+ * grad_w is OVERWRITTEN (not accumulated).  Either output may be NULL to skip it.
+ */
+int finc_backward_f32(const float *grad_z, const float *x, const float *w_canon, float *grad_x, float *grad_w_canon,
+                      int B, int G, int Cq, int H, int W, int KH, int KW, unsigned orient, finc_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FINC_H */

@@ -1,0 +1,74 @@
+"""The C-ABI library loads and exports every symbol include/finc.h declares (no GPU, no compute calls)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+from helpers import REPO
+from fincflow_amd import _lib
+
+
+def header_symbols():
+    text = open(os.path.join(REPO, "include", "finc.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(finc_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exists_and_loads():
+    assert os.path.exists(_lib.LIB_PATH), "run __graft_entry__.build() first"
+    assert _lib.lib().finc_version() >= 100
+
+
+def test_every_declared_symbol_is_exported():
+    syms = header_symbols()
+    assert len(syms) >= 15
+    raw = ctypes.CDLL(_lib.LIB_PATH)
+    for s in syms:
+        assert hasattr(raw, s), f"{s} declared in include/finc.h but not exported"
+    assert sorted(_lib.SYMBOLS) == syms
+
+
+def test_status_strings():
+    L = _lib.lib()
+    assert L.finc_status_string(0) == b"ok"
+    seen = {L.finc_status_string(i) for i in range(8)}
+    assert len(seen) == 8 and b"unknown status" not in seen
+    assert L.finc_status_string(99) == b"unknown status"
+
+
+def test_algo_selection_is_host_side_and_consistent():
+    L = _lib.lib()
+    MFMA, STRICT = 2, 1
+    # the named configs: c2 (Cq=12, 32x32), c3 (Cq=24, 64x64) -> MFMA wavefront kernel
+    assert L.finc_inverse_algo_for(12, 32, 32, 3, 3) == MFMA
+    assert L.finc_inverse_algo_for(24, 64, 64, 3, 3) == MFMA
+    assert L.finc_forward_algo_for(24, 64, 64, 3, 3) == MFMA
+    # c5 (Cq=48, 5x5): fragments do not fit the register file of one wave -> reference-order kernel
+    assert L.finc_inverse_algo_for(48, 128, 128, 5, 5) == STRICT
+    # W not a multiple of 4 -> reference-order kernel
+    assert L.finc_inverse_algo_for(24, 64, 63, 3, 3) == STRICT
+    assert L.finc_workspace_bytes(4, 24, 3, 3) >= 4 * 108 * 64 * 4
+    assert L.finc_workspace_bytes(4, 48, 5, 5) >= 256
+
+
+def test_argument_validation_without_touching_the_gpu():
+    """NULL pointers and bad dims are rejected before any HIP call."""
+    L = _lib.lib()
+    assert L.finc_inverse_f32(None, None, None, 1, 4, 1, 8, 8, 3, 3, 0xE4, 0, None, 0, None) == 1
+    one = ctypes.c_void_p(16)
+    assert L.finc_inverse_f32(one, one, ctypes.c_void_p(32), 0, 4, 1, 8, 8, 3, 3, 0xE4, 0, None, 0, None) == 2
+    assert L.finc_inverse_f32(one, one, ctypes.c_void_p(32), 1, 17, 1, 8, 8, 3, 3, 0xE4, 0, None, 0, None) == 2
+    assert L.finc_inverse_f32(ctypes.c_void_p(18), one, ctypes.c_void_p(32), 1, 4, 1, 8, 8, 3, 3, 0xE4, 0, None, 0, None) == 7
+    assert L.finc_forward_f32(one, one, one, 1, 4, 1, 8, 8, 3, 3, 0xE4, 0, None, 0, None) == 2  # in == out
+    # MFMA algo without a workspace
+    assert L.finc_inverse_f32(one, one, ctypes.c_void_p(32), 1, 4, 24, 64, 64, 3, 3, 0xE4, 2, None, 0, None) == 4
+    # MFMA algo on a shape it has no instantiation for
+    assert L.finc_inverse_f32(one, one, ctypes.c_void_p(32), 1, 4, 48, 128, 128, 5, 5, 0xE4, 2, one, 1 << 30, None) == 3
+
+
+def test_check_raises_python_exceptions():
+    with pytest.raises(ValueError):
+        _lib.check(2, "x")
+    with pytest.raises(_lib.FincError):
+        _lib.check(3, "x")

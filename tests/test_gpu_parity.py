@@ -1,0 +1,322 @@
+"""Parity of the HIP path (through the C ABI) with the oracle and the reference's golden vectors.
+
+Run on the MI355X box: python -m pytest tests -m gpu.  Nothing here reads /root/reference.
+Tolerances:
+  * algo="strict" inverse: BIT-EXACT with the fp32 reference-order restatement
+    (oracle.inverse_f32 == the reference's reverse_python / solve_mc.py).
+  * algo="mfma" / "auto" inverse and every forward: <= 1e-5 relative fp32 error
+    (max|a-b| / max|b|), BASELINE.json's tolerance, against the reference outputs.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle
+from helpers import ORDER_BITS, ORIENT_FASTFLOW, golden, golden_names, rel_err, unit_stored_weights
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    from fincflow_amd import _lib
+    _lib.lib()  # fail loudly if the HIP library is missing
+    return torch.device("cuda:0")
+
+
+def t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+def canon(ws, G, orient, dev):
+    from fincflow_amd import ops
+    return ops.canonicalize(t(ws, dev), G, orient)
+
+
+UNIT_CASES = golden_names("unit_")
+PADDED_CASES = golden_names("padded_")
+LITERAL_CASES = golden_names("literal_")
+
+
+@pytest.mark.parametrize("name", UNIT_CASES)
+def test_canonicalize_matches_oracle(name, dev):
+    g = golden(name)
+    ws = unit_stored_weights(g)
+    wc = canon(ws, 4, ORIENT_FASTFLOW, dev)
+    assert np.array_equal(wc.cpu().numpy(), oracle.canonicalize(ws, 4, ORIENT_FASTFLOW))
+
+
+@pytest.mark.parametrize("name", UNIT_CASES)
+def test_unit_inverse_strict_bit_exact(name, dev):
+    from fincflow_amd import ops
+    g = golden(name)
+    ws = unit_stored_weights(g)
+    wc = canon(ws, 4, ORIENT_FASTFLOW, dev)
+    out = ops.finc_inverse(t(g["z"], dev), wc, 4, ORIENT_FASTFLOW, algo="strict").cpu().numpy()
+    ref = g["x_rev_python_fp32"] if "x_rev_python_fp32" in g else \
+        oracle.inverse_f32(g["z"], oracle.canonicalize(ws, 4, ORIENT_FASTFLOW), 4, ORIENT_FASTFLOW, nthreads=8)
+    assert np.array_equal(out, ref)
+
+
+@pytest.mark.parametrize("name", UNIT_CASES)
+def test_unit_inverse_auto_within_tolerance(name, dev):
+    from fincflow_amd import ops
+    g = golden(name)
+    wc = canon(unit_stored_weights(g), 4, ORIENT_FASTFLOW, dev)
+    out = ops.finc_inverse(t(g["z"], dev), wc, 4, ORIENT_FASTFLOW, algo="auto").cpu().numpy()
+    tol = 1e-3 if "heavy" in name else TOL  # see tests/test_oracle.py::test_unit_round_trip
+    assert rel_err(out, g["x_rev_cython"]) <= tol
+    assert rel_err(out, g["x"]) <= 10 * tol
+
+
+@pytest.mark.parametrize("name", UNIT_CASES)
+@pytest.mark.parametrize("algo", ["strict", "auto"])
+def test_unit_forward(name, algo, dev):
+    from fincflow_amd import ops
+    g = golden(name)
+    wc = canon(unit_stored_weights(g), 4, ORIENT_FASTFLOW, dev)
+    out = ops.finc_forward(t(g["x"], dev), wc, 4, ORIENT_FASTFLOW, algo=algo).cpu().numpy()
+    assert rel_err(out, g["z"]) <= TOL
+
+
+def test_mfma_path_is_actually_taken(dev):
+    """The named configs must run the MFMA wavefront kernel, and asking for it explicitly must agree with auto."""
+    from fincflow_amd import _lib, ops
+    L = _lib.lib()
+    assert L.finc_inverse_algo_for(12, 32, 32, 3, 3) == 2 and L.finc_forward_algo_for(24, 64, 64, 3, 3) == 2
+    g = golden("unit_B2_C48_32x32_k3")
+    wc = canon(unit_stored_weights(g), 4, ORIENT_FASTFLOW, dev)
+    a = ops.finc_inverse(t(g["z"], dev), wc, algo="mfma")
+    b = ops.finc_inverse(t(g["z"], dev), wc, algo="auto")
+    assert torch.equal(a, b)
+    with pytest.raises(_lib.FincError):
+        ops.finc_inverse(torch.randn(1, 4, 8, 7, device=dev), wc[:4, :1].contiguous(), 4, algo="mfma")
+
+
+@pytest.mark.parametrize("name", PADDED_CASES)
+def test_padded_every_order(name, dev):
+    from fincflow_amd import ops
+    g = golden(name)
+    o = ORDER_BITS[str(g["order"])]
+    wc = canon(g["w"], 1, o, dev)
+    z = t(g["z"], dev)
+    strict = ops.finc_inverse(z, wc, 1, o, algo="strict").cpu().numpy()
+    if "x_rev_python_fp32" in g:
+        assert np.array_equal(strict, g["x_rev_python_fp32"])
+    auto = ops.finc_inverse(z, wc, 1, o, algo="auto").cpu().numpy()
+    assert rel_err(auto, g["x_rev_cython"]) <= TOL
+    assert rel_err(strict, g["x_rev_cython"]) <= TOL
+    if "zdirect" not in name:
+        for algo in ("strict", "auto"):
+            assert rel_err(ops.finc_forward(t(g["x"], dev), wc, 1, o, algo=algo).cpu().numpy(), g["z"]) <= TOL
+
+
+@pytest.mark.parametrize("name", LITERAL_CASES)
+def test_literal_known_answers(name, dev):
+    """cuda/cinc_cuda/test_cuda_kernel.py:3-56, fastflow/test_examples.py:6-25,54-73 -- exact (small integers)."""
+    from fincflow_amd import ops
+    g = golden(name)
+    o = ORDER_BITS[str(g["order"])]
+    wc = canon(g["w"], 1, o, dev)
+    inp = t(g["inp"], dev)
+    if bool(g["reverse_first"]):
+        out = ops.finc_inverse(inp, wc, 1, o)
+        back = ops.finc_forward(out, wc, 1, o)
+    else:
+        out = ops.finc_forward(inp, wc, 1, o)
+        back = ops.finc_inverse(out, wc, 1, o)
+    assert np.array_equal(out.cpu().numpy(), g["out"])
+    assert np.array_equal(back.cpu().numpy(), g["inp"])  # util.py:36 re-convolution check
+
+
+def test_reference_op_signature(dev):
+    """`inverse(input, kernel, output) -> [output]` (cinc_cuda_level2.cpp:19-32): in place, alias returned,
+    RuntimeError on non-contiguous, no zero-fill requirement."""
+    from fincflow_amd import ops
+    g = golden("unit_c1_B2_C4_8x8_k3")
+    ws = unit_stored_weights(g)
+    kernel = canon(ws, 4, ORIENT_FASTFLOW, dev)
+    # the reference flips chunks 1..3 before the call (fastflow.py:85-90)
+    z = torch.from_numpy(g["z"])
+    zc = torch.cat([z[:, 0:1], z[:, 1:2].flip(3), z[:, 2:3].flip(2), z[:, 3:4].flip(2, 3)], 1).contiguous().to(dev)
+    y = torch.full_like(zc, float("nan"))  # NOT zero-filled
+    res = ops.inverse(zc, kernel, y)
+    assert isinstance(res, list) and res[0].data_ptr() == y.data_ptr()
+    yc = y.cpu()
+    x = torch.cat([yc[:, 0:1], yc[:, 1:2].flip(3), yc[:, 2:3].flip(2), yc[:, 3:4].flip(2, 3)], 1).numpy()
+    assert rel_err(x, g["x_rev_cython"]) <= TOL
+    with pytest.raises(RuntimeError, match="contiguous"):
+        ops.inverse(zc.transpose(2, 3), kernel, y)
+
+
+def test_invariant_violation_raises(dev):
+    from fincflow_amd import _lib, ops
+    ws = oracle.make_stored_weights(4, 3, 3, 3)
+    wc = canon(ws, 4, ORIENT_FASTFLOW, dev)
+    ops.check_invariant(wc, 4)
+    bad = wc.clone()
+    bad[4, 1, -1, -1] = 0.9  # group 1, c=1: diagonal != 1
+    with pytest.raises(_lib.FincError, match="unit lower triangular"):
+        ops.check_invariant(bad, 4)
+    bad = wc.clone()
+    bad[0, 2, -1, -1] = 0.1  # above the diagonal
+    with pytest.raises(_lib.FincError):
+        ops.check_invariant(bad, 4)
+
+
+# ------------------------------------------------------------------ modules
+@pytest.mark.parametrize("name", ["unit_c1_B2_C4_8x8_k3", "unit_B2_C48_32x32_k3", "unit_B1_C8_10x14_k3x5"])
+def test_fastflowunit_module(name, dev):
+    """Drop-in module with the reference's state dict: forward == golden z, reverse == golden inverse."""
+    from fincflow_amd import FastFlowUnit
+    g = golden(name)
+    C = g["x"].shape[1]
+    unit = FastFlowUnit(C, C, tuple(int(k) for k in g["kernel_size"]))
+    unit.load_state_dict({f"conv_{o}.conv.weight": torch.from_numpy(g[f"w_{o}"]) for o in ("tl", "tr", "bl", "br")})
+    unit = unit.to(dev)
+    z, ld = unit(t(g["x"], dev))
+    assert ld == 0.0 and rel_err(z.detach().cpu().numpy(), g["z"]) <= TOL
+    xr = unit.reverse(t(g["z"], dev))
+    assert isinstance(xr, torch.Tensor) and rel_err(xr.cpu().numpy(), g["x_rev_cython"]) <= TOL
+    x1 = unit.reverse_level1(t(g["z"], dev))
+    assert rel_err(x1.cpu().numpy(), g["x_rev_cython"]) <= TOL
+
+
+def test_padded_module_and_sequential(dev):
+    from fincflow_amd import FastFlowUnit, FlowSequential, PaddedConv2d
+    from fincflow_amd.layers import StandardNormal
+    g = golden("padded_BR_B1_C5_9x9_k2x3_zdirect")
+    m = PaddedConv2d(5, 5, (2, 3), order="BR")
+    m.load_state_dict({"conv.weight": torch.from_numpy(g["w"])})
+    m = m.to(dev)
+    y, ld = m.reverse(t(g["z"], dev))
+    assert ld == 0 and rel_err(y.cpu().numpy(), g["x_rev_cython"]) <= TOL
+    torch.manual_seed(1)
+    seq = FlowSequential(StandardNormal((8, 16, 16)), FastFlowUnit(8, 8, 3), FastFlowUnit(8, 8, 3)).to(dev)
+    x = torch.randn(3, 8, 16, 16, device=dev)
+    zz, logp = seq(x)
+    assert logp.shape == (3,)
+    assert rel_err(seq.reconstruct(x).cpu().numpy(), x.cpu().numpy()) <= 1e-5
+    assert seq.sample(2).shape == (2, 8, 16, 16)
+
+
+def test_weight_update_invalidates_cache(dev):
+    from fincflow_amd import FastFlowUnit
+    torch.manual_seed(2)
+    unit = FastFlowUnit(8, 8, 3).to(dev)
+    x = torch.randn(2, 8, 8, 8, device=dev)
+    z, _ = unit(x)
+    assert rel_err(unit.reverse(z).cpu().numpy(), x.cpu().numpy()) <= 1e-5
+    with torch.no_grad():
+        unit.conv_tr.conv.weight[0, 1, 0, 0] += 0.25  # a free tap
+    z2, _ = unit(x)
+    assert not torch.equal(z, z2)
+    assert rel_err(unit.reverse(z2).cpu().numpy(), x.cpu().numpy()) <= 1e-5
+
+
+def test_autograd_matches_torch_conv(dev):
+    """Backward of the forward conv against autograd through F.pad + F.conv2d on the CPU,
+    including the in-kernel gradient mask (layers/conv.py:98-99)."""
+    import torch.nn.functional as F
+    from fincflow_amd import FastFlowUnit
+    torch.manual_seed(3)
+    unit = FastFlowUnit(12, 12, 3).to(dev)
+    x = torch.randn(2, 12, 9, 12, device=dev, requires_grad=True)
+    z, _ = unit(x)
+    gz = torch.randn_like(z)
+    z.backward(gz)
+    # CPU twin, written the way the reference does it (fastflow.py:31-50, layers/conv.py:102-107)
+    xc = x.detach().cpu().requires_grad_(True)
+    outs, ws = [], []
+    for m, chunk in zip((unit.conv_tl, unit.conv_tr, unit.conv_bl, unit.conv_br), torch.chunk(xc, 4, 1)):
+        w = m.conv.weight.detach().cpu().requires_grad_(True)
+        ws.append(w)
+        outs.append(F.conv2d(F.pad(chunk, m.pad), w))
+    zc = torch.cat(outs, 1)
+    assert rel_err(z.detach().cpu().numpy(), zc.detach().numpy()) <= TOL
+    zc.backward(gz.cpu())
+    assert rel_err(x.grad.cpu().numpy(), xc.grad.numpy()) <= TOL
+    for m, w in zip((unit.conv_tl, unit.conv_tr, unit.conv_bl, unit.conv_br), ws):
+        expect = (w.grad * m.mask).numpy()
+        got = m.conv.weight.grad.cpu().numpy()
+        assert rel_err(got, expect) <= 1e-4  # B*H*W-term fp32 reductions in different orders
+        assert np.all(got[m.mask.numpy() == 0] == 0)
+
+
+# ------------------------------------------------------------------ edge cases and full sizes
+@pytest.mark.parametrize("shape", [(1, 4, 1, 4, 3, 3), (1, 4, 4, 1, 3, 3), (3, 8, 5, 3, 2, 2), (2, 4, 3, 40, 3, 3),
+                                   (2, 4, 40, 4, 3, 3), (1, 20, 17, 12, 3, 3), (2, 16, 6, 8, 1, 3), (2, 16, 8, 8, 3, 1),
+                                   (1, 4, 2, 2, 3, 3)])
+def test_ragged_and_degenerate_shapes(shape, dev):
+    """Sizes smaller than the filter, 1-pixel rows/columns, 1xK and Kx1 filters, H>W and H<W: strict is
+    bit-exact with the oracle, auto stays within tolerance, whichever kernel it resolves to."""
+    from fincflow_amd import ops
+    B, C, H, W, KH, KW = shape
+    rng = np.random.default_rng(sum(shape))
+    ws = oracle.make_stored_weights(4, C // 4, KH, KW, seed=sum(shape))
+    wco = oracle.canonicalize(ws, 4, ORIENT_FASTFLOW)
+    z = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    wc = canon(ws, 4, ORIENT_FASTFLOW, dev)
+    ref32 = oracle.inverse_f32(z, wco)
+    assert np.array_equal(ops.finc_inverse(t(z, dev), wc, algo="strict").cpu().numpy(), ref32)
+    auto = ops.finc_inverse(t(z, dev), wc, algo="auto").cpu().numpy()
+    assert rel_err(auto, oracle.inverse_via_f64(z, wco)) <= TOL
+    for algo in ("strict", "auto"):
+        assert rel_err(ops.finc_forward(t(z, dev), wc, algo=algo).cpu().numpy(), oracle.forward_f32(z, wco)) <= TOL
+
+
+def test_empty_batch(dev):
+    from fincflow_amd import ops
+    wc = canon(oracle.make_stored_weights(4, 2, 3, 3), 4, ORIENT_FASTFLOW, dev)
+    out = ops.finc_inverse(torch.empty(0, 8, 8, 8, device=dev), wc)
+    assert out.shape == (0, 8, 8, 8)
+
+
+@pytest.mark.parametrize("cfg", [("c2", 64, 48, 32, 32, 3), ("c3", 256, 96, 64, 64, 3)])
+def test_full_size_properties(cfg, dev):
+    """BASELINE configs[1] and [2] at full batch: size-independent properties --
+    (a) round trip inverse(forward(x)) == x, (b) residual forward(inverse(z)) == z for z ~ N(0,1) (the sampling
+    distribution, train/losses.py:42-45), (c) linearity of the inverse, (d) images are independent (the batch
+    split of 8e): solving a slice alone gives the same bits as solving it inside the batch,
+    (e) a sample of images agrees with the CPU oracle."""
+    from fincflow_amd import ops
+    name, B, C, H, W, K = cfg
+    torch.manual_seed(7)
+    ws = oracle.make_stored_weights(4, C // 4, K, K)
+    wc = canon(ws, 4, ORIENT_FASTFLOW, dev)
+    x = torch.randn(B, C, H, W, device=dev)
+    z = ops.finc_forward(x, wc)
+    xr = ops.finc_inverse(z, wc)
+    assert rel_err(xr.cpu().numpy(), x.cpu().numpy()) <= TOL                      # (a)
+    zs = torch.randn(B, C, H, W, device=dev)
+    xs = ops.finc_inverse(zs, wc)
+    assert rel_err(ops.finc_forward(xs, wc).cpu().numpy(), zs.cpu().numpy()) <= TOL  # (b)
+    lin = ops.finc_inverse(z + 0.5 * zs, wc)
+    assert rel_err(lin.cpu().numpy(), (xr + 0.5 * xs).cpu().numpy()) <= TOL       # (c)
+    sl = slice(B // 2, B // 2 + 3)
+    assert torch.equal(ops.finc_inverse(zs[sl].contiguous(), wc), xs[sl])         # (d)
+    pick = [0, B // 2, B - 1]
+    wco = oracle.canonicalize(ws, 4, ORIENT_FASTFLOW)
+    ref = oracle.inverse_via_f64(zs[pick].cpu().numpy(), wco, nthreads=8)
+    assert rel_err(xs[pick].cpu().numpy(), ref) <= TOL                            # (e)
+    refz = oracle.forward_f32(x[pick].cpu().numpy(), wco, nthreads=8)
+    assert rel_err(z[pick].cpu().numpy(), refz) <= TOL
+
+
+def test_c5_shape_one_image_strict_fallback(dev):
+    """configs[4] (5x5, C=192, 128x128): no MFMA instantiation yet -> reference-order kernel.  One image,
+    checked against the oracle on a crop-independent property (round trip) and directly on one group."""
+    from fincflow_amd import _lib, ops
+    assert _lib.lib().finc_inverse_algo_for(48, 128, 128, 5, 5) == 1
+    # std 0.02, not 0.05: at 5x5 / Cq=48 the init std of layers/conv.py:64 makes the inverse itself unstable
+    # (|inverse(N(0,1))| reaches 3e7 by 48x48 in fp64); 0.02 gives the same operator norm as 3x3 / Cq=24.
+    ws = oracle.make_stored_weights(4, 48, 5, 5, std=0.02)
+    wc = canon(ws, 4, ORIENT_FASTFLOW, dev)
+    torch.manual_seed(9)
+    x = torch.randn(1, 192, 128, 128, device=dev)
+    z = ops.finc_forward(x, wc)
+    xr = ops.finc_inverse(z, wc)
+    assert rel_err(xr.cpu().numpy(), x.cpu().numpy()) <= TOL

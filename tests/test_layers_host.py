@@ -1,0 +1,66 @@
+"""Host logic of the drop-in modules (no GPU): constructor contract, state-dict keys, init rule, masks,
+and that compute on a CPU tensor fails loudly instead of falling back."""
+import numpy as np
+import pytest
+import torch
+
+from fincflow_amd import FastFlowUnit, FlowSequential, PaddedConv2d, ops
+from fincflow_amd.layers import StandardNormal
+from oracle import oracle
+from helpers import ORDER_BITS, ORIENT_FASTFLOW, golden
+
+
+def test_fastflowunit_contract():
+    """fastflow.py:15-27: out_channels overridden by C//4, int kernel -> square, C%4 asserted."""
+    u = FastFlowUnit(8, 999, 3)
+    keys = sorted(u.state_dict().keys())
+    assert keys == ["conv_bl.conv.weight", "conv_br.conv.weight", "conv_tl.conv.weight", "conv_tr.conv.weight"]
+    for k in keys:
+        assert tuple(u.state_dict()[k].shape) == (2, 2, 3, 3)
+    assert [m.order for m in (u.conv_tl, u.conv_tr, u.conv_bl, u.conv_br)] == ["TL", "TR", "BL", "BR"]
+    with pytest.raises(AssertionError):
+        FastFlowUnit(6, 6, 3)
+    assert FastFlowUnit(4, 4, (3, 5)).conv_tl.kernel_size == (3, 5)
+
+
+@pytest.mark.parametrize("order", ["TL", "TR", "BL", "BR"])
+def test_padded_init_mask_pad(order):
+    """layers/conv.py:41-96 against the values recorded from the reference."""
+    g = golden(f"padded_{order}_B2_C3_7x7_k3")
+    m = PaddedConv2d(3, 3, (3, 3), order=order)
+    assert m.pad == tuple(g["pad"])
+    assert np.array_equal(m.mask.numpy(), g["mask"])
+    wc = oracle.canonicalize(m.conv.weight.detach().numpy(), 1, ORDER_BITS[order])
+    assert oracle.check_invariant(wc, 1) == 0
+    assert m.logdet() == 0.0
+    # reset_gradients multiplies by the mask (layers/conv.py:98-99)
+    m.conv.weight.grad = torch.ones_like(m.conv.weight)
+    m.reset_gradients()
+    assert np.array_equal(m.conv.weight.grad.numpy(), g["mask"])
+    with pytest.raises(AssertionError):
+        PaddedConv2d(3, 3, (3, 3), order="XX")
+
+
+def test_reference_state_dict_loads():
+    g = golden("unit_c1_B2_C4_8x8_k3")
+    u = FastFlowUnit(4, 4, 3)
+    sd = {f"conv_{o}.conv.weight": torch.from_numpy(g[f"w_{o}"]) for o in ("tl", "tr", "bl", "br")}
+    u.load_state_dict(sd)
+    ws = torch.cat(u._weights()).detach().numpy()
+    assert oracle.check_invariant(oracle.canonicalize(ws, 4, ORIENT_FASTFLOW), 4) == 0
+
+
+def test_no_cpu_fallback():
+    u = FastFlowUnit(4, 4, 3)
+    x = torch.randn(1, 4, 8, 8)
+    with pytest.raises(RuntimeError, match="CUDA tensor"):
+        u(x)
+    with pytest.raises(RuntimeError, match="CUDA tensor"):
+        u.reverse(x)
+    with pytest.raises(RuntimeError, match="CUDA tensor"):
+        ops.inverse(x, torch.randn(4, 1, 3, 3), torch.zeros_like(x))
+
+
+def test_flowsequential_protocol_shape():
+    seq = FlowSequential(StandardNormal((4, 8, 8)), FastFlowUnit(4, 4, 3), FastFlowUnit(4, 4, 3))
+    assert len(list(seq)) == 2 and hasattr(seq, "sample") and hasattr(seq, "log_prob")

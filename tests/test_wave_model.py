@@ -1,0 +1,26 @@
+"""The lane-level model of the MFMA wavefront kernel (tests/wave_model.py) reproduces the oracle.
+This pins the kernel's schedule / indexing on a machine without a GPU; the GPU tests pin the kernel itself."""
+import numpy as np
+import pytest
+
+from oracle import oracle
+from helpers import rel_err
+import wave_model
+
+CASES = [(4, 8, 8, 3, 3), (3, 16, 16, 3, 3), (6, 8, 8, 3, 3), (12, 20, 20, 3, 3), (24, 19, 32, 3, 3),
+         (16, 12, 12, 2, 2), (4, 10, 12, 5, 5), (2, 10, 16, 3, 5), (5, 7, 4, 3, 3), (8, 40, 8, 3, 3),
+         (1, 8, 8, 3, 3), (3, 4, 4, 3, 3)]
+
+
+@pytest.mark.parametrize("CQ,H,W,KH,KW", CASES)
+def test_wave_schedule(CQ, H, W, KH, KW):
+    rng = np.random.default_rng(CQ * 1000 + H)
+    wc = oracle.make_stored_weights(1, CQ, KH, KW, orient=0, seed=CQ + H)
+    x = rng.standard_normal((1, CQ, H, W)).astype(np.float32)
+    z = oracle.forward_f32(x, wc, 1, 0)
+    xi = wave_model.run(z[0].astype(np.float64), wc, fwd=False)
+    assert not np.isnan(xi).any(), "a pixel was never stored"
+    assert rel_err(xi, oracle.inverse_f64(z, wc, 1)[0]) < 1e-12
+    zf = wave_model.run(x[0].astype(np.float64), wc, fwd=True)
+    assert not np.isnan(zf).any()
+    assert rel_err(zf, z[0]) < 1e-6

@@ -1,0 +1,289 @@
+"""Lane-level numpy model of fincflow_amd/csrc/finc_mfma.hip (TEST INFRASTRUCTURE).
+
+It re-enacts, step by step and lane by lane, the schedule of `finc_wave_kernel`
+for ONE (image, group) problem in canonical orientation: the skewed row-per-lane
+wavefront, the z / x LDS rings with their 4-step I/O cadence, the DPP row_shr
+neighbour exchange, the band hand-over FIFO, the D-layout -> operand packing and
+the fragment layout produced by `pack_kernel`.  The MFMA itself is modelled as
+an exact fp64 matrix product, so any disagreement with the oracle is a schedule
+or indexing bug, not rounding.  It exists so that the kernel's bookkeeping can
+be checked on a machine without a GPU.
+"""
+import numpy as np
+
+LANES = 64
+
+
+def cfg(CQP, KH, KW, fwd):
+    MT = (CQP + 15) // 16
+    NKZ = CQP // 4
+    LASTV = (CQP - 16 * (MT - 1)) // 4
+    PACK = LASTV <= 2
+    NKD = 4 * (MT - 1) + 2 if PACK else 4 * MT
+    NK = NKZ if fwd else NKD
+    return dict(MT=MT, NKZ=NKZ, PACK=PACK, NKD=NKD, NK=NK)
+
+
+def chan_d(MT, PACK, j, q):
+    full = 4 * (MT - 1) if PACK else 4 * MT
+    if j < full:
+        return 16 * (j >> 2) + 4 * q + (j & 3)
+    jj = j - full
+    return 16 * (MT - 1) + (4 * q + 2 * jj if q < 2 else 4 * (q - 2) + 2 * jj + 1)
+
+
+def pack_fragments(wc, CQP, fwd):
+    """pack_kernel: returns {('z', j, mt) | ((a,b), j, mt): array[64]} in fp64."""
+    Cq, _, KH, KW = wc.shape
+    c = cfg(CQP, KH, KW, fwd)
+    MT, NKZ, NK = c["MT"], c["NKZ"], c["NK"]
+    w = wc.astype(np.float64)
+    L = w[:, :, KH - 1, KW - 1]
+    Linv = np.linalg.inv(L) if not fwd else None
+    frags = {}
+
+    def frag(mat, colfn, nk, key):
+        for j in range(nk):
+            for mt in range(MT):
+                v = np.zeros(LANES)
+                for lane in range(LANES):
+                    q, i = lane >> 4, lane & 15
+                    row, col = 16 * mt + i, colfn(j, q)
+                    if row < Cq and col < Cq:
+                        v[lane] = mat[row, col]
+                frags[(key, j, mt)] = v
+
+    if fwd:
+        for a in range(KH):
+            for b in range(KW):
+                frag(w[:, :, KH - 1 - a, KW - 1 - b], lambda j, q: 4 * j + q, NKZ, (a, b))
+    else:
+        frag(Linv, lambda j, q: 4 * j + q, NKZ, "z")
+        for a in range(KH):
+            for b in range(KW):
+                if (a, b) != (0, 0):
+                    frag(-(Linv @ w[:, :, KH - 1 - a, KW - 1 - b]), lambda j, q: chan_d(MT, c["PACK"], j, q), NK, (a, b))
+    return frags
+
+
+def mfma(a, b, c):
+    """v_mfma_f32_16x16x4_f32 lane maps: A[i=l&15][k=l>>4], B[k=l>>4][j=l&15], D[row=4*(l>>4)+r][col=l&15]."""
+    A = np.zeros((16, 4))
+    Bm = np.zeros((4, 16))
+    for lane in range(LANES):
+        A[lane & 15, lane >> 4] = a[lane]
+        Bm[lane >> 4, lane & 15] = b[lane]
+    Dm = A @ Bm
+    out = c.copy()
+    for lane in range(LANES):
+        for r in range(4):
+            out[lane, r] += Dm[4 * (lane >> 4) + r, lane & 15]
+    return out
+
+
+def row_shr(n, old, src):
+    out = old.copy()
+    for lane in range(LANES):
+        if (lane & 15) - n >= 0:
+            out[lane] = src[lane - n]
+    return out
+
+
+def permlane32_swap_lo(vdst, src):
+    """new vdst of v_permlane32_swap: [vdst lanes 0-31, src lanes 0-31]."""
+    return np.concatenate([vdst[:32], src[:32]])
+
+
+def pack_d(acc, c):
+    MT, PACK, NKD = c["MT"], c["PACK"], c["NKD"]
+    xpk = np.zeros((NKD, LANES))
+    full = MT - 1 if PACK else MT
+    for mt in range(full):
+        for r in range(4):
+            xpk[4 * mt + r] = acc[mt][:, r]
+    if PACK:
+        a = acc[MT - 1]
+        xpk[4 * (MT - 1) + 0] = permlane32_swap_lo(a[:, 0], a[:, 1])
+        xpk[4 * (MT - 1) + 1] = permlane32_swap_lo(a[:, 2], a[:, 3])
+    return xpk
+
+
+def run(inp, wc, fwd=False):
+    """inp [Cq,H,W] (z for inverse, x for forward), wc [Cq,Cq,KH,KW] canonical -> out [Cq,H,W] (fp64)."""
+    CQ, H, W = inp.shape
+    KH, KW = wc.shape[2:]
+    CQP = (CQ + 3) // 4 * 4
+    c = cfg(CQP, KH, KW, fwd)
+    MT, NKZ, NKD, NK = c["MT"], c["NKZ"], c["NKD"], c["NK"]
+    assert W % 4 == 0
+    P = min(16, W)
+    assert P >= KH - 1
+    NB = (H + P - 1) // P
+    Tend = (NB * W + P - 1 + 3) // 4 * 4
+    D = W - P + 1
+    fr = pack_fragments(wc, CQP, fwd)
+    out = np.full((CQ, H, W), np.nan)
+    lanes = np.arange(LANES)
+    q, p = lanes >> 4, lanes & 15
+
+    zring = np.full((NKZ, 12, LANES), np.nan)
+    xring = np.full((NKD, 8, LANES), np.nan)
+    fifo = np.zeros((D, NK, 4, max(KH - 1, 1)))
+    fl4 = -((p + 3) >> 2)
+    lcol, lrow = 4 * fl4, p.copy()
+    scol, srow = 4 * (fl4 - 1), p.copy()
+    lslot = ((4 * fl4) % 12 + 12) % 12
+    sslot = (4 * (fl4 - 1)) & 7
+    zin = np.zeros((NKZ, 4, LANES))
+    state = dict(zin_valid=False)
+
+    def io_land():
+        nonlocal lslot
+        if state["zin_valid"]:
+            for j in range(NKZ):
+                for k in range(4):
+                    zring[j, lslot + k, lanes] = zin[j, k]
+            lslot = np.where(lslot == 8, 0, lslot + 4)
+
+    def io_issue():
+        nonlocal lcol, lrow
+        for lane in range(LANES):
+            ok = lcol[lane] >= 0 and lrow[lane] < H and p[lane] < P
+            for j in range(NKZ):
+                ch = 4 * j + q[lane]
+                for k in range(4):
+                    zin[j, k, lane] = inp[ch, lrow[lane], lcol[lane] + k] if (ok and ch < CQ) else 0.0
+        state["zin_valid"] = True
+        lcol = lcol + 4
+        wrap = lcol == W
+        lcol = np.where(wrap, 0, lcol)
+        lrow = np.where(wrap, lrow + P, lrow)
+
+    def io_store():
+        nonlocal scol, srow, sslot
+        for lane in range(LANES):
+            ok = scol[lane] >= 0 and srow[lane] < H and p[lane] < P
+            for j in range(NKD):
+                ch = chan_d(MT, c["PACK"], j, q[lane])
+                if ok and ch < CQ:
+                    for k in range(4):
+                        out[ch, srow[lane], scol[lane] + k] = xring[j, sslot[lane] + k, lane]
+        sslot = sslot ^ 4
+        scol = scol + 4
+        wrap = scol == W
+        scol = np.where(wrap, 0, scol)
+        srow = np.where(wrap, srow + P, srow)
+
+    R = np.zeros((KH, KW, NK, LANES))
+    DL = np.zeros((KH, KH, NK, LANES))
+    fslot = 0
+    push_l = p - (P - (KH - 1))
+    do_push = (KH > 1) & (push_l >= 0) & (p < P)
+
+    def fifo_push(v):
+        for lane in range(LANES):
+            if do_push[lane]:
+                for j in range(NK):
+                    fifo[fslot, j, q[lane], push_l[lane]] = v[j, lane]
+
+    def fifo_pop(a):
+        ps = 0 if fslot + 1 == D else fslot + 1
+        v = np.zeros((NK, LANES))
+        for lane in range(LANES):
+            if p[lane] < a:
+                for j in range(NK):
+                    v[j, lane] = fifo[ps, j, q[lane], KH - 1 - a + p[lane]]
+        return v
+
+    def shift(a, fv, src):
+        return np.stack([row_shr(a, fv[j], src[j]) for j in range(NK)])
+
+    def mm(key, j, mt, b, acc):
+        return mfma(fr[(key, j, mt)], b, acc)
+
+    io_issue(); io_land(); io_issue(); io_land(); io_issue()
+    if not fwd:
+        acc = [np.zeros((LANES, 4)) for _ in range(MT)]
+        cn = -p
+        zs = ((-p) % 12 + 12) % 12
+        xs = (-1 - p) & 7
+        for t in range(-1, Tend):
+            if (t & 3) == 0:
+                io_land(); io_issue(); io_store()
+            zv = np.stack([np.where(cn >= 0, zring[j, zs, lanes], 0.0) for j in range(NKZ)])
+            wrapn = cn == 0
+            for j in range(NK):
+                for mt in range(MT):
+                    if KW > 1:
+                        acc[mt] = mm((0, 1), j, mt, R[0, 1, j], acc[mt])
+                    if KH > 1:
+                        acc[mt] = mm((1, 0), j, mt, R[1, 0, j], acc[mt])
+            for a in range(KH):
+                for b in range(KW - 1, 0, -1):
+                    if a + b >= 2:
+                        R[a, b] = np.where(wrapn, 0.0, R[a, b - 1])
+                if a >= 2:
+                    R[a, 0] = DL[a, a - 2]
+            accn = [np.zeros((LANES, 4)) for _ in range(MT)]
+            for j in range(NKZ):
+                for mt in range(MT):
+                    accn[mt] = mm("z", j, mt, zv[j], accn[mt])
+            for a in range(KH):
+                for b in range(KW):
+                    if a + b >= 2:
+                        for j in range(NK):
+                            for mt in range(MT):
+                                accn[mt] = mm((a, b), j, mt, R[a, b, j], accn[mt])
+            xpk = pack_d(acc, c)
+            for j in range(NKD):
+                xring[j, xs, lanes] = xpk[j]
+            if KH > 1:
+                fifo_push(xpk)
+                R[1, 0] = shift(1, fifo_pop(1), xpk)
+                for a in range(2, KH):
+                    for k in range(a - 2, 0, -1):
+                        DL[a, k] = DL[a, k - 1]
+                    DL[a, 0] = shift(a, fifo_pop(a), xpk)
+            if KW > 1:
+                R[0, 1] = np.where(wrapn, 0.0, xpk)
+            acc = accn
+            cn = np.where(cn + 1 == W, 0, cn + 1)
+            zs = np.where(zs + 1 == 12, 0, zs + 1)
+            xs = (xs + 1) & 7
+            fslot = 0 if fslot + 1 == D else fslot + 1
+        io_store()
+    else:
+        cc = -p
+        zc = ((-p) % 12 + 12) % 12
+        xs = (-p) & 7
+        for t in range(0, Tend):
+            if (t & 3) == 0:
+                io_land(); io_issue(); io_store()
+            wrap = cc == 0
+            for a in range(KH):
+                for b in range(KW - 1, 0, -1):
+                    R[a, b] = np.where(wrap, 0.0, R[a, b - 1])
+            R[0, 0] = np.stack([np.where(cc >= 0, zring[j, zc, lanes], 0.0) for j in range(NKZ)])
+            if KH > 1:
+                for a in range(1, KH):
+                    R[a, 0] = DL[a, a - 1]
+                    for k in range(a - 1, 0, -1):
+                        DL[a, k] = DL[a, k - 1]
+                fifo_push(R[0, 0])
+                for a in range(1, KH):
+                    DL[a, 0] = shift(a, fifo_pop(a), R[0, 0])
+            ac = [np.zeros((LANES, 4)) for _ in range(MT)]
+            for a in range(KH):
+                for b in range(KW):
+                    for j in range(NK):
+                        for mt in range(MT):
+                            ac[mt] = mm((a, b), j, mt, R[a, b, j], ac[mt])
+            xpk = pack_d(ac, c)
+            for j in range(NKD):
+                xring[j, xs, lanes] = xpk[j]
+            cc = np.where(cc + 1 == W, 0, cc + 1)
+            zc = np.where(zc + 1 == 12, 0, zc + 1)
+            xs = (xs + 1) & 7
+            fslot = 0 if fslot + 1 == D else fslot + 1
+        io_store()
+    return out
