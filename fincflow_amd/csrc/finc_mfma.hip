@@ -100,14 +100,17 @@ __device__ inline void pack_d(const v4f (&acc)[C::MT], float (&xpk)[C::NKD])
         xpk[4 * mt + 3] = acc[mt].w;
     }
     if constexpr (C::PACK) {
-        const v4f a = acc[C::MT - 1];
+        // NB: __builtin_bit_cast applied directly to an ext-vector ELEMENT (a.y, s0.x ...) silently reads
+        // element 0 with this compiler; always go through scalar temporaries.
+        const float ax = acc[C::MT - 1].x, ay = acc[C::MT - 1].y, az = acc[C::MT - 1].z, aw = acc[C::MT - 1].w;
         // v_permlane32_swap: new vdst = [vdst.lo32lanes, src.lo32lanes]
-        v2u s0 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a.x), __builtin_bit_cast(unsigned, a.y),
-                                                  false, false);
-        v2u s1 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a.z), __builtin_bit_cast(unsigned, a.w),
-                                                  false, false);
-        xpk[4 * (C::MT - 1) + 0] = __builtin_bit_cast(float, s0.x);
-        xpk[4 * (C::MT - 1) + 1] = __builtin_bit_cast(float, s1.x);
+        const v2u s0 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, ax), __builtin_bit_cast(unsigned, ay),
+                                                        false, false);
+        const v2u s1 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, az), __builtin_bit_cast(unsigned, aw),
+                                                        false, false);
+        const unsigned u0 = s0.x, u1 = s1.x;
+        xpk[4 * (C::MT - 1) + 0] = __builtin_bit_cast(float, u0);
+        xpk[4 * (C::MT - 1) + 1] = __builtin_bit_cast(float, u1);
     }
 }
 
