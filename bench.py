@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""Headline benchmark of the FInC Flow hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (BASELINE.json: "inverse images/sec + fwd+logdet ms/img, 3x3 conv @64x64x96"): one FastFlowUnit,
+3x3, C=96 (Cq=24), 64x64, batch 256 PER GPU (configs[2]); synthetic fp32 data, weights by the reference's
+init rule (layers/conv.py:63-79).  A step = one pass of the hot path over one batch resident in HBM:
+`unit.reverse(z)` (= one launch of the MFMA wavefront kernel).  The timed region is exactly K such steps
+between barrier + torch.cuda.synchronize(); value = images solved by all ranks / max-over-ranks time.
+The forward (+logdet, identically 0) is timed the same way right after and reported next to it.
+
+Images are independent, so ranks shard the batch with no data-path collective ("weak" scaling: the per-GPU
+batch is fixed); the only RCCL traffic is one broadcast of the layer's weights before the timed region.
+
+Extra objects on the JSON line:
+  roofline      dominant kernel (inverse): algorithmic bytes per launch (8*E + 4*C*Cq*KH*KW)
+                / mean launch duration from HIP events on the launch stream, vs 8 TB/s HBM peak; `traffic`
+                = HBM bytes per launch from rocprofv3 PMC passes (profiles/traffic_*.json) or null.
+  cpu_baseline  the CPU solve timed on this box's host cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: 8.0 TB/s spec
+FP32_PEAK_TFLOPS = 157.3   # same table: fp32 vector == fp32-input MFMA
+
+WORKLOADS = {
+    # name: (per-GPU batch, C, H, W, K, weight std)
+    "c3": (256, 96, 64, 64, 3, 0.05),   # BASELINE configs[2] -- the metric's shape
+    "c2": (64, 48, 32, 32, 3, 0.05),    # BASELINE configs[1]
+}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--cpu-sample", type=int, default=None, help="images in the CPU baseline sample")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    return ap.parse_args()
+
+
+def cpu_baseline(B_sample, C, H, W, K, std):
+    """CPU solve of `B_sample` images of the same workload on this box's cores.  Preferred: the reference's own
+    Cython solver rebuilt into oracle/_ref (kind "reference", one thread -- its prange compiles without
+    OpenMP, setup.py:1-5), called per group like FastFlowUnit.reverse_level1 (fastflow.py:57-76).
+    Always also: our C restatement with OpenMP over (image, group) on every core (kind "port")."""
+    import numpy as np
+    from oracle import build_ref, oracle
+    ws = oracle.make_stored_weights(4, C // 4, K, K, std=std)
+    wc = oracle.canonicalize(ws, 4, oracle.ORIENT_FASTFLOW)
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((B_sample, C, H, W)).astype(np.float32)
+    z = oracle.forward_f32(x, wc, nthreads=oracle.max_threads())
+    ncores = os.cpu_count() or 1
+    nthreads = min(oracle.max_threads(), ncores)
+    t0 = time.perf_counter()
+    xp = oracle.inverse_via_f64(z, wc, nthreads=nthreads)
+    t_port = time.perf_counter() - t0
+    assert np.abs(xp - x).max() / np.abs(x).max() < 1e-4
+    port = {"value": B_sample / t_port, "unit": "images/s", "cores": nthreads, "kind": "port",
+            "sample": f"{B_sample} images of the bench workload, fp64 solve (oracle/finc_oracle.c), OpenMP over image x group"}
+    solve_parallel = None
+    try:
+        solve_parallel = build_ref.load()
+    except Exception:
+        pass
+    if solve_parallel is None:
+        return port
+    nref = max(1, min(B_sample, 4))
+    Cq = C // 4
+    t0 = time.perf_counter()
+    for b in range(nref):
+        for g in range(4):  # canonical-orientation solve of each group, as layers/conv.py:113-163 does after its flips
+            zz = np.ascontiguousarray(z[b:b + 1, g * Cq:(g + 1) * Cq], dtype=np.float64)
+            solve_parallel(zz, np.ascontiguousarray(wc[g * Cq:(g + 1) * Cq], dtype=np.float64), (K, K))
+    t_ref = time.perf_counter() - t0
+    return {"value": nref / t_ref, "unit": "images/s", "cores": 1, "kind": "reference",
+            "sample": f"{nref} images of the bench workload through the reference's solve_parallel_mc.pyx "
+                      f"(oracle/_ref), 4 group solves per image, single thread as the reference runs it",
+            "port_all_cores": port}
+
+
+def load_traffic(workload):
+    path = os.path.join(REPO, "profiles", f"traffic_{workload}.json")
+    if os.path.exists(path):
+        with open(path) as f:
+            return json.load(f)
+    return None
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from fincflow_amd import FastFlowUnit
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
+
+    B, C, H, W, K, std = WORKLOADS[args.workload]
+    Cq = C // 4
+    torch.manual_seed(1234)
+    unit = FastFlowUnit(C, C, K).to(dev)
+    if world > 1:  # the one collective of the path: replicate the layer (<= 83 KB) from rank 0
+        for w in unit._weights():
+            dist.broadcast(w.data, src=0)
+    gen = torch.Generator(device=dev).manual_seed(1000 + rank)  # each rank owns different images
+    x = torch.randn(B, C, H, W, device=dev, generator=gen)
+    with torch.no_grad():
+        z, logdet = unit(x)
+        xr = unit.reverse(z)                      # also builds the packed-fragment cache
+    torch.cuda.synchronize()
+    err = float((xr - x).abs().max() / x.abs().max())
+    assert logdet == 0.0 and err <= 1e-5, f"round trip broken before timing: {err}"
+    out = torch.empty_like(z)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(fn, steps, warmup):
+        for _ in range(warmup):
+            fn()
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+        barrier()
+        t0 = time.perf_counter()
+        for a, b in evs:
+            a.record()
+            fn()
+            b.record()
+        barrier()
+        dt = time.perf_counter() - t0
+        per_launch_ms = sum(a.elapsed_time(b) for a, b in evs) / steps
+        if world > 1:
+            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt, per_launch_ms
+
+    with torch.no_grad():
+        inv_dt, inv_launch_ms = timed(lambda: unit._cache.inverse(z, unit._weights(), 4, 0xE4, out=out),
+                                      args.steps, args.warmup)
+        fwd_dt, fwd_launch_ms = timed(lambda: unit(x), args.steps, args.warmup)
+    err_after = float((out - x).abs().max() / x.abs().max())
+    assert err_after <= 1e-5, err_after
+
+    if rank == 0:
+        E = B * C * H * W
+        alg_bytes = 8 * E + 4 * C * Cq * K * K
+        alg_flops = 2 * E * K * K * Cq
+        inv_gbs = alg_bytes / (inv_launch_ms * 1e-3) / 1e9
+        traffic = load_traffic(args.workload)
+        line = {
+            "metric": "inverse images/sec (FastFlowUnit 3x3 @64x64x96)" if args.workload == "c3"
+                      else f"inverse images/sec (FastFlowUnit, workload {args.workload})",
+            "value": world * B * args.steps / inv_dt,
+            "unit": "images/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": inv_dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[{2 if args.workload == 'c3' else 1}]: FastFlowUnit {K}x{K}, C={C} "
+                                   f"(4 groups x Cq={Cq}), {H}x{W}, batch {B} per GPU; step = unit.reverse(z), "
+                                   f"z = unit.forward(x), x ~ N(0,1); weights N(0,{std}^2) + reference init rule",
+                       "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"batch-sharded x{world}",
+                       "round_trip_rel_err": err_after},
+            "forward": {"ms_per_img": fwd_dt / args.steps / B * 1e3, "images_per_s": world * B * args.steps / fwd_dt,
+                        "logdet": 0.0, "launch_ms": fwd_launch_ms,
+                        "frac_hbm_peak": alg_bytes / (fwd_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        "frac_fp32_peak": alg_flops / (fwd_launch_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS},
+            "roofline": {"kernel": "finc_wave_kernel<24,3,3,inverse>", "bound": "hbm", "achieved": inv_gbs,
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": inv_gbs / HBM_PEAK_GBS,
+                         "traffic": (traffic or {}).get("inverse_hbm_bytes_per_launch"),
+                         "traffic_source": (traffic or {}).get("source"),
+                         "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": inv_launch_ms,
+                         "frac_fp32_peak": alg_flops / (inv_launch_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS},
+        }
+        if not args.no_cpu:
+            sample = args.cpu_sample or (4 * (os.cpu_count() or 1) if args.workload == "c3" else B)
+            line["cpu_baseline"] = cpu_baseline(min(sample, B), C, H, W, K, std)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
