@@ -37,10 +37,14 @@
 // neighbour exchange and the fragment packing.
 #include "finc_common.h"
 
+#include <type_traits>
+#include <utility>
+
 namespace {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef unsigned v2u __attribute__((ext_vector_type(2)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
 
 template <int CQP_, int KH_, int KW_, bool FWD_>
 struct Cfg {
@@ -114,23 +118,57 @@ __device__ inline void pack_d(const v4f (&acc)[C::MT], float (&xpk)[C::NKD])
     }
 }
 
-struct IoState {
-    int lcol, lrow; // next group to load (canonical col may be negative = not yet)
-    int scol, srow; // next group to store
-    int lslot;      // z-ring slot (0,4,8) where the in-flight group lands
-    int sslot;      // x-ring slot (0,4) of the group to store
+// taps of the inverse's phase B (a+b >= 2), row-major; taps of the forward in (a asc, b DESC) order
+template <int KH, int KW>
+struct BTaps {
+    static constexpr int count()
+    {
+        int n = 0;
+        for (int a = 0; a < KH; ++a)
+            for (int b = 0; b < KW; ++b) n += (a + b >= 2);
+        return n;
+    }
+    static constexpr int a_of(int i)
+    {
+        for (int a = 0; a < KH; ++a)
+            for (int b = 0; b < KW; ++b)
+                if (a + b >= 2 && i-- == 0) return a;
+        return 0;
+    }
+    static constexpr int b_of(int i)
+    {
+        for (int a = 0; a < KH; ++a)
+            for (int b = 0; b < KW; ++b)
+                if (a + b >= 2 && i-- == 0) return b;
+        return 0;
+    }
 };
+
+#define FINC_SB() __builtin_amdgcn_sched_barrier(0)
+template <int I>
+using IC = std::integral_constant<int, I>;
+
+constexpr unsigned OFF_INVALID = 0x80000000u;    // voffset beyond any slab: buffer loads return 0, stores are dropped
+constexpr unsigned OFF_BAD_CHANNEL = 0x40000000u; // added to a valid offset it still lands beyond the slab (< 1 GiB)
 
 // -----------------------------------------------------------------------------------------------
 // The kernel.  grid = B*G workgroups of one wavefront.
+//
+// A step is cut into scheduling regions by sched_barrier(0); every region holds a block of
+// independent MFMAs plus side work (LDS traffic, DPP shifts, masks, HBM loads/stores) whose inputs
+// were produced at least one region earlier, so the in-order wave never waits and the side work
+// issues in the shadow of the 32-cycle MFMAs.  The loop is unrolled x4 so the 4-step I/O cadence
+// (read x ring / store / land z / issue loads) falls on fixed steps.
 // -----------------------------------------------------------------------------------------------
-template <int CQP, int KH, int KW, bool FWD>
+template <int CQP, int KH, int KW, bool FWD, bool SEC>
 __global__ __launch_bounds__(64) void finc_wave_kernel(const float *__restrict__ in, const float *__restrict__ packed,
                                                        float *__restrict__ out, int G, int CQ, int H, int W, int P,
                                                        int Tend, unsigned orient)
 {
     using C = Cfg<CQP, KH, KW, FWD>;
     constexpr int MT = C::MT, NKZ = C::NKZ, NKD = C::NKD, NK = C::NK, NFRAG = C::NFRAG;
+    constexpr int JS = 4 * (KH - 1);          // FIFO: floats per k-step (4 k-slots x (KH-1) source lanes)
+    constexpr int SS = NK * JS;               // FIFO: floats per step slot
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float *zring = lds;
     float *xring = lds + C::ZRING;
@@ -143,10 +181,14 @@ __global__ __launch_bounds__(64) void finc_wave_kernel(const float *__restrict__
     const unsigned o = finc_group_orient(orient, g);
     const bool fh = (o & FINC_FLIP_H) != 0, fw = (o & FINC_FLIP_W) != 0;
     const int HW = H * W;
-    const float *ing = in + (size_t)bg * CQ * HW;
-    float *outg = out + (size_t)bg * CQ * HW;
-    const int D = W - P + 1;                 // FIFO depth (steps between a band's last rows and the next band's first)
-    const int fifo_n = D * NK * 4 * (KH - 1);
+    const unsigned slab_bytes = (unsigned)CQ * (unsigned)HW * 4u;
+    const __amdgpu_buffer_rsrc_t rin =
+        __builtin_amdgcn_make_buffer_rsrc((void *)(in + (size_t)bg * CQ * HW), 0, (int)slab_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rout =
+        __builtin_amdgcn_make_buffer_rsrc((void *)(out + (size_t)bg * CQ * HW), 0, (int)slab_bytes, 0x00020000);
+    const int D = W - P + 1;                  // FIFO depth (steps between a band's last rows and the next band's first)
+    const int fifo_n = D * SS;
+    const int trash = fifo_n + lane;          // per-lane scratch word(s): lanes that neither push nor pop point here
 
     // ---- filter fragments -> registers -------------------------------------------------------
     float af[NFRAG];
@@ -155,81 +197,134 @@ __global__ __launch_bounds__(64) void finc_wave_kernel(const float *__restrict__
 #pragma unroll
         for (int f = 0; f < NFRAG; ++f) af[f] = pk[f * 64];
     }
-    for (int i = lane; i < fifo_n; i += 64) fifo[i] = 0.f;
+    for (int i = lane; i < fifo_n + SS + 64; i += 64) fifo[i] = 0.f;
 
-    // ---- per-lane stream state -----------------------------------------------------------------
-    const int fl4 = -((p + 3) >> 2);         // floor(-p/4)
-    IoState io;
-    io.lcol = 4 * fl4; io.lrow = p;          // io(-12) loads group floor((-12-p)/4)+3 = floor(-p/4)
-    io.scol = 4 * (fl4 - 1); io.srow = p;    // io(0) stores group floor(-p/4)-1
-    io.lslot = ((4 * fl4) % 12 + 12) % 12;
-    io.sslot = (4 * (fl4 - 1)) & 7;
-    float zin[NKZ][4];
+    // ---- per-lane HBM stream state -------------------------------------------------------------
+    const int fl4 = -((p + 3) >> 2);          // floor(-p/4): first 4-column group this lane ever needs
+    // SEC (W % 16 == 0): a lane fetches whole 64-byte sectors (4 groups) at a time, so every sector crosses the
+    // fabric once; otherwise one 16-byte group per window (each sector is then fetched 4 times).
+    constexpr int NPC = SEC ? 4 : 1;          // 16-byte pieces held per channel
+    int lcol = SEC ? (fl4 == -4 ? -16 : 0) : 4 * fl4, lrow = p; // next chunk/group to load (canonical column)
+    int lph = fl4 & 3;                        // SEC: window phase; this lane loads when it is 0
+    int scol = 4 * (fl4 - 2), srow = p;       // next group to store
+    int lslot = SEC ? ((4 * (fl4 - 1)) % 12 + 12) % 12 : ((4 * fl4) % 12 + 12) % 12; // z-ring slot of the next landing
+    int sslot = (4 * (fl4 - 2)) & 7;          // x-ring slot (0,4) of the group to store
+    unsigned zoff[NKZ], coff[NKD];            // per-lane channel byte offsets inside the slab
+#pragma unroll
+    for (int j = 0; j < NKZ; ++j) zoff[j] = (4 * j + q) < CQ ? (unsigned)(4 * j + q) * HW * 4u : OFF_BAD_CHANNEL;
+#pragma unroll
+    for (int j = 0; j < NKD; ++j) {
+        const int c = chan_d(MT, C::PACK, j, q);
+        coff[j] = c < CQ ? (unsigned)c * HW * 4u : OFF_BAD_CHANNEL;
+    }
+    v4u zb[NKZ][NPC];                         // in flight HBM -> z ring (raw: nothing may touch it until it lands)
 #pragma unroll
     for (int j = 0; j < NKZ; ++j)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) zin[j][k] = 0.f;
-    bool zin_valid = false;                  // nothing in flight yet
+        for (int m = 0; m < NPC; ++m) zb[j][m] = (v4u){0u, 0u, 0u, 0u};
+    float sv[NKD][4];                         // group in flight x ring -> HBM
+    unsigned st_off = OFF_INVALID;
+    // A W-flipped group (TR/BR) is mirrored by choosing the ring SLOT of each element, never by moving data:
+    // a select on a loaded value would drag the s_waitcnt for the whole HBM latency up to the issue point.
+    const int k0 = fw ? 3 : 0, k1 = fw ? 2 : 1, k2 = fw ? 1 : 2, k3 = fw ? 0 : 3;
 
-    auto io_land = [&]() {
-        if (zin_valid) {
+    auto io_issue = [&]() {
+        const bool ok = lcol >= 0 && lrow < H && p < P;
+        const int mrow = fh ? H - 1 - lrow : lrow;
+        if constexpr (SEC) {
+            // memory-ascending pieces m = 0..3 of the sector; piece m is canonical group (fw ? 3-m : m)
+            const int mcol = fw ? W - 16 - lcol : lcol;
+            const unsigned off = (unsigned)(mrow * W + mcol) * 4u;
+            if (lph == 0) {                   // one row class per window (divergent: other lanes keep their data)
+#pragma unroll
+                for (int j = 0; j < NKZ; ++j) {
+                    const unsigned vo = ok ? off + zoff[j] : OFF_INVALID;
+#pragma unroll
+                    for (int m = 0; m < 4; ++m) zb[j][m] = __builtin_amdgcn_raw_buffer_load_b128(rin, vo + 16u * m, 0, 0);
+                }
+                lcol += 16;
+                if (lcol == W) { lcol = 0; lrow += P; }
+            }
+            lph = (lph + 1) & 3;
+        } else {
+            const int mcol = fw ? W - 4 - lcol : lcol;
+            const unsigned off = (unsigned)(mrow * W + mcol) * 4u;
 #pragma unroll
             for (int j = 0; j < NKZ; ++j)
-#pragma unroll
-                for (int k = 0; k < 4; ++k) zring[(j * C::ZSLOTS + io.lslot + k) * 64 + lane] = zin[j][k];
-            io.lslot = io.lslot == 8 ? 0 : io.lslot + 4;
+                zb[j][0] = __builtin_amdgcn_raw_buffer_load_b128(rin, ok ? off + zoff[j] : OFF_INVALID, 0, 0);
+            lcol += 4;
+            if (lcol == W) { lcol = 0; lrow += P; }
         }
     };
-    auto io_issue = [&]() {
-        const bool ok = io.lcol >= 0 && io.lrow < H && p < P;
-        const int mrow = fh ? H - 1 - io.lrow : io.lrow;
-        const int mcol = fw ? W - 4 - io.lcol : io.lcol;
-        const float *src = ing + mrow * W + mcol;
+    auto io_land = [&]() {
+        float *b0 = zring + (lslot + k0) * 64 + lane, *b1 = zring + (lslot + k1) * 64 + lane;
+        float *b2 = zring + (lslot + k2) * 64 + lane, *b3 = zring + (lslot + k3) * 64 + lane;
+        // SEC: the group due now is canonical group s = (lph+3)&3 of the sector held = memory piece m
+        const int sg = (lph + 3) & 3;
+        const int mp = fw ? 3 - sg : sg;
+        const bool m1 = (mp & 1) != 0, m2 = (mp & 2) != 0;
 #pragma unroll
         for (int j = 0; j < NKZ; ++j) {
-            const int c = 4 * j + q;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok && c < CQ) v = *reinterpret_cast<const float4 *>(src + c * HW);
-            zin[j][0] = fw ? v.w : v.x;
-            zin[j][1] = fw ? v.z : v.y;
-            zin[j][2] = fw ? v.y : v.z;
-            zin[j][3] = fw ? v.x : v.w;
+            unsigned v0, v1, v2, v3;
+            if constexpr (SEC) {
+                const unsigned a0 = zb[j][0].x, a1 = zb[j][0].y, a2 = zb[j][0].z, a3 = zb[j][0].w;
+                const unsigned c0 = zb[j][1].x, c1 = zb[j][1].y, c2 = zb[j][1].z, c3 = zb[j][1].w;
+                const unsigned d0 = zb[j][2].x, d1 = zb[j][2].y, d2 = zb[j][2].z, d3 = zb[j][2].w;
+                const unsigned e0 = zb[j][3].x, e1 = zb[j][3].y, e2 = zb[j][3].z, e3 = zb[j][3].w;
+                v0 = m2 ? (m1 ? e0 : d0) : (m1 ? c0 : a0);
+                v1 = m2 ? (m1 ? e1 : d1) : (m1 ? c1 : a1);
+                v2 = m2 ? (m1 ? e2 : d2) : (m1 ? c2 : a2);
+                v3 = m2 ? (m1 ? e3 : d3) : (m1 ? c3 : a3);
+            } else {
+                v0 = zb[j][0].x; v1 = zb[j][0].y; v2 = zb[j][0].z; v3 = zb[j][0].w;
+            }
+            b0[j * C::ZSLOTS * 64] = __builtin_bit_cast(float, v0);
+            b1[j * C::ZSLOTS * 64] = __builtin_bit_cast(float, v1);
+            b2[j * C::ZSLOTS * 64] = __builtin_bit_cast(float, v2);
+            b3[j * C::ZSLOTS * 64] = __builtin_bit_cast(float, v3);
         }
-        zin_valid = true;
-        io.lcol += 4;
-        if (io.lcol == W) { io.lcol = 0; io.lrow += P; }
+        lslot = lslot == 8 ? 0 : lslot + 4;
     };
-    auto io_store = [&]() {
-        const bool ok = io.scol >= 0 && io.srow < H && p < P;
-        const int mrow = fh ? H - 1 - io.srow : io.srow;
-        const int mcol = fw ? W - 4 - io.scol : io.scol;
-        float *dst = outg + mrow * W + mcol;
+    auto io_sread = [&]() {
+        const bool ok = scol >= 0 && srow < H && p < P;
+        const int mrow = fh ? H - 1 - srow : srow;
+        const int mcol = fw ? W - 4 - scol : scol;
+        st_off = ok ? (unsigned)(mrow * W + mcol) * 4u : OFF_INVALID;
+        const float *b0 = xring + (sslot + k0) * 64 + lane, *b1 = xring + (sslot + k1) * 64 + lane;
+        const float *b2 = xring + (sslot + k2) * 64 + lane, *b3 = xring + (sslot + k3) * 64 + lane;
 #pragma unroll
         for (int j = 0; j < NKD; ++j) {
-            const int c = chan_d(MT, C::PACK, j, q);
-            const float *r = xring + (j * C::XSLOTS + io.sslot) * 64 + lane;
-            float4 v;
-            v.x = r[fw ? 192 : 0];
-            v.y = r[fw ? 128 : 64];
-            v.z = r[fw ? 64 : 128];
-            v.w = r[fw ? 0 : 192];
-            if (ok && c < CQ) *reinterpret_cast<float4 *>(dst + c * HW) = v;
+            sv[j][0] = b0[j * C::XSLOTS * 64];
+            sv[j][1] = b1[j * C::XSLOTS * 64];
+            sv[j][2] = b2[j * C::XSLOTS * 64];
+            sv[j][3] = b3[j * C::XSLOTS * 64];
         }
-        io.sslot ^= 4;
-        io.scol += 4;
-        if (io.scol == W) { io.scol = 0; io.srow += P; }
+        sslot ^= 4;
+        scol += 4;
+        if (scol == W) { scol = 0; srow += P; }
+    };
+    auto io_swrite = [&]() {
+#pragma unroll
+        for (int j = 0; j < NKD; ++j) {
+            v4u v;
+            v.x = __builtin_bit_cast(unsigned, sv[j][0]);
+            v.y = __builtin_bit_cast(unsigned, sv[j][1]);
+            v.z = __builtin_bit_cast(unsigned, sv[j][2]);
+            v.w = __builtin_bit_cast(unsigned, sv[j][3]);
+            __builtin_amdgcn_raw_buffer_store_b128(v, rout, st_off == OFF_INVALID ? OFF_INVALID : st_off + coff[j], 0, 0);
+        }
+    };
+    auto io_phase = [&](auto ph_c) {           // one quarter of the window's HBM work per step
+        constexpr int PH = decltype(ph_c)::value;
+        if constexpr (PH == 0) io_sread();
+        if constexpr (PH == 1) io_swrite();
+        if constexpr (PH == 2) io_land();
+        if constexpr (PH == 3) io_issue();
     };
 
-    // position bookkeeping: at step t this lane is at position u = t - p of its row chain
-    // (inverse starts at t = -1 so that position 0 of lane 0 gets its z-term; forward starts at t = 0)
-    int cn = -p;                              // inverse: column of position u+1 (negative: not started)
-    int zs = ((-p) % 12 + 12) % 12;           // inverse: z-ring slot of position u+1
-    int xs = FWD ? ((-p) & 7) : ((-1 - p) & 7); // x-ring slot of position u
-    int fslot = 0;                            // FIFO slot written this step
-
-    // neighbour operands.  R[a][b] = operand of tap (a,b) for the current step.
-    float R[KH][KW][NK];
-    float DL[KH][KH][NK];                     // DL[a][k]: row_shr:a copies waiting k+1 more steps (a >= 2; a >= 1 fwd)
+    // ---- neighbour operands --------------------------------------------------------------------
+    float R[KH][KW][NK];                      // R[a][b]: B operand of tap (a,b) for the current step
+    float DL[KH][KH][NK];                     // DL[a][k]: row_shr:a copies that are k+1 steps old
 #pragma unroll
     for (int a = 0; a < KH; ++a) {
 #pragma unroll
@@ -241,52 +336,95 @@ __global__ __launch_bounds__(64) void finc_wave_kernel(const float *__restrict__
 #pragma unroll
             for (int j = 0; j < NK; ++j) DL[a][k][j] = 0.f;
     }
-    v4f acc[MT];
+    float fv[KH][NK];                         // FIFO pops (row a of the previous band) waiting for their DPP merge
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) acc[mt] = (v4f){0.f, 0.f, 0.f, 0.f};
+    for (int a = 0; a < KH; ++a)
+#pragma unroll
+        for (int j = 0; j < NK; ++j) fv[a][j] = 0.f;
 
-    // FIFO: lanes P-(KH-1)..P-1 push their operand regs; lanes p < a pop lane P-a+p of D-1 steps ago
+    // FIFO: lanes P-(KH-1)..P-1 push their operand regs every step; lanes p < a pop lane P-a+p of D-1 steps ago.
     const int push_l = p - (P - (KH - 1));
     const bool do_push = KH > 1 && push_l >= 0 && p < P;
+    const int push_base = q * (KH - 1) + push_l;
+    int fslot = 0;
     auto fifo_push = [&](const float (&v)[NK]) {
-        if (do_push) {
+        const int ptr = do_push ? fslot * SS + push_base : trash;
 #pragma unroll
-            for (int j = 0; j < NK; ++j) fifo[((fslot * NK + j) * 4 + q) * (KH - 1) + push_l] = v[j];
+        for (int j = 0; j < NK; ++j) fifo[ptr + j * JS] = v[j];
+    };
+    auto fifo_pop_all = [&]() {
+        const int ps = fslot + 1 == D ? 0 : fslot + 1;
+#pragma unroll
+        for (int a = 1; a < KH; ++a) {
+            const int ptr = p < a ? ps * SS + q * (KH - 1) + (KH - 1 - a + p) : trash;
+#pragma unroll
+            for (int j = 0; j < NK; ++j) fv[a][j] = fifo[ptr + j * JS];
         }
     };
-    auto fifo_pop = [&](int a, float (&v)[NK]) {
-        const int ps = fslot + 1 == D ? 0 : fslot + 1;
-        if (p < a) {
+    // S_a = row_shr:a(src), lanes p < a take the FIFO value; then shift the delay lines.
+    auto shift_all = [&](const float (&src)[NK], bool fwd_delay) {
+        if constexpr (KH > 1) {
+            float sn[KH][NK];
+            ShiftOp<1>::apply(sn[1], fv[1], src);
+            if constexpr (KH > 2) ShiftOp<2>::apply(sn[2], fv[2], src);
+            if constexpr (KH > 3) ShiftOp<3>::apply(sn[3], fv[3], src);
+            if constexpr (KH > 4) ShiftOp<4>::apply(sn[4], fv[4], src);
+            if constexpr (KH > 5) ShiftOp<5>::apply(sn[5], fv[5], src);
+            if constexpr (KH > 6) ShiftOp<6>::apply(sn[6], fv[6], src);
 #pragma unroll
-            for (int j = 0; j < NK; ++j) v[j] = fifo[((ps * NK + j) * 4 + q) * (KH - 1) + (KH - 1 - a + p)];
-        } else {
+            for (int a = 1; a < KH; ++a) {
+                // inverse: R[a][0](t+1) = S_a(t+1-a): a-1 steps of delay; forward (one step ahead): a steps
+                const int nd = fwd_delay ? a : a - 1;
+                if (nd == 0) {
 #pragma unroll
-            for (int j = 0; j < NK; ++j) v[j] = 0.f;
+                    for (int j = 0; j < NK; ++j) R[a][0][j] = sn[a][j];
+                } else {
+                    if (fwd_delay) {
+#pragma unroll
+                        for (int j = 0; j < NK; ++j) R[a][0][j] = DL[a][nd - 1][j];
+                    }
+#pragma unroll
+                    for (int k = nd - 1; k >= 1; --k)
+#pragma unroll
+                        for (int j = 0; j < NK; ++j) DL[a][k][j] = DL[a][k - 1][j];
+#pragma unroll
+                    for (int j = 0; j < NK; ++j) DL[a][0][j] = sn[a][j];
+                }
+            }
         }
     };
 
     __syncthreads(); // single wave: orders the FIFO zero-fill before use
 
+    // pre-loop = the HBM side of the two windows before the first computed one
+    if constexpr (SEC) {
+        io_land();   // window -3 (lands only zeros)
+        io_issue();
+        io_land();   // window -2: the first group lands
+        io_issue();
+    } else {
+        io_issue();
+        io_land();
+        io_issue();  // left in flight, lands in window -1
+    }
+
+    int xs = (-4 - p) & 7;                    // x-ring slot of the position of step t (t starts at -4)
+    int nslot = ((-3 - p) % 12 + 12) % 12;    // z-ring slot of the position of step t+1
+    int cn = -3 - p;                          // column of the position of step t+1 (negative: lane not started)
+
     if constexpr (!FWD) {
         // =========================== inverse ===========================
-        constexpr int FZ = 0;                          // z-term fragments: (j*MT + mt)
+        constexpr int FZ = 0;                          // z-term fragments: j*MT + mt
         constexpr int FT = NKZ * MT;                   // tap fragments: FT + (((a*KW+b)-1)*NK + j)*MT + mt
-        io_issue(); io_land(); io_issue(); io_land(); io_issue(); // virtual t = -12, -8, -4
-        for (int t = -1; t < Tend; ++t) {
-            if ((t & 3) == 0) { io_land(); io_issue(); io_store(); }
-
-            // (1) z of the NEXT position
-            float zv[NKZ];
+        using BT = BTaps<KH, KW>;
+        constexpr int NCH = BT::count();
+        v4f acc[MT];
 #pragma unroll
-            for (int j = 0; j < NKZ; ++j) {
-                float v = zring[(j * C::ZSLOTS + zs) * 64 + lane];
-                zv[j] = cn >= 0 ? v : 0.f;
-            }
-            const bool wrapn = cn == 0;                // the next position starts a row
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = (v4f){0.f, 0.f, 0.f, 0.f};
 
-            // (2) phase A: the two taps that need the pixel solved last step
+        auto phase_a = [&](int j0, int j1) {
 #pragma unroll
-            for (int j = 0; j < NK; ++j)
+            for (int j = j0; j < j1; ++j)
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     if constexpr (KW > 1)
@@ -296,8 +434,17 @@ __global__ __launch_bounds__(64) void finc_wave_kernel(const float *__restrict__
                         acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[FT + ((1 * KW + 0 - 1) * NK + j) * MT + mt],
                                                                        R[1][0][j], acc[mt], 0, 0, 0);
                 }
+        };
 
-            // (3) age the operands that do not depend on this step's result
+        auto step = [&](auto ph_c) {
+            const bool wrapn = cn == 0;                // the next position starts a row
+            const bool started = cn >= 0;
+            float zraw[NKZ], zv[NKZ], xpk[NKD];
+            v4f accn[MT];
+
+            // ---- RA1: z of the next position is requested; operands that do not depend on this step age
+#pragma unroll
+            for (int j = 0; j < NKZ; ++j) zraw[j] = zring[(j * C::ZSLOTS + nslot) * 64 + lane];
 #pragma unroll
             for (int a = 0; a < KH; ++a) {
 #pragma unroll
@@ -312,9 +459,14 @@ __global__ __launch_bounds__(64) void finc_wave_kernel(const float *__restrict__
                     for (int j = 0; j < NK; ++j) R[a][0][j] = DL[a][a - 2][j];
                 }
             }
-
-            // (4) phase B: everything of the next step that is already known
-            v4f accn[MT];
+            phase_a(0, NK / 2);
+            FINC_SB();
+            // ---- RA2
+#pragma unroll
+            for (int j = 0; j < NKZ; ++j) zv[j] = started ? zraw[j] : 0.f;
+            phase_a(NK / 2, NK);
+            FINC_SB();
+            // ---- RB0: z-term of the next step
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) accn[mt] = (v4f){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -322,123 +474,147 @@ __global__ __launch_bounds__(64) void finc_wave_kernel(const float *__restrict__
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
                     accn[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[FZ + j * MT + mt], zv[j], accn[mt], 0, 0, 0);
-#pragma unroll
-            for (int a = 0; a < KH; ++a)
-#pragma unroll
-                for (int b = 0; b < KW; ++b) {
-                    if (a + b >= 2) {
-#pragma unroll
-                        for (int j = 0; j < NK; ++j)
-#pragma unroll
-                            for (int mt = 0; mt < MT; ++mt)
-                                accn[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(
-                                    af[FT + ((a * KW + b - 1) * NK + j) * MT + mt], R[a][b][j], accn[mt], 0, 0, 0);
-                    }
-                }
+            FINC_SB();
 
-            // (5) post-process the pixel just solved
-            float xpk[NKD];
-            pack_d<C>(acc, xpk);
+            auto post1 = [&]() {                       // the pixel solved this step leaves the accumulators
+                pack_d<C>(acc, xpk);
 #pragma unroll
-            for (int j = 0; j < NKD; ++j) xring[(j * C::XSLOTS + xs) * 64 + lane] = xpk[j];
-            if constexpr (KH > 1) {
-                fifo_push(xpk);
-                float fv[NK];
-                fifo_pop(1, fv);
-                ShiftOp<1>::apply(R[1][0], fv, xpk);
-                if constexpr (KH > 2) {
-#pragma unroll
-                    for (int a = 2; a < KH; ++a) {
-#pragma unroll
-                        for (int k = a - 2; k >= 1; --k)
-#pragma unroll
-                            for (int j = 0; j < NK; ++j) DL[a][k][j] = DL[a][k - 1][j];
-                    }
-                    if constexpr (KH > 2) { fifo_pop(2, fv); ShiftOp<2>::apply(DL[2][0], fv, xpk); }
-                    if constexpr (KH > 3) { fifo_pop(3, fv); ShiftOp<3>::apply(DL[3][0], fv, xpk); }
-                    if constexpr (KH > 4) { fifo_pop(4, fv); ShiftOp<4>::apply(DL[4][0], fv, xpk); }
-                    if constexpr (KH > 5) { fifo_pop(5, fv); ShiftOp<5>::apply(DL[5][0], fv, xpk); }
-                    if constexpr (KH > 6) { fifo_pop(6, fv); ShiftOp<6>::apply(DL[6][0], fv, xpk); }
+                for (int j = 0; j < NKD; ++j) xring[(j * C::XSLOTS + xs) * 64 + lane] = xpk[j];
+                if constexpr (KH > 1) {
+                    fifo_push(xpk);
+                    fifo_pop_all();
                 }
-            }
-            if constexpr (KW > 1) {
+                if constexpr (KW > 1) {
 #pragma unroll
-                for (int j = 0; j < NK; ++j) R[0][1][j] = wrapn ? 0.f : xpk[j];
-            }
+                    for (int j = 0; j < NK; ++j) R[0][1][j] = wrapn ? 0.f : xpk[j];
+                }
+            };
+            auto post2 = [&]() { shift_all(xpk, false); };
 
-            // (6) advance
+            // ---- RB1..: one region per remaining tap, side work attached to the first three
+            auto chunk = [&](auto ci_c) {
+                constexpr int CI = decltype(ci_c)::value;
+                constexpr int a = BT::a_of(CI), b = BT::b_of(CI);
+#pragma unroll
+                for (int j = 0; j < NK; ++j)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+                        accn[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[FT + ((a * KW + b - 1) * NK + j) * MT + mt],
+                                                                        R[a][b][j], accn[mt], 0, 0, 0);
+                if constexpr (CI == 0) post1();
+                if constexpr (CI == (NCH > 1 ? 1 : 0)) io_phase(ph_c);
+                if constexpr (CI == (NCH > 2 ? 2 : NCH - 1)) post2();
+                FINC_SB();
+            };
+            if constexpr (NCH == 0) {
+                post1();
+                io_phase(ph_c);
+                post2();
+                FINC_SB();
+            } else {
+                [&]<int... I>(std::integer_sequence<int, I...>) { (chunk(IC<I>{}), ...); }
+                (std::make_integer_sequence<int, NCH>{});
+            }
+            // ---- advance
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) acc[mt] = accn[mt];
             ++cn; if (cn == W) cn = 0;
-            ++zs; if (zs == 12) zs = 0;
+            ++nslot; if (nslot == 12) nslot = 0;
             xs = (xs + 1) & 7;
             ++fslot; if (fslot == D) fslot = 0;
+        };
+
+        for (int t0 = -4; t0 < Tend; t0 += 4) {
+            step(IC<0>{});
+            step(IC<1>{});
+            step(IC<2>{});
+            step(IC<3>{});
         }
-        io_store(); // flush: t == Tend
+        io_sread();
+        io_swrite();
     } else {
         // =========================== forward ===========================
-        // fragments: ((a*KW+b)*NK + j)*MT + mt
-        int cc = -p;                                  // column of position u
-        int zc = ((-p) % 12 + 12) % 12;
-        io_issue(); io_land(); io_issue(); io_land(); io_issue();
-        for (int t = 0; t < Tend; ++t) {
-            if ((t & 3) == 0) { io_land(); io_issue(); io_store(); }
-            const bool wrap = cc == 0;
-            // age first (uses the previous step's operands), then insert the new column
+        // fragments: ((a*KW+b)*NK + j)*MT + mt.  Operands of step t+1 are prepared while step t's MFMAs run.
+        constexpr int NCH = KH * KW;                   // chunk CI <-> tap (a = CI / KW, b = KW-1 - CI % KW)
+        v4f acA[MT], acB[MT];
 #pragma unroll
-            for (int a = 0; a < KH; ++a)
+        for (int mt = 0; mt < MT; ++mt) { acA[mt] = (v4f){0.f, 0.f, 0.f, 0.f}; acB[mt] = (v4f){0.f, 0.f, 0.f, 0.f}; }
+        float vn[NK];
 #pragma unroll
-                for (int b = KW - 1; b >= 1; --b)
-#pragma unroll
-                    for (int j = 0; j < NK; ++j) R[a][b][j] = wrap ? 0.f : R[a][b - 1][j];
-#pragma unroll
-            for (int j = 0; j < NKZ; ++j) {
-                float v = zring[(j * C::ZSLOTS + zc) * 64 + lane];
-                R[0][0][j] = cc >= 0 ? v : 0.f;
-            }
-            if constexpr (KH > 1) {
-                // R[a][0](t) = row_shr:a of the stream a steps ago
-#pragma unroll
-                for (int a = 1; a < KH; ++a) {
-#pragma unroll
-                    for (int j = 0; j < NK; ++j) R[a][0][j] = DL[a][a - 1][j];
-#pragma unroll
-                    for (int k = a - 1; k >= 1; --k)
-#pragma unroll
-                        for (int j = 0; j < NK; ++j) DL[a][k][j] = DL[a][k - 1][j];
-                }
-                fifo_push(R[0][0]);
-                float fv[NK];
-                fifo_pop(1, fv); ShiftOp<1>::apply(DL[1][0], fv, R[0][0]);
-                if constexpr (KH > 2) { fifo_pop(2, fv); ShiftOp<2>::apply(DL[2][0], fv, R[0][0]); }
-                if constexpr (KH > 3) { fifo_pop(3, fv); ShiftOp<3>::apply(DL[3][0], fv, R[0][0]); }
-                if constexpr (KH > 4) { fifo_pop(4, fv); ShiftOp<4>::apply(DL[4][0], fv, R[0][0]); }
-                if constexpr (KH > 5) { fifo_pop(5, fv); ShiftOp<5>::apply(DL[5][0], fv, R[0][0]); }
-                if constexpr (KH > 6) { fifo_pop(6, fv); ShiftOp<6>::apply(DL[6][0], fv, R[0][0]); }
-            }
-            v4f ac[MT];
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) ac[mt] = (v4f){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int a = 0; a < KH; ++a)
-#pragma unroll
-                for (int b = 0; b < KW; ++b)
-#pragma unroll
-                    for (int j = 0; j < NK; ++j)
-#pragma unroll
-                        for (int mt = 0; mt < MT; ++mt)
-                            ac[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[((a * KW + b) * NK + j) * MT + mt],
-                                                                          R[a][b][j], ac[mt], 0, 0, 0);
+        for (int j = 0; j < NK; ++j) vn[j] = 0.f;
+
+        auto emit = [&](const v4f (&ac)[MT], int slot) {      // a finished pixel -> x ring
             float xpk[NKD];
             pack_d<C>(ac, xpk);
 #pragma unroll
-            for (int j = 0; j < NKD; ++j) xring[(j * C::XSLOTS + xs) * 64 + lane] = xpk[j];
-            ++cc; if (cc == W) cc = 0;
-            ++zc; if (zc == 12) zc = 0;
+            for (int j = 0; j < NKD; ++j) xring[(j * C::XSLOTS + slot) * 64 + lane] = xpk[j];
+        };
+
+        auto step = [&](auto ph_c, v4f (&ac)[MT], const v4f (&acprev)[MT]) {
+            const bool wrapn = cn == 0;
+            const bool started = cn >= 0;
+            float vraw[NK];
+            auto side = [&](auto k_c) {
+                constexpr int K = decltype(k_c)::value;
+                if constexpr (K == 0) {                // previous pixel out, next input requested
+                    emit(acprev, (xs + 7) & 7);
+#pragma unroll
+                    for (int j = 0; j < NK; ++j) vraw[j] = zring[(j * C::ZSLOTS + nslot) * 64 + lane];
+                }
+                if constexpr (K == 1) {
+#pragma unroll
+                    for (int j = 0; j < NK; ++j) vn[j] = started ? vraw[j] : 0.f;
+                    if constexpr (KH > 1) {
+                        fifo_push(vn);
+                        fifo_pop_all();
+                    }
+                }
+                if constexpr (K == 2) io_phase(ph_c);
+            };
+            auto chunk = [&](auto ci_c) {
+                constexpr int CI = decltype(ci_c)::value;
+                constexpr int a = CI / KW, b = KW - 1 - CI % KW;
+                if constexpr (CI == 0) {
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) ac[mt] = (v4f){0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int j = 0; j < NK; ++j)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+                        ac[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[((a * KW + b) * NK + j) * MT + mt], R[a][b][j],
+                                                                      ac[mt], 0, 0, 0);
+                // operand of this tap for the NEXT step (its MFMAs above have been issued: WAR-safe in order)
+                if constexpr (b >= 1) {
+#pragma unroll
+                    for (int j = 0; j < NK; ++j) R[a][b][j] = wrapn ? 0.f : R[a][b - 1][j];
+                }
+                if constexpr (CI == 0) side(IC<0>{});
+                if constexpr (CI == (NCH > 1 ? 1 : 0)) side(IC<1>{});
+                if constexpr (CI == (NCH > 2 ? 2 : NCH - 1)) side(IC<2>{});
+                FINC_SB();
+            };
+            [&]<int... I>(std::integer_sequence<int, I...>) { (chunk(IC<I>{}), ...); }
+            (std::make_integer_sequence<int, NCH>{});
+            // column b = 0 of every row: the new input and its row_shr copies
+#pragma unroll
+            for (int j = 0; j < NK; ++j) R[0][0][j] = vn[j];
+            shift_all(vn, true);
+            ++cn; if (cn == W) cn = 0;
+            ++nslot; if (nslot == 12) nslot = 0;
             xs = (xs + 1) & 7;
             ++fslot; if (fslot == D) fslot = 0;
+        };
+
+        for (int t0 = -4; t0 < Tend; t0 += 4) {
+            step(IC<0>{}, acA, acB);
+            step(IC<1>{}, acB, acA);
+            step(IC<2>{}, acA, acB);
+            step(IC<3>{}, acB, acA);
         }
-        io_store();
+        emit(acB, (xs + 7) & 7);
+        io_sread();
+        io_swrite();
     }
 }
 
@@ -511,7 +687,8 @@ typedef void (*wave_fn)(const float *, const float *, float *, int, int, int, in
 struct Inst {
     int cqp, kh, kw;
     bool fwd;
-    wave_fn fn;
+    wave_fn fn;      // 16-byte-group I/O (any W % 4 == 0)
+    wave_fn fn_sec;  // 64-byte-sector I/O (W % 16 == 0)
     int nkz, nkd, nk, mt, nfrag, pack;
 };
 
@@ -519,7 +696,7 @@ template <int CQP, int KH, int KW, bool FWD>
 constexpr Inst make_inst()
 {
     using C = Cfg<CQP, KH, KW, FWD>;
-    return Inst{CQP, KH, KW, FWD, finc_wave_kernel<CQP, KH, KW, FWD>, C::NKZ, C::NKD, C::NK, C::MT, C::NFRAG,
+    return Inst{CQP, KH, KW, FWD, finc_wave_kernel<CQP, KH, KW, FWD, false>, finc_wave_kernel<CQP, KH, KW, FWD, true>, C::NKZ, C::NKD, C::NK, C::MT, C::NFRAG,
                 C::PACK ? 1 : 0};
 }
 
@@ -544,7 +721,8 @@ const Inst *find_inst(int Cq, int KH, int KW, bool forward)
 size_t lds_bytes(const Inst &i, int W, int P)
 {
     const size_t D = (size_t)(W - P + 1);
-    return sizeof(float) * ((size_t)i.nkz * 12 * 64 + (size_t)i.nkd * 8 * 64 + D * i.nk * 4 * (i.kh - 1));
+    const size_t ss = (size_t)i.nk * 4 * (i.kh - 1);
+    return sizeof(float) * ((size_t)i.nkz * 12 * 64 + (size_t)i.nkd * 8 * 64 + D * ss + ss + 64);
 }
 
 } // namespace
@@ -557,6 +735,7 @@ bool finc_mfma_supported(int Cq, int H, int W, int KH, int KW, bool forward)
     const int P = W < 16 ? W : 16;
     if (P < KH - 1) return false;
     if (lds_bytes(*i, W, P) > 160 * 1024) return false;
+    if ((size_t)Cq * H * W * 4 >= ((size_t)1 << 30)) return false; // buffer-offset range marks (OFF_BAD_CHANNEL)
     return true;
 }
 
@@ -590,17 +769,18 @@ int finc_mfma_launch(const float *in, const void *packed, float *out, const Finc
     const int NB = (s.H + P - 1) / P;
     const int Tend = (NB * s.W + P - 1 + 3) / 4 * 4;
     const size_t lds = lds_bytes(*i, s.W, P);
-    static thread_local const void *attr_done[64];
+    const wave_fn fn = (s.W % 16 == 0) ? i->fn_sec : i->fn;
+    static thread_local const void *attr_done[128];
     static thread_local int n_attr = 0;
     if (lds > 48 * 1024) {
         bool seen = false;
-        for (int k = 0; k < n_attr; ++k) seen |= attr_done[k] == (const void *)i->fn;
+        for (int k = 0; k < n_attr; ++k) seen |= attr_done[k] == (const void *)fn;
         if (!seen) {
-            FINC_HIP_TRY(hipFuncSetAttribute((const void *)i->fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            if (n_attr < 64) attr_done[n_attr++] = (const void *)i->fn;
+            FINC_HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+            if (n_attr < 128) attr_done[n_attr++] = (const void *)fn;
         }
     }
-    hipLaunchKernelGGL(i->fn, dim3(s.B * s.G), dim3(64), lds, st, in, (const float *)packed, out, s.G, s.Cq, s.H, s.W,
+    hipLaunchKernelGGL(fn, dim3(s.B * s.G), dim3(64), lds, st, in, (const float *)packed, out, s.G, s.Cq, s.H, s.W,
                        P, Tend, s.orient);
     FINC_CHECK_LAUNCH();
     return FINC_OK;

@@ -1,0 +1,15 @@
+"""Summarise rocprofv3 --pmc passes: per kernel, mean counter value per dispatch."""
+import csv, glob, os, sys, collections, json
+root = sys.argv[1]
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
+    for row in csv.DictReader(open(f)):
+        k = row["Kernel_Name"]
+        if "finc_wave_kernel" not in k:
+            continue
+        k = "inverse" if "false>" in k else "forward"
+        acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
+out = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in acc.items()}
+out["n_dispatches"] = {k: {c: len(v) for c, v in d.items()} for k, d in acc.items()}
+json.dump(out, open(os.path.join(root, "summary.json"), "w"), indent=1, sort_keys=True)
+print(json.dumps(out, indent=1, sort_keys=True))

@@ -126,53 +126,86 @@ def run(inp, wc, fwd=False):
     lanes = np.arange(LANES)
     q, p = lanes >> 4, lanes & 15
 
+    SS = NK * 4 * max(KH - 1, 1)
     zring = np.full((NKZ, 12, LANES), np.nan)
     xring = np.full((NKD, 8, LANES), np.nan)
     fifo = np.zeros((D, NK, 4, max(KH - 1, 1)))
     fl4 = -((p + 3) >> 2)
-    lcol, lrow = 4 * fl4, p.copy()
-    scol, srow = 4 * (fl4 - 1), p.copy()
-    lslot = ((4 * fl4) % 12 + 12) % 12
-    sslot = (4 * (fl4 - 1)) & 7
+    SEC = W % 16 == 0                     # 64-byte sector loads (finc_wave_kernel<..., SEC=true>)
+    lcol = np.where(fl4 == -4, -16, 0) if SEC else 4 * fl4
+    lrow = p.copy()
+    lph = fl4 & 3
+    scol, srow = 4 * (fl4 - 2), p.copy()
+    lslot = ((4 * (fl4 - 1)) % 12 + 12) % 12 if SEC else ((4 * fl4) % 12 + 12) % 12
+    sslot = (4 * (fl4 - 2)) & 7
     zin = np.zeros((NKZ, 4, LANES))
-    state = dict(zin_valid=False)
+    zb = np.zeros((NKZ, 4, 4, LANES))     # SEC: [j][piece][element][lane]
+    sv = np.zeros((NKD, 4, LANES))
+    st = dict(ok=np.zeros(LANES, bool), row=p.copy(), col=p.copy())
 
     def io_land():
         nonlocal lslot
-        if state["zin_valid"]:
-            for j in range(NKZ):
-                for k in range(4):
-                    zring[j, lslot + k, lanes] = zin[j, k]
-            lslot = np.where(lslot == 8, 0, lslot + 4)
+        sg = (lph + 3) & 3
+        for j in range(NKZ):
+            for k in range(4):
+                val = zb[j, sg, k, lanes] if SEC else zin[j, k]
+                zring[j, lslot + k, lanes] = val
+        lslot = np.where(lslot == 8, 0, lslot + 4)
 
     def io_issue():
-        nonlocal lcol, lrow
+        nonlocal lcol, lrow, lph
+        if SEC:
+            for lane in range(LANES):
+                if lph[lane] != 0:
+                    continue
+                ok = lcol[lane] >= 0 and lrow[lane] < H and p[lane] < P
+                for j in range(NKZ):
+                    ch = 4 * j + q[lane]
+                    for m in range(4):
+                        for k in range(4):
+                            zb[j, m, k, lane] = inp[ch, lrow[lane], lcol[lane] + 4 * m + k] if (ok and ch < CQ) else 0.0
+            load = lph == 0
+            lcol = np.where(load, lcol + 16, lcol)
+            wrap = load & (lcol == W)
+            lcol = np.where(wrap, 0, lcol)
+            lrow = np.where(wrap, lrow + P, lrow)
+            lph = (lph + 1) & 3
+            return
         for lane in range(LANES):
             ok = lcol[lane] >= 0 and lrow[lane] < H and p[lane] < P
             for j in range(NKZ):
                 ch = 4 * j + q[lane]
                 for k in range(4):
                     zin[j, k, lane] = inp[ch, lrow[lane], lcol[lane] + k] if (ok and ch < CQ) else 0.0
-        state["zin_valid"] = True
         lcol = lcol + 4
         wrap = lcol == W
         lcol = np.where(wrap, 0, lcol)
         lrow = np.where(wrap, lrow + P, lrow)
 
-    def io_store():
+    def io_sread():
         nonlocal scol, srow, sslot
-        for lane in range(LANES):
-            ok = scol[lane] >= 0 and srow[lane] < H and p[lane] < P
-            for j in range(NKD):
-                ch = chan_d(MT, c["PACK"], j, q[lane])
-                if ok and ch < CQ:
-                    for k in range(4):
-                        out[ch, srow[lane], scol[lane] + k] = xring[j, sslot[lane] + k, lane]
+        st["ok"] = (scol >= 0) & (srow < H) & (p < P)
+        st["row"], st["col"] = srow.copy(), scol.copy()
+        for j in range(NKD):
+            for k in range(4):
+                sv[j, k] = xring[j, sslot + k, lanes]
         sslot = sslot ^ 4
         scol = scol + 4
         wrap = scol == W
         scol = np.where(wrap, 0, scol)
         srow = np.where(wrap, srow + P, srow)
+
+    def io_swrite():
+        for lane in range(LANES):
+            if st["ok"][lane]:
+                for j in range(NKD):
+                    ch = chan_d(MT, c["PACK"], j, q[lane])
+                    if ch < CQ:
+                        for k in range(4):
+                            out[ch, st["row"][lane], st["col"][lane] + k] = sv[j, k, lane]
+
+    def io_phase(ph):
+        [io_sread, io_swrite, io_land, io_issue][ph]()
 
     R = np.zeros((KH, KW, NK, LANES))
     DL = np.zeros((KH, KH, NK, LANES))
@@ -198,32 +231,46 @@ def run(inp, wc, fwd=False):
     def shift(a, fv, src):
         return np.stack([row_shr(a, fv[j], src[j]) for j in range(NK)])
 
+    def shift_all(fvs, src, fwd_delay):
+        for a in range(1, KH):
+            sn = shift(a, fvs[a], src)
+            nd = a if fwd_delay else a - 1
+            if nd == 0:
+                R[a, 0] = sn
+            else:
+                if fwd_delay:
+                    R[a, 0] = DL[a, nd - 1]
+                for k in range(nd - 1, 0, -1):
+                    DL[a, k] = DL[a, k - 1]
+                DL[a, 0] = sn
+
     def mm(key, j, mt, b, acc):
         return mfma(fr[(key, j, mt)], b, acc)
 
-    io_issue(); io_land(); io_issue(); io_land(); io_issue()
+    if SEC:
+        io_land(); io_issue(); io_land(); io_issue()
+    else:
+        io_issue(); io_land(); io_issue()
+    xs = (-4 - p) & 7
+    nslot = ((-3 - p) % 12 + 12) % 12
+    cn = -3 - p
     if not fwd:
         acc = [np.zeros((LANES, 4)) for _ in range(MT)]
-        cn = -p
-        zs = ((-p) % 12 + 12) % 12
-        xs = (-1 - p) & 7
-        for t in range(-1, Tend):
-            if (t & 3) == 0:
-                io_land(); io_issue(); io_store()
-            zv = np.stack([np.where(cn >= 0, zring[j, zs, lanes], 0.0) for j in range(NKZ)])
+        for t in range(-4, Tend):
             wrapn = cn == 0
-            for j in range(NK):
-                for mt in range(MT):
-                    if KW > 1:
-                        acc[mt] = mm((0, 1), j, mt, R[0, 1, j], acc[mt])
-                    if KH > 1:
-                        acc[mt] = mm((1, 0), j, mt, R[1, 0, j], acc[mt])
+            zv = np.stack([np.where(cn >= 0, zring[j, nslot, lanes], 0.0) for j in range(NKZ)])
             for a in range(KH):
                 for b in range(KW - 1, 0, -1):
                     if a + b >= 2:
                         R[a, b] = np.where(wrapn, 0.0, R[a, b - 1])
                 if a >= 2:
                     R[a, 0] = DL[a, a - 2]
+            for j in range(NK):
+                for mt in range(MT):
+                    if KW > 1:
+                        acc[mt] = mm((0, 1), j, mt, R[0, 1, j], acc[mt])
+                    if KH > 1:
+                        acc[mt] = mm((1, 0), j, mt, R[1, 0, j], acc[mt])
             accn = [np.zeros((LANES, 4)) for _ in range(MT)]
             for j in range(NKZ):
                 for mt in range(MT):
@@ -237,53 +284,57 @@ def run(inp, wc, fwd=False):
             xpk = pack_d(acc, c)
             for j in range(NKD):
                 xring[j, xs, lanes] = xpk[j]
+            fvs = {}
             if KH > 1:
                 fifo_push(xpk)
-                R[1, 0] = shift(1, fifo_pop(1), xpk)
-                for a in range(2, KH):
-                    for k in range(a - 2, 0, -1):
-                        DL[a, k] = DL[a, k - 1]
-                    DL[a, 0] = shift(a, fifo_pop(a), xpk)
+                fvs = {a: fifo_pop(a) for a in range(1, KH)}
             if KW > 1:
                 R[0, 1] = np.where(wrapn, 0.0, xpk)
+            io_phase(t & 3)
+            shift_all(fvs, xpk, False)
             acc = accn
             cn = np.where(cn + 1 == W, 0, cn + 1)
-            zs = np.where(zs + 1 == 12, 0, zs + 1)
+            nslot = np.where(nslot + 1 == 12, 0, nslot + 1)
             xs = (xs + 1) & 7
             fslot = 0 if fslot + 1 == D else fslot + 1
-        io_store()
+        io_sread(); io_swrite()
     else:
-        cc = -p
-        zc = ((-p) % 12 + 12) % 12
-        xs = (-p) & 7
-        for t in range(0, Tend):
-            if (t & 3) == 0:
-                io_land(); io_issue(); io_store()
-            wrap = cc == 0
-            for a in range(KH):
-                for b in range(KW - 1, 0, -1):
-                    R[a, b] = np.where(wrap, 0.0, R[a, b - 1])
-            R[0, 0] = np.stack([np.where(cc >= 0, zring[j, zc, lanes], 0.0) for j in range(NKZ)])
-            if KH > 1:
-                for a in range(1, KH):
-                    R[a, 0] = DL[a, a - 1]
-                    for k in range(a - 1, 0, -1):
-                        DL[a, k] = DL[a, k - 1]
-                fifo_push(R[0, 0])
-                for a in range(1, KH):
-                    DL[a, 0] = shift(a, fifo_pop(a), R[0, 0])
-            ac = [np.zeros((LANES, 4)) for _ in range(MT)]
-            for a in range(KH):
-                for b in range(KW):
-                    for j in range(NK):
-                        for mt in range(MT):
-                            ac[mt] = mm((a, b), j, mt, R[a, b, j], ac[mt])
+        vn = np.zeros((NK, LANES))
+        acprev = [np.zeros((LANES, 4)) for _ in range(MT)]
+
+        def emit(ac, slot):
             xpk = pack_d(ac, c)
             for j in range(NKD):
-                xring[j, xs, lanes] = xpk[j]
-            cc = np.where(cc + 1 == W, 0, cc + 1)
-            zc = np.where(zc + 1 == 12, 0, zc + 1)
+                xring[j, slot, lanes] = xpk[j]
+
+        for t in range(-4, Tend):
+            wrapn = cn == 0
+            ac = [np.zeros((LANES, 4)) for _ in range(MT)]
+            fvs = {}
+            for ci in range(KH * KW):
+                a, b = ci // KW, KW - 1 - ci % KW
+                for j in range(NK):
+                    for mt in range(MT):
+                        ac[mt] = mm((a, b), j, mt, R[a, b, j], ac[mt])
+                if b >= 1:
+                    R[a, b] = np.where(wrapn, 0.0, R[a, b - 1])
+                if ci == 0:
+                    emit(acprev, (xs + 7) & 7)
+                    vraw = np.stack([zring[j, nslot, lanes] for j in range(NK)])
+                if ci == (1 if KH * KW > 1 else 0):
+                    vn = np.where(cn >= 0, vraw, 0.0)
+                    if KH > 1:
+                        fifo_push(vn)
+                        fvs = {a2: fifo_pop(a2) for a2 in range(1, KH)}
+                if ci == (2 if KH * KW > 2 else KH * KW - 1):
+                    io_phase(t & 3)
+            R[0, 0] = vn
+            shift_all(fvs, vn, True)
+            acprev = ac
+            cn = np.where(cn + 1 == W, 0, cn + 1)
+            nslot = np.where(nslot + 1 == 12, 0, nslot + 1)
             xs = (xs + 1) & 7
             fslot = 0 if fslot + 1 == D else fslot + 1
-        io_store()
+        emit(acprev, (xs + 7) & 7)
+        io_sread(); io_swrite()
     return out
