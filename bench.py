@@ -42,8 +42,8 @@ WORKLOADS = {
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-sample", type=int, default=None, help="images in the CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
@@ -138,7 +138,17 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def spin_up(fn, seconds=0.25):
+        """Untimed preamble, before the W warmup steps: the card needs ~50 launches (tens of ms) after idling
+        before its clocks settle; a 20-step run measured cold reads 15-20 % low.  Not a step, not timed."""
+        t_end = time.perf_counter() + seconds
+        while time.perf_counter() < t_end:
+            for _ in range(10):
+                fn()
+            torch.cuda.synchronize()
+
     def timed(fn, steps, warmup):
+        spin_up(fn)
         for _ in range(warmup):
             fn()
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]

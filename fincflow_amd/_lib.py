@@ -7,7 +7,7 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libfinc_hip.so")
+LIB_PATH = os.environ.get("FINCFLOW_LIB") or os.path.join(HERE, "libfinc_hip.so")  # env override: debug builds only
 
 OK = 0
 ALGO = {"auto": 0, "strict": 1, "mfma": 2}

@@ -145,6 +145,11 @@ struct BTaps {
 };
 
 #define FINC_SB() __builtin_amdgcn_sched_barrier(0)
+// Timing-only ablation builds (scripts/ablate.sh): 1 = no HBM I/O, 2 = also no post-processing of the solved
+// pixel, 3 = also no operand ageing / z reads.  Results are wrong for any value but 0; never shipped.
+#ifndef FINC_ABLATE
+#define FINC_ABLATE 0
+#endif
 template <int I>
 using IC = std::integral_constant<int, I>;
 
@@ -196,19 +201,28 @@ __global__ __launch_bounds__(64) void finc_wave_kernel(const float *__restrict__
         const float *pk = packed + (size_t)g * NFRAG * 64 + lane;
 #pragma unroll
         for (int f = 0; f < NFRAG; ++f) af[f] = pk[f * 64];
+        // The fragments are only ever MFMA A operands, which may be AGPRs; everything the VALU touches must be a
+        // VGPR and there are only 256 of each.  Pin the fragments to AGPRs so the allocator does not shuffle
+        // operands between the two files (v_accvgpr_* moves are VALU issue that f32 MFMAs do not hide).
+#pragma unroll
+        for (int f = 0; f < NFRAG; ++f) asm volatile("" : "+a"(af[f]));
     }
     for (int i = lane; i < fifo_n + SS + 64; i += 64) fifo[i] = 0.f;
 
     // ---- per-lane HBM stream state -------------------------------------------------------------
     const int fl4 = -((p + 3) >> 2);          // floor(-p/4): first 4-column group this lane ever needs
-    // SEC (W % 16 == 0): a lane fetches whole 64-byte sectors (4 groups) at a time, so every sector crosses the
-    // fabric once; otherwise one 16-byte group per window (each sector is then fetched 4 times).
-    constexpr int NPC = SEC ? 4 : 1;          // 16-byte pieces held per channel
-    int lcol = SEC ? (fl4 == -4 ? -16 : 0) : 4 * fl4, lrow = p; // next chunk/group to load (canonical column)
-    int lph = fl4 & 3;                        // SEC: window phase; this lane loads when it is 0
+    // SEC (W % 8 == 0): HBM is touched in aligned 32-byte pieces (two 4-column groups), the write atom of the
+    // fabric: a lane loads 32 bytes every other window and lands one half per window; it holds an even group
+    // one window and stores it together with the odd one.  (16-byte pieces cost 4 fetches per 64-byte sector
+    // and a 32-byte partial write per store: FETCH_SIZE 4x, WRITE_SIZE 2x, and the fabric saturates at B=256.)
+    constexpr int NPC = SEC ? 2 : 1;          // 16-byte pieces held per channel
+    // first chunk this lane loads: window -3 if fl4 is even, else -2; chunk index floor(fl4/2) rounded up for odd
+    int lcol = SEC ? 8 * ((fl4 - (fl4 & 1)) / 2 + (fl4 & 1)) : 4 * fl4, lrow = p;
+    int lph = fl4 & 1;                        // SEC: window parity; this lane loads when it is 0
     int scol = 4 * (fl4 - 2), srow = p;       // next group to store
     int lslot = SEC ? ((4 * (fl4 - 1)) % 12 + 12) % 12 : ((4 * fl4) % 12 + 12) % 12; // z-ring slot of the next landing
     int sslot = (4 * (fl4 - 2)) & 7;          // x-ring slot (0,4) of the group to store
+    int sph = fl4 & 1;                        // SEC: parity of the group read next (odd: the pair is complete)
     unsigned zoff[NKZ], coff[NKD];            // per-lane channel byte offsets inside the slab
 #pragma unroll
     for (int j = 0; j < NKZ; ++j) zoff[j] = (4 * j + q) < CQ ? (unsigned)(4 * j + q) * HW * 4u : OFF_BAD_CHANNEL;
@@ -222,8 +236,14 @@ __global__ __launch_bounds__(64) void finc_wave_kernel(const float *__restrict__
     for (int j = 0; j < NKZ; ++j)
 #pragma unroll
         for (int m = 0; m < NPC; ++m) zb[j][m] = (v4u){0u, 0u, 0u, 0u};
-    float sv[NKD][4];                         // group in flight x ring -> HBM
+    float sv[NKD][4];                         // group just read from the x ring
+    float sh[NKD][4];                         // SEC: the even group held for one window
+#pragma unroll
+    for (int j = 0; j < NKD; ++j)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sh[j][k] = 0.f;
     unsigned st_off = OFF_INVALID;
+    bool st_fire = false;
     // A W-flipped group (TR/BR) is mirrored by choosing the ring SLOT of each element, never by moving data:
     // a select on a loaded value would drag the s_waitcnt for the whole HBM latency up to the issue point.
     const int k0 = fw ? 3 : 0, k1 = fw ? 2 : 1, k2 = fw ? 1 : 2, k3 = fw ? 0 : 3;
@@ -232,20 +252,20 @@ __global__ __launch_bounds__(64) void finc_wave_kernel(const float *__restrict__
         const bool ok = lcol >= 0 && lrow < H && p < P;
         const int mrow = fh ? H - 1 - lrow : lrow;
         if constexpr (SEC) {
-            // memory-ascending pieces m = 0..3 of the sector; piece m is canonical group (fw ? 3-m : m)
-            const int mcol = fw ? W - 16 - lcol : lcol;
+            // memory-ascending pieces m = 0,1 of the 32 bytes; piece m is canonical group (fw ? 1-m : m)
+            const int mcol = fw ? W - 8 - lcol : lcol;
             const unsigned off = (unsigned)(mrow * W + mcol) * 4u;
-            if (lph == 0) {                   // one row class per window (divergent: other lanes keep their data)
+            if (lph == 0) {                   // one parity class per window (divergent: other lanes keep their data)
 #pragma unroll
                 for (int j = 0; j < NKZ; ++j) {
                     const unsigned vo = ok ? off + zoff[j] : OFF_INVALID;
-#pragma unroll
-                    for (int m = 0; m < 4; ++m) zb[j][m] = __builtin_amdgcn_raw_buffer_load_b128(rin, vo + 16u * m, 0, 0);
+                    zb[j][0] = __builtin_amdgcn_raw_buffer_load_b128(rin, vo, 0, 0);
+                    zb[j][1] = __builtin_amdgcn_raw_buffer_load_b128(rin, vo + 16u, 0, 0);
                 }
-                lcol += 16;
+                lcol += 8;
                 if (lcol == W) { lcol = 0; lrow += P; }
             }
-            lph = (lph + 1) & 3;
+            lph ^= 1;
         } else {
             const int mcol = fw ? W - 4 - lcol : lcol;
             const unsigned off = (unsigned)(mrow * W + mcol) * 4u;
@@ -259,22 +279,15 @@ __global__ __launch_bounds__(64) void finc_wave_kernel(const float *__restrict__
     auto io_land = [&]() {
         float *b0 = zring + (lslot + k0) * 64 + lane, *b1 = zring + (lslot + k1) * 64 + lane;
         float *b2 = zring + (lslot + k2) * 64 + lane, *b3 = zring + (lslot + k3) * 64 + lane;
-        // SEC: the group due now is canonical group s = (lph+3)&3 of the sector held = memory piece m
-        const int sg = (lph + 3) & 3;
-        const int mp = fw ? 3 - sg : sg;
-        const bool m1 = (mp & 1) != 0, m2 = (mp & 2) != 0;
+        // SEC: the group due now is canonical group (lph ^ 1) of the pair held = memory piece (fw ? lph : lph ^ 1)
+        const bool hi = SEC && ((fw ? lph : (lph ^ 1)) != 0);
 #pragma unroll
         for (int j = 0; j < NKZ; ++j) {
             unsigned v0, v1, v2, v3;
             if constexpr (SEC) {
                 const unsigned a0 = zb[j][0].x, a1 = zb[j][0].y, a2 = zb[j][0].z, a3 = zb[j][0].w;
                 const unsigned c0 = zb[j][1].x, c1 = zb[j][1].y, c2 = zb[j][1].z, c3 = zb[j][1].w;
-                const unsigned d0 = zb[j][2].x, d1 = zb[j][2].y, d2 = zb[j][2].z, d3 = zb[j][2].w;
-                const unsigned e0 = zb[j][3].x, e1 = zb[j][3].y, e2 = zb[j][3].z, e3 = zb[j][3].w;
-                v0 = m2 ? (m1 ? e0 : d0) : (m1 ? c0 : a0);
-                v1 = m2 ? (m1 ? e1 : d1) : (m1 ? c1 : a1);
-                v2 = m2 ? (m1 ? e2 : d2) : (m1 ? c2 : a2);
-                v3 = m2 ? (m1 ? e3 : d3) : (m1 ? c3 : a3);
+                v0 = hi ? c0 : a0; v1 = hi ? c1 : a1; v2 = hi ? c2 : a2; v3 = hi ? c3 : a3;
             } else {
                 v0 = zb[j][0].x; v1 = zb[j][0].y; v2 = zb[j][0].z; v3 = zb[j][0].w;
             }
@@ -288,8 +301,11 @@ __global__ __launch_bounds__(64) void finc_wave_kernel(const float *__restrict__
     auto io_sread = [&]() {
         const bool ok = scol >= 0 && srow < H && p < P;
         const int mrow = fh ? H - 1 - srow : srow;
-        const int mcol = fw ? W - 4 - scol : scol;
+        // SEC: offset of the pair's memory-first piece, meaningful in the window that reads the odd group
+        const int ccol = SEC ? scol - 4 : scol;
+        const int mcol = fw ? W - (SEC ? 8 : 4) - ccol : ccol;
         st_off = ok ? (unsigned)(mrow * W + mcol) * 4u : OFF_INVALID;
+        st_fire = !SEC || sph != 0;
         const float *b0 = xring + (sslot + k0) * 64 + lane, *b1 = xring + (sslot + k1) * 64 + lane;
         const float *b2 = xring + (sslot + k2) * 64 + lane, *b3 = xring + (sslot + k3) * 64 + lane;
 #pragma unroll
@@ -299,23 +315,41 @@ __global__ __launch_bounds__(64) void finc_wave_kernel(const float *__restrict__
             sv[j][2] = b2[j * C::XSLOTS * 64];
             sv[j][3] = b3[j * C::XSLOTS * 64];
         }
+        sph ^= 1;
         sslot ^= 4;
         scol += 4;
         if (scol == W) { scol = 0; srow += P; }
     };
     auto io_swrite = [&]() {
+        // every lane issues; lanes whose pair is not complete (or that are off the image) drop by offset
+        const unsigned base = st_fire ? st_off : OFF_INVALID;
+        const unsigned o_even = fw ? 16u : 0u, o_odd = fw ? 0u : 16u; // held (even) group / fresh (odd) group
 #pragma unroll
         for (int j = 0; j < NKD; ++j) {
+            const unsigned vo = base == OFF_INVALID ? OFF_INVALID : base + coff[j];
             v4u v;
             v.x = __builtin_bit_cast(unsigned, sv[j][0]);
             v.y = __builtin_bit_cast(unsigned, sv[j][1]);
             v.z = __builtin_bit_cast(unsigned, sv[j][2]);
             v.w = __builtin_bit_cast(unsigned, sv[j][3]);
-            __builtin_amdgcn_raw_buffer_store_b128(v, rout, st_off == OFF_INVALID ? OFF_INVALID : st_off + coff[j], 0, 0);
+            if constexpr (SEC) {
+                v4u h;
+                h.x = __builtin_bit_cast(unsigned, sh[j][0]);
+                h.y = __builtin_bit_cast(unsigned, sh[j][1]);
+                h.z = __builtin_bit_cast(unsigned, sh[j][2]);
+                h.w = __builtin_bit_cast(unsigned, sh[j][3]);
+                __builtin_amdgcn_raw_buffer_store_b128(h, rout, vo + o_even, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(v, rout, vo + o_odd, 0, 0);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) sh[j][k] = st_fire ? sh[j][k] : sv[j][k]; // even group: hold it
+            } else {
+                __builtin_amdgcn_raw_buffer_store_b128(v, rout, vo, 0, 0);
+            }
         }
     };
     auto io_phase = [&](auto ph_c) {           // one quarter of the window's HBM work per step
         constexpr int PH = decltype(ph_c)::value;
+        if constexpr (FINC_ABLATE >= 1) return;
         if constexpr (PH == 0) io_sread();
         if constexpr (PH == 1) io_swrite();
         if constexpr (PH == 2) io_land();
@@ -439,19 +473,24 @@ __global__ __launch_bounds__(64) void finc_wave_kernel(const float *__restrict__
         auto step = [&](auto ph_c) {
             const bool wrapn = cn == 0;                // the next position starts a row
             const bool started = cn >= 0;
+            // the masks cost VALU issue that f32 MFMAs do not hide: apply them only on the steps where a lane
+            // wraps (16 of every W steps) / has not started yet (the first 16 steps)
+            const bool any_wrap = __builtin_amdgcn_ballot_w64(wrapn) != 0;
+            const bool any_idle = __builtin_amdgcn_ballot_w64(!started) != 0;
             float zraw[NKZ], zv[NKZ], xpk[NKD];
             v4f accn[MT];
 
             // ---- RA1: z of the next position is requested; operands that do not depend on this step age
 #pragma unroll
-            for (int j = 0; j < NKZ; ++j) zraw[j] = zring[(j * C::ZSLOTS + nslot) * 64 + lane];
+            for (int j = 0; j < NKZ; ++j) zraw[j] = FINC_ABLATE >= 3 ? af[j] : zring[(j * C::ZSLOTS + nslot) * 64 + lane];
 #pragma unroll
             for (int a = 0; a < KH; ++a) {
+                if constexpr (FINC_ABLATE >= 3) break;
 #pragma unroll
                 for (int b = KW - 1; b >= 1; --b) {
                     if (a + b >= 2) {
 #pragma unroll
-                        for (int j = 0; j < NK; ++j) R[a][b][j] = wrapn ? 0.f : R[a][b - 1][j];
+                        for (int j = 0; j < NK; ++j) R[a][b][j] = R[a][b - 1][j];
                     }
                 }
                 if (a >= 2) {
@@ -459,11 +498,26 @@ __global__ __launch_bounds__(64) void finc_wave_kernel(const float *__restrict__
                     for (int j = 0; j < NK; ++j) R[a][0][j] = DL[a][a - 2][j];
                 }
             }
+            if (any_wrap) {
+#pragma unroll
+                for (int a = 0; a < KH; ++a)
+#pragma unroll
+                    for (int b = 1; b < KW; ++b) {
+                        if (a + b >= 2) {
+#pragma unroll
+                            for (int j = 0; j < NK; ++j) R[a][b][j] = wrapn ? 0.f : R[a][b][j];
+                        }
+                    }
+            }
             phase_a(0, NK / 2);
             FINC_SB();
             // ---- RA2
 #pragma unroll
-            for (int j = 0; j < NKZ; ++j) zv[j] = started ? zraw[j] : 0.f;
+            for (int j = 0; j < NKZ; ++j) zv[j] = zraw[j];
+            if (any_idle) {
+#pragma unroll
+                for (int j = 0; j < NKZ; ++j) zv[j] = started ? zv[j] : 0.f;
+            }
             phase_a(NK / 2, NK);
             FINC_SB();
             // ---- RB0: z-term of the next step
@@ -477,6 +531,12 @@ __global__ __launch_bounds__(64) void finc_wave_kernel(const float *__restrict__
             FINC_SB();
 
             auto post1 = [&]() {                       // the pixel solved this step leaves the accumulators
+                if constexpr (FINC_ABLATE >= 2) {          // keep every accumulator alive, do nothing else
+                    pack_d<C>(acc, xpk);
+#pragma unroll
+                    for (int j = 0; j < NKD; ++j) asm volatile("" ::"v"(xpk[j]));
+                    return;
+                }
                 pack_d<C>(acc, xpk);
 #pragma unroll
                 for (int j = 0; j < NKD; ++j) xring[(j * C::XSLOTS + xs) * 64 + lane] = xpk[j];
@@ -486,10 +546,14 @@ __global__ __launch_bounds__(64) void finc_wave_kernel(const float *__restrict__
                 }
                 if constexpr (KW > 1) {
 #pragma unroll
-                    for (int j = 0; j < NK; ++j) R[0][1][j] = wrapn ? 0.f : xpk[j];
+                    for (int j = 0; j < NK; ++j) R[0][1][j] = xpk[j];
+                    if (any_wrap) {
+#pragma unroll
+                        for (int j = 0; j < NK; ++j) R[0][1][j] = wrapn ? 0.f : R[0][1][j];
+                    }
                 }
             };
-            auto post2 = [&]() { shift_all(xpk, false); };
+            auto post2 = [&]() { if constexpr (FINC_ABLATE < 2) shift_all(xpk, false); };
 
             // ---- RB1..: one region per remaining tap, side work attached to the first three
             auto chunk = [&](auto ci_c) {
@@ -553,6 +617,8 @@ __global__ __launch_bounds__(64) void finc_wave_kernel(const float *__restrict__
         auto step = [&](auto ph_c, v4f (&ac)[MT], const v4f (&acprev)[MT]) {
             const bool wrapn = cn == 0;
             const bool started = cn >= 0;
+            const bool any_wrap = __builtin_amdgcn_ballot_w64(wrapn) != 0;
+            const bool any_idle = __builtin_amdgcn_ballot_w64(!started) != 0;
             float vraw[NK];
             auto side = [&](auto k_c) {
                 constexpr int K = decltype(k_c)::value;
@@ -563,7 +629,11 @@ __global__ __launch_bounds__(64) void finc_wave_kernel(const float *__restrict__
                 }
                 if constexpr (K == 1) {
 #pragma unroll
-                    for (int j = 0; j < NK; ++j) vn[j] = started ? vraw[j] : 0.f;
+                    for (int j = 0; j < NK; ++j) vn[j] = vraw[j];
+                    if (any_idle) {
+#pragma unroll
+                        for (int j = 0; j < NK; ++j) vn[j] = started ? vn[j] : 0.f;
+                    }
                     if constexpr (KH > 1) {
                         fifo_push(vn);
                         fifo_pop_all();
@@ -587,7 +657,11 @@ __global__ __launch_bounds__(64) void finc_wave_kernel(const float *__restrict__
                 // operand of this tap for the NEXT step (its MFMAs above have been issued: WAR-safe in order)
                 if constexpr (b >= 1) {
 #pragma unroll
-                    for (int j = 0; j < NK; ++j) R[a][b][j] = wrapn ? 0.f : R[a][b - 1][j];
+                    for (int j = 0; j < NK; ++j) R[a][b][j] = R[a][b - 1][j];
+                    if (any_wrap) {
+#pragma unroll
+                        for (int j = 0; j < NK; ++j) R[a][b][j] = wrapn ? 0.f : R[a][b][j];
+                    }
                 }
                 if constexpr (CI == 0) side(IC<0>{});
                 if constexpr (CI == (NCH > 1 ? 1 : 0)) side(IC<1>{});
@@ -688,7 +762,7 @@ struct Inst {
     int cqp, kh, kw;
     bool fwd;
     wave_fn fn;      // 16-byte-group I/O (any W % 4 == 0)
-    wave_fn fn_sec;  // 64-byte-sector I/O (W % 16 == 0)
+    wave_fn fn_sec;  // 32-byte-piece I/O (W % 8 == 0)
     int nkz, nkd, nk, mt, nfrag, pack;
 };
 
@@ -769,7 +843,7 @@ int finc_mfma_launch(const float *in, const void *packed, float *out, const Finc
     const int NB = (s.H + P - 1) / P;
     const int Tend = (NB * s.W + P - 1 + 3) / 4 * 4;
     const size_t lds = lds_bytes(*i, s.W, P);
-    const wave_fn fn = (s.W % 16 == 0) ? i->fn_sec : i->fn;
+    const wave_fn fn = (s.W % 8 == 0) ? i->fn_sec : i->fn;
     static thread_local const void *attr_done[128];
     static thread_local int n_attr = 0;
     if (lds > 48 * 1024) {

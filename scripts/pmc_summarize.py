@@ -7,7 +7,7 @@ for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursiv
         k = row["Kernel_Name"]
         if "finc_wave_kernel" not in k:
             continue
-        k = "inverse" if "false>" in k else "forward"
+        k = "inverse" if "3, false" in k or "5, false" in k or "2, false" in k else "forward"
         acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
 out = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in acc.items()}
 out["n_dispatches"] = {k: {c: len(v) for c, v in d.items()} for k, d in acc.items()}

@@ -131,21 +131,21 @@ def run(inp, wc, fwd=False):
     xring = np.full((NKD, 8, LANES), np.nan)
     fifo = np.zeros((D, NK, 4, max(KH - 1, 1)))
     fl4 = -((p + 3) >> 2)
-    SEC = W % 16 == 0                     # 64-byte sector loads (finc_wave_kernel<..., SEC=true>)
-    lcol = np.where(fl4 == -4, -16, 0) if SEC else 4 * fl4
+    SEC = W % 8 == 0                      # 32-byte pieces (finc_wave_kernel<..., SEC=true>)
+    lcol = 8 * ((fl4 - (fl4 & 1)) // 2 + (fl4 & 1)) if SEC else 4 * fl4
     lrow = p.copy()
-    lph = fl4 & 3
+    lph = fl4 & 1
     scol, srow = 4 * (fl4 - 2), p.copy()
     lslot = ((4 * (fl4 - 1)) % 12 + 12) % 12 if SEC else ((4 * fl4) % 12 + 12) % 12
     sslot = (4 * (fl4 - 2)) & 7
     zin = np.zeros((NKZ, 4, LANES))
-    zb = np.zeros((NKZ, 4, 4, LANES))     # SEC: [j][piece][element][lane]
+    zb = np.zeros((NKZ, 2, 4, LANES))     # SEC: [j][piece][element][lane]
     sv = np.zeros((NKD, 4, LANES))
-    st = dict(ok=np.zeros(LANES, bool), row=p.copy(), col=p.copy())
+    st = dict(ok=np.zeros(LANES, bool), row=p.copy(), col=p.copy(), fire=np.zeros(LANES, bool))
 
     def io_land():
         nonlocal lslot
-        sg = (lph + 3) & 3
+        sg = lph ^ 1
         for j in range(NKZ):
             for k in range(4):
                 val = zb[j, sg, k, lanes] if SEC else zin[j, k]
@@ -161,15 +161,15 @@ def run(inp, wc, fwd=False):
                 ok = lcol[lane] >= 0 and lrow[lane] < H and p[lane] < P
                 for j in range(NKZ):
                     ch = 4 * j + q[lane]
-                    for m in range(4):
+                    for m in range(2):
                         for k in range(4):
                             zb[j, m, k, lane] = inp[ch, lrow[lane], lcol[lane] + 4 * m + k] if (ok and ch < CQ) else 0.0
             load = lph == 0
-            lcol = np.where(load, lcol + 16, lcol)
+            lcol = np.where(load, lcol + 8, lcol)
             wrap = load & (lcol == W)
             lcol = np.where(wrap, 0, lcol)
             lrow = np.where(wrap, lrow + P, lrow)
-            lph = (lph + 1) & 3
+            lph = lph ^ 1
             return
         for lane in range(LANES):
             ok = lcol[lane] >= 0 and lrow[lane] < H and p[lane] < P
@@ -182,13 +182,18 @@ def run(inp, wc, fwd=False):
         lcol = np.where(wrap, 0, lcol)
         lrow = np.where(wrap, lrow + P, lrow)
 
+    sh = np.zeros((NKD, 4, LANES))        # SEC: the even group, held one window
+    sph = fl4 & 1
+
     def io_sread():
-        nonlocal scol, srow, sslot
+        nonlocal scol, srow, sslot, sph
         st["ok"] = (scol >= 0) & (srow < H) & (p < P)
-        st["row"], st["col"] = srow.copy(), scol.copy()
+        st["row"], st["col"] = srow.copy(), (scol - 4 if SEC else scol)
+        st["fire"] = (sph != 0) if SEC else np.ones(LANES, bool)
         for j in range(NKD):
             for k in range(4):
                 sv[j, k] = xring[j, sslot + k, lanes]
+        sph = sph ^ 1
         sslot = sslot ^ 4
         scol = scol + 4
         wrap = scol == W
@@ -197,12 +202,19 @@ def run(inp, wc, fwd=False):
 
     def io_swrite():
         for lane in range(LANES):
-            if st["ok"][lane]:
-                for j in range(NKD):
-                    ch = chan_d(MT, c["PACK"], j, q[lane])
-                    if ch < CQ:
-                        for k in range(4):
-                            out[ch, st["row"][lane], st["col"][lane] + k] = sv[j, k, lane]
+            if st["fire"][lane]:
+                if st["ok"][lane]:
+                    for j in range(NKD):
+                        ch = chan_d(MT, c["PACK"], j, q[lane])
+                        if ch < CQ:
+                            for k in range(4):
+                                if SEC:
+                                    out[ch, st["row"][lane], st["col"][lane] + k] = sh[j, k, lane]
+                                    out[ch, st["row"][lane], st["col"][lane] + 4 + k] = sv[j, k, lane]
+                                else:
+                                    out[ch, st["row"][lane], st["col"][lane] + k] = sv[j, k, lane]
+            else:
+                sh[:, :, lane] = sv[:, :, lane]
 
     def io_phase(ph):
         [io_sread, io_swrite, io_land, io_issue][ph]()
