@@ -121,8 +121,8 @@ def main():
     torch.manual_seed(1234)
     unit = FastFlowUnit(C, C, K).to(dev)
     if world > 1:  # the one collective of the path: replicate the layer (<= 83 KB) from rank 0
-        for w in unit._weights():
-            dist.broadcast(w.data, src=0)
+        from fincflow_amd.dist import broadcast_weights
+        broadcast_weights(unit, src=0)
     gen = torch.Generator(device=dev).manual_seed(1000 + rank)  # each rank owns different images
     x = torch.randn(B, C, H, W, device=dev, generator=gen)
     with torch.no_grad():

@@ -150,6 +150,12 @@ class PackedWeights:
         self.w_canon = None
         self.packed_inv = None
 
+    def invalidate(self):
+        """Force a rebuild on the next call.  Needed after writes that do not bump Tensor._version
+        (torch.distributed collectives, writes through `.data`)."""
+        self.key = None
+        self.packed_inv = None
+
     def get(self, weights, G, orient):
         key = tuple((w.data_ptr(), w._version) for w in weights) + (orient,)
         if key != self.key:
