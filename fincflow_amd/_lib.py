@@ -55,7 +55,7 @@ def lib():
     runp = [vp, vp, vp, i, i, i, i, i, i, i, u, vp]
     L.finc_inverse_packed_f32.argtypes = runp
     L.finc_forward_packed_f32.argtypes = runp
-    L.finc_backward_f32.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, i, i, u, vp]
+    L.finc_backward_f32.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, i, i, u, vp, sz, vp]
     for name in SYMBOLS:
         getattr(L, name)  # AttributeError here = header and library out of sync
     _lib = L

@@ -119,17 +119,19 @@ size_t finc_workspace_bytes(int G, int Cq, int KH, int KW)
 {
     if (G <= 0 || Cq <= 0 || KH <= 0 || KW <= 0) return 256;
     size_t n = finc_mfma_packed_bytes(G, Cq, KH, KW);
+    const size_t c = finc_conv_packed_bytes(G, Cq, KH, KW);
+    if (c > n) n = c;
     return n < 256 ? 256 : n;
 }
 
 int finc_inverse_algo_for(int Cq, int H, int W, int KH, int KW)
 {
-    return finc_mfma_supported(Cq, H, W, KH, KW, false) ? FINC_ALGO_MFMA : FINC_ALGO_STRICT;
+    return finc_mfma_supported(Cq, H, W, KH, KW) ? FINC_ALGO_MFMA : FINC_ALGO_STRICT;
 }
 
 int finc_forward_algo_for(int Cq, int H, int W, int KH, int KW)
 {
-    return finc_mfma_supported(Cq, H, W, KH, KW, true) ? FINC_ALGO_MFMA : FINC_ALGO_STRICT;
+    return finc_conv_supported(Cq, H, W, KH, KW) ? FINC_ALGO_MFMA : FINC_ALGO_STRICT;
 }
 
 static int run(const float *in, const float *w_canon, float *out, int B, int G, int Cq, int H, int W, int KH,
@@ -148,10 +150,16 @@ static int run(const float *in, const float *w_canon, float *out, int B, int G, 
         return forward ? finc_launch_forward_generic(in, w_canon, out, s, st)
                        : finc_launch_inverse_strict(in, w_canon, out, s, st);
     if (algo != FINC_ALGO_MFMA) return FINC_ERR_UNSUPPORTED;
-    if (!finc_mfma_supported(Cq, H, W, KH, KW, forward)) return FINC_ERR_UNSUPPORTED;
+    if (forward) {
+        if (!finc_conv_supported(Cq, H, W, KH, KW)) return FINC_ERR_UNSUPPORTED;
+        if (!workspace || workspace_bytes < finc_conv_packed_bytes(G, Cq, KH, KW)) return FINC_ERR_WORKSPACE;
+        if (int e = finc_conv_pack(w_canon, workspace, G, Cq, KH, KW, false, st)) return e;
+        return finc_conv_launch(in, workspace, out, s, st);
+    }
+    if (!finc_mfma_supported(Cq, H, W, KH, KW)) return FINC_ERR_UNSUPPORTED;
     if (!workspace || workspace_bytes < finc_mfma_packed_bytes(G, Cq, KH, KW)) return FINC_ERR_WORKSPACE;
-    if (int e = finc_mfma_pack(w_canon, workspace, G, Cq, KH, KW, forward, st)) return e;
-    return finc_mfma_launch(in, workspace, out, s, forward, st);
+    if (int e = finc_mfma_pack(w_canon, workspace, G, Cq, KH, KW, st)) return e;
+    return finc_mfma_launch(in, workspace, out, s, st);
 }
 
 int finc_inverse_f32(const float *z, const float *w_canon, float *x, int B, int G, int Cq, int H, int W, int KH,
@@ -170,8 +178,12 @@ static int pack(const float *w_canon, void *packed, int G, int Cq, int KH, int K
 {
     if (!w_canon || !packed) return FINC_ERR_NULL_POINTER;
     if (int e = check_shape(1, G, Cq, 1, 1, KH, KW)) return e;
+    if (forward) {
+        if (finc_conv_packed_bytes(G, Cq, KH, KW) == 0) return FINC_ERR_UNSUPPORTED;
+        return finc_conv_pack(w_canon, packed, G, Cq, KH, KW, false, (hipStream_t)stream);
+    }
     if (finc_mfma_packed_bytes(G, Cq, KH, KW) == 0) return FINC_ERR_UNSUPPORTED;
-    return finc_mfma_pack(w_canon, packed, G, Cq, KH, KW, forward, (hipStream_t)stream);
+    return finc_mfma_pack(w_canon, packed, G, Cq, KH, KW, (hipStream_t)stream);
 }
 
 int finc_pack_inverse_weights_f32(const float *w_canon, void *packed, int G, int Cq, int KH, int KW,
@@ -193,9 +205,13 @@ static int run_packed(const float *in, const void *packed, float *out, int B, in
     if (int e = check_shape(B, G, Cq, H, W, KH, KW)) return e;
     if (misaligned(in) || misaligned(out)) return FINC_ERR_ALIGNMENT;
     if (in == out) return FINC_ERR_BAD_DIMS;
-    if (!finc_mfma_supported(Cq, H, W, KH, KW, forward)) return FINC_ERR_UNSUPPORTED;
     FincShape s{B, G, Cq, H, W, KH, KW, orient};
-    return finc_mfma_launch(in, packed, out, s, forward, (hipStream_t)stream);
+    if (forward) {
+        if (!finc_conv_supported(Cq, H, W, KH, KW)) return FINC_ERR_UNSUPPORTED;
+        return finc_conv_launch(in, packed, out, s, (hipStream_t)stream);
+    }
+    if (!finc_mfma_supported(Cq, H, W, KH, KW)) return FINC_ERR_UNSUPPORTED;
+    return finc_mfma_launch(in, packed, out, s, (hipStream_t)stream);
 }
 
 int finc_inverse_packed_f32(const float *z, const void *packed, float *x, int B, int G, int Cq, int H, int W, int KH,
@@ -211,14 +227,27 @@ int finc_forward_packed_f32(const float *x, const void *packed, float *z, int B,
 }
 
 int finc_backward_f32(const float *grad_z, const float *x, const float *w_canon, float *grad_x, float *grad_w_canon,
-                      int B, int G, int Cq, int H, int W, int KH, int KW, unsigned orient, finc_stream_t stream)
+                      int B, int G, int Cq, int H, int W, int KH, int KW, unsigned orient, void *workspace,
+                      size_t workspace_bytes, finc_stream_t stream)
 {
     if (!grad_z) return FINC_ERR_NULL_POINTER;
     if (grad_x && !w_canon) return FINC_ERR_NULL_POINTER;
     if (grad_w_canon && !x) return FINC_ERR_NULL_POINTER;
     if (int e = check_shape(B, G, Cq, H, W, KH, KW)) return e;
+    if (grad_x == grad_z) return FINC_ERR_BAD_DIMS;
     FincShape s{B, G, Cq, H, W, KH, KW, orient};
-    return finc_launch_backward_generic(grad_z, x, w_canon, grad_x, grad_w_canon, s, (hipStream_t)stream);
+    hipStream_t st = (hipStream_t)stream;
+    // grad_x: the same conv on the H- and W-flipped image with in/out channels transposed (finc_conv.hip)
+    if (grad_x && workspace && finc_conv_supported(Cq, H, W, KH, KW) &&
+        workspace_bytes >= finc_conv_packed_bytes(G, Cq, KH, KW)) {
+        if (int e = finc_conv_pack(w_canon, workspace, G, Cq, KH, KW, true, st)) return e;
+        FincShape sb = s;
+        sb.orient = orient ^ ((G >= 16) ? 0xFFFFFFFFu : ((1u << (2 * G)) - 1u));
+        if (int e = finc_conv_launch(grad_z, workspace, grad_x, sb, st)) return e;
+        grad_x = nullptr;
+    }
+    if (!grad_x && !grad_w_canon) return FINC_OK;
+    return finc_launch_backward_generic(grad_z, x, w_canon, grad_x, grad_w_canon, s, st);
 }
 
 } // extern "C"

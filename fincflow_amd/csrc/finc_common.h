@@ -44,8 +44,14 @@ int finc_launch_forward_generic(const float *x, const float *wc, float *z, const
 int finc_launch_backward_generic(const float *gz, const float *x, const float *wc, float *gx, float *gw,
                                  const FincShape &s, hipStream_t st);
 
-// ---- MFMA wavefront kernels: finc_mfma.hip ----
-bool finc_mfma_supported(int Cq, int H, int W, int KH, int KW, bool forward);
+// ---- inverse, MFMA wavefront kernel: finc_mfma.hip ----
+bool finc_mfma_supported(int Cq, int H, int W, int KH, int KW);
 size_t finc_mfma_packed_bytes(int G, int Cq, int KH, int KW);
-int finc_mfma_pack(const float *wc, void *packed, int G, int Cq, int KH, int KW, bool forward, hipStream_t st);
-int finc_mfma_launch(const float *in, const void *packed, float *out, const FincShape &s, bool forward, hipStream_t st);
+int finc_mfma_pack(const float *wc, void *packed, int G, int Cq, int KH, int KW, hipStream_t st);
+int finc_mfma_launch(const float *in, const void *packed, float *out, const FincShape &s, hipStream_t st);
+
+// ---- forward / grad-input, MFMA strip kernel: finc_conv.hip ----
+bool finc_conv_supported(int Cq, int H, int W, int KH, int KW);
+size_t finc_conv_packed_bytes(int G, int Cq, int KH, int KW);
+int finc_conv_pack(const float *wc, void *packed, int G, int Cq, int KH, int KW, bool transpose, hipStream_t st);
+int finc_conv_launch(const float *in, const void *packed, float *out, const FincShape &s, hipStream_t st);

@@ -1,0 +1,275 @@
+// Forward masked convolution (and, with transposed fragments, its input gradient) for gfx950.
+//
+// The forward has no recurrence, so it does not use the skewed wavefront of finc_mfma.hip.  One wavefront
+// owns a STRIP of 16 canonical columns of one (image, group) slab and walks it top to bottom, one row per step:
+//
+//   * lane (q,p): column w0+p, k-slot q.  The 16 lanes of a row q read 16 consecutive floats of one channel row
+//     = one 64-byte sector per load and per store: HBM traffic is coalesced by construction, no LDS at all.
+//   * per step: z[Cq x 16px] = sum_{a,b} W_ab * x[(h-a, w-b)]  as KH*KW*ceil(Cq/4)*ceil(Cq/16)
+//     v_mfma_f32_16x16x4_f32, all independent (two accumulator chains per output tile).
+//   * column shifts b come from DPP row_shr:b, the b columns left of the strip from a tiny masked "halo" load;
+//     row shifts a are the operands of the previous rows, kept in registers (the row slot rotates with the
+//     loop, which is unrolled by KH, so ageing a row costs no instruction).
+//   * filter fragments live in AGPRs for the whole kernel (same packing as the wavefront kernel: fragment
+//     (tap, j, mt), lane (q,i) = W[16mt+i][4j+q]).
+//
+// grad_input of this conv is the same operator on the H- and W-flipped image with in/out channels transposed
+// (DESIGN.md 3.3), so finc_backward_f32 calls this kernel with `transpose` fragments and orient ^ 3 per group.
+// Replaces F.pad + cuDNN conv (layers/conv.py:102-107) x4 + chunk/cat (fastflow.py:31-50).
+#include "finc_common.h"
+
+#include <type_traits>
+#include <utility>
+
+namespace {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+constexpr unsigned OFF_INVALID = 0x80000000u;
+constexpr unsigned OFF_BAD_CHANNEL = 0x40000000u;
+
+template <int I>
+using IC = std::integral_constant<int, I>;
+
+template <int N>
+__device__ inline float row_shr(float old, float src)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old),
+                                                                 __builtin_bit_cast(int, src), 0x110 + N, 0xf, 0xf,
+                                                                 false));
+}
+template <int N>
+__device__ inline float row_shl(float src)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, src), 0x100 + N, 0xf, 0xf,
+                                                                 true));
+}
+
+template <int CQP, int KH, int KW>
+__global__ __launch_bounds__(64) void finc_conv_kernel(const float *__restrict__ in, const float *__restrict__ packed,
+                                                       float *__restrict__ out, int G, int CQ, int H, int W, int NS,
+                                                       unsigned orient)
+{
+    constexpr int MT = (CQP + 15) / 16, NKZ = CQP / 4, NTAP = KH * KW, NFRAG = NTAP * NKZ * MT;
+    const int lane = threadIdx.x;
+    const int q = lane >> 4, p = lane & 15;
+    const int strip = blockIdx.x % NS;
+    const int bg = blockIdx.x / NS;
+    const int g = bg % G;
+    const unsigned o = finc_group_orient(orient, g);
+    const bool fh = (o & FINC_FLIP_H) != 0, fw = (o & FINC_FLIP_W) != 0;
+    const int HW = H * W;
+    const unsigned slab_bytes = (unsigned)CQ * (unsigned)HW * 4u;
+    const __amdgpu_buffer_rsrc_t rin =
+        __builtin_amdgcn_make_buffer_rsrc((void *)(in + (size_t)bg * CQ * HW), 0, (int)slab_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rout =
+        __builtin_amdgcn_make_buffer_rsrc((void *)(out + (size_t)bg * CQ * HW), 0, (int)slab_bytes, 0x00020000);
+
+    float af[NFRAG];
+    {
+        const float *pk = packed + (size_t)g * NFRAG * 64 + lane;
+#pragma unroll
+        for (int f = 0; f < NFRAG; ++f) af[f] = pk[f * 64];
+#pragma unroll
+        for (int f = 0; f < NFRAG; ++f) asm volatile("" : "+a"(af[f])); // MFMA A operands: keep them out of the VGPRs
+    }
+
+    // Addressing is branch-free and select-free: a buffer offset = (row part, scalar) + (lane part, constant).
+    // An off-image row contributes OFF_INVALID (2^31), an off-image column or padded channel OFF_BAD_CHANNEL
+    // (2^30); any such sum lands beyond the slab (< 2^30 bytes), where loads return 0 and stores are dropped.
+    const int col = strip * 16 + p;
+    const int hcol = strip * 16 - (KW - 1) + p;           // lanes p < KW-1 also hold the columns left of the strip
+    const bool colok = col < W;
+    const bool hok = p < KW - 1 && hcol >= 0;
+    const unsigned coloff = (unsigned)(fw ? W - 1 - col : col) * 4u;
+    const unsigned hcoloff = (unsigned)(fw ? W - 1 - hcol : hcol) * 4u;
+    unsigned lin[NKZ], lhal[NKZ], lout[MT][4];
+#pragma unroll
+    for (int j = 0; j < NKZ; ++j) {
+        const bool chok = (4 * j + q) < CQ;
+        const unsigned ch = (unsigned)(4 * j + q) * HW * 4u;
+        lin[j] = (colok && chok) ? coloff + ch : OFF_BAD_CHANNEL;
+        lhal[j] = (hok && chok) ? hcoloff + ch : OFF_BAD_CHANNEL;
+    }
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int c = 16 * mt + 4 * q + r;
+            lout[mt][r] = (colok && c < CQ) ? coloff + (unsigned)c * HW * 4u : OFF_BAD_CHANNEL;
+        }
+    auto rowoff = [&](int h) {                            // scalar
+        return (h >= 0 && h < H) ? (unsigned)((fh ? H - 1 - h : h) * W) * 4u : OFF_INVALID;
+    };
+
+    float X[KH][KW][NKZ];                                 // X[s][b]: row slot s, shifted b columns
+#pragma unroll
+    for (int s = 0; s < KH; ++s)
+#pragma unroll
+        for (int b = 0; b < KW; ++b)
+#pragma unroll
+            for (int j = 0; j < NKZ; ++j) X[s][b][j] = 0.f;
+    float nxt[NKZ], nxh[NKZ];                             // the row loaded one step ahead (+ its halo)
+    auto issue = [&](int h) {
+        const unsigned ro = rowoff(h);
+#pragma unroll
+        for (int j = 0; j < NKZ; ++j) {
+            const unsigned u = __builtin_amdgcn_raw_buffer_load_b32(rin, ro + lin[j], 0, 0);
+            nxt[j] = __builtin_bit_cast(float, u);
+            if constexpr (KW > 1) {
+                const unsigned uh = __builtin_amdgcn_raw_buffer_load_b32(rin, ro + lhal[j], 0, 0);
+                nxh[j] = __builtin_bit_cast(float, uh);
+            }
+        }
+    };
+    v4f acc[KH][MT];                                      // one accumulator set per unrolled sub-step
+#pragma unroll
+    for (int s = 0; s < KH; ++s)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[s][mt] = (v4f){0.f, 0.f, 0.f, 0.f};
+
+    auto store_row = [&](const v4f (&ac)[MT], int h) {   // h = the row those accumulators belong to
+        const unsigned ro = rowoff(h);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const float v0 = ac[mt].x, v1 = ac[mt].y, v2 = ac[mt].z, v3 = ac[mt].w;
+            const float vv[4] = {v0, v1, v2, v3};
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vv[r]), rout, ro + lout[mt][r], 0, 0);
+        }
+    };
+
+    auto step = [&](auto s_c, int h) {
+        constexpr int S = decltype(s_c)::value;           // row slot of row h  (h % KH == S)
+        // the row that arrived becomes column-shift 0 of slot S; its shifted copies follow
+#pragma unroll
+        for (int j = 0; j < NKZ; ++j) X[S][0][j] = nxt[j];
+        if constexpr (KW > 1) {
+            float hl[NKZ];
+#pragma unroll
+            for (int j = 0; j < NKZ; ++j) hl[j] = nxh[j];
+            // lane p < b needs column w0+p-b = halo lane p-b+KW-1: shift the halo left by KW-1-b first
+#pragma unroll
+            for (int j = 0; j < NKZ; ++j) {
+                if constexpr (KW > 1) X[S][KW - 1][j] = row_shr<KW - 1>(hl[j], nxt[j]);
+                if constexpr (KW > 2) X[S][KW - 2][j] = row_shr<KW - 2>(row_shl<1>(hl[j]), nxt[j]);
+                if constexpr (KW > 3) X[S][KW - 3][j] = row_shr<KW - 3>(row_shl<2>(hl[j]), nxt[j]);
+                if constexpr (KW > 4) X[S][KW - 4][j] = row_shr<KW - 4>(row_shl<3>(hl[j]), nxt[j]);
+                if constexpr (KW > 5) X[S][KW - 5][j] = row_shr<KW - 5>(row_shl<4>(hl[j]), nxt[j]);
+                if constexpr (KW > 6) X[S][KW - 6][j] = row_shr<KW - 6>(row_shl<5>(hl[j]), nxt[j]);
+            }
+        }
+        issue(h + 1);                                     // next row: a whole step of MFMAs to arrive
+        // the previous row's result leaves while this row's MFMAs run
+        store_row(acc[(S + KH - 1) % KH], h - 1);
+        v4f ac[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) ac[mt] = (v4f){0.f, 0.f, 0.f, 0.f};
+        // rows h-a live in slot (S - a) mod KH; older rows first (their operands are long ready)
+#pragma unroll
+        for (int a = KH - 1; a >= 0; --a)
+#pragma unroll
+            for (int b = 0; b < KW; ++b)
+#pragma unroll
+                for (int j = 0; j < NKZ; ++j)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+                        ac[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[((a * KW + b) * NKZ + j) * MT + mt],
+                                                                      X[(S + KH - a) % KH][b][j], ac[mt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acc[S][mt] = ac[mt];
+    };
+
+    issue(0);
+    for (int h0 = 0; h0 < H + 1; h0 += KH) {
+        [&]<int... I>(std::integer_sequence<int, I...>) { (step(IC<I>{}, h0 + I), ...); }
+        (std::make_integer_sequence<int, KH>{});
+    }
+}
+
+// fragment (tap (a,b), j, mt), lane (q,i): W[row 16mt+i][col 4j+q][KH-1-a][KW-1-b]; `transpose` swaps row/col
+__global__ void conv_pack_kernel(const float *__restrict__ wc, float *__restrict__ packed, int Cq, int KH, int KW, int MT,
+                                 int NKZ, int transpose, int nfrag)
+{
+    const int g = blockIdx.y;
+    const float *wg = wc + (size_t)g * Cq * Cq * KH * KW;
+    const int KK = KH * KW;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < nfrag * 64; e += gridDim.x * blockDim.x) {
+        const int lane = e & 63, f = e >> 6;
+        const int q = lane >> 4, i = lane & 15;
+        const int mt = f % MT, j = (f / MT) % NKZ, tap = f / (MT * NKZ);
+        const int row = 16 * mt + i, col = 4 * j + q;
+        const int a = tap / KW, b = tap % KW;
+        float v = 0.f;
+        if (row < Cq && col < Cq) {
+            const int oc = transpose ? col : row, ic = transpose ? row : col;
+            v = wg[((size_t)oc * Cq + ic) * KK + (KH - 1 - a) * KW + (KW - 1 - b)];
+        }
+        packed[((size_t)g * nfrag + f) * 64 + lane] = v;
+    }
+}
+
+typedef void (*conv_fn)(const float *, const float *, float *, int, int, int, int, int, unsigned);
+struct ConvInst {
+    int cqp, kh, kw;
+    conv_fn fn;
+    int mt, nkz, nfrag;
+};
+template <int CQP, int KH, int KW>
+constexpr ConvInst make_conv()
+{
+    return ConvInst{CQP, KH, KW, finc_conv_kernel<CQP, KH, KW>, (CQP + 15) / 16, CQP / 4,
+                    KH * KW * (CQP / 4) * ((CQP + 15) / 16)};
+}
+const ConvInst g_conv[] = {
+    make_conv<4, 3, 3>(),  make_conv<8, 3, 3>(),  make_conv<12, 3, 3>(), make_conv<16, 3, 3>(), make_conv<24, 3, 3>(),
+    make_conv<32, 3, 3>(), make_conv<48, 3, 3>(), make_conv<4, 2, 2>(),  make_conv<16, 2, 2>(), make_conv<4, 5, 5>(),
+    make_conv<16, 5, 5>(), make_conv<4, 3, 5>(),  make_conv<4, 1, 3>(),  make_conv<4, 3, 1>(),
+};
+const ConvInst *find_conv(int Cq, int KH, int KW)
+{
+    const int cqp = (Cq + 3) / 4 * 4;
+    for (const ConvInst &i : g_conv)
+        if (i.cqp == cqp && i.kh == KH && i.kw == KW) return &i;
+    return nullptr;
+}
+
+} // namespace
+
+bool finc_conv_supported(int Cq, int H, int W, int KH, int KW)
+{
+    if (!find_conv(Cq, KH, KW)) return false;
+    if ((size_t)Cq * H * W * 4 >= ((size_t)1 << 30)) return false;
+    return true;
+}
+
+size_t finc_conv_packed_bytes(int G, int Cq, int KH, int KW)
+{
+    const ConvInst *i = find_conv(Cq, KH, KW);
+    return i ? (size_t)i->nfrag * 64 * sizeof(float) * (size_t)G : 0;
+}
+
+int finc_conv_pack(const float *wc, void *packed, int G, int Cq, int KH, int KW, bool transpose, hipStream_t st)
+{
+    const ConvInst *i = find_conv(Cq, KH, KW);
+    if (!i) return FINC_ERR_UNSUPPORTED;
+    const int total = i->nfrag * 64;
+    int blocks = (total + 255) / 256;
+    if (blocks > 64) blocks = 64;
+    hipLaunchKernelGGL(conv_pack_kernel, dim3(blocks, G), dim3(256), 0, st, wc, (float *)packed, Cq, KH, KW, i->mt,
+                       i->nkz, transpose ? 1 : 0, i->nfrag);
+    FINC_CHECK_LAUNCH();
+    return FINC_OK;
+}
+
+int finc_conv_launch(const float *in, const void *packed, float *out, const FincShape &s, hipStream_t st)
+{
+    const ConvInst *i = find_conv(s.Cq, s.KH, s.KW);
+    if (!i || !finc_conv_supported(s.Cq, s.H, s.W, s.KH, s.KW)) return FINC_ERR_UNSUPPORTED;
+    const int NS = (s.W + 15) / 16;
+    hipLaunchKernelGGL(i->fn, dim3(s.B * s.G * NS), dim3(64), 0, st, in, (const float *)packed, out, s.G, s.Cq, s.H,
+                       s.W, NS, s.orient);
+    FINC_CHECK_LAUNCH();
+    return FINC_OK;
+}

@@ -32,9 +32,7 @@
 //     are staged through per-lane LDS rings, because lane p is (t-p) mod 4
 //     into its 4-column group.
 //
-// The forward kernel is the same machine with the input stream in place of the
-// solved pixels (no recurrence), so it shares the I/O rings, the DPP/FIFO
-// neighbour exchange and the fragment packing.
+// The forward has no recurrence and uses a different, simpler mapping: finc_conv.hip.
 #include "finc_common.h"
 
 #include <type_traits>
@@ -46,18 +44,17 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 typedef unsigned v2u __attribute__((ext_vector_type(2)));
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
 
-template <int CQP_, int KH_, int KW_, bool FWD_>
+template <int CQP_, int KH_, int KW_>
 struct Cfg {
     static constexpr int CQP = CQP_, KH = KH_, KW = KW_;
-    static constexpr bool FWD = FWD_;
     static constexpr int MT = (CQP + 15) / 16;            // 16-row output-channel tiles
     static constexpr int NKZ = CQP / 4;                   // k-steps of a streamed operand (k-slot q <-> channel 4j+q)
     static constexpr int LASTV = (CQP - 16 * (MT - 1)) / 4; // k-slots of the last D tile that hold real channels
     static constexpr bool PACK = LASTV <= 2;              // fold the last tile's 4 half-empty regs into 2
     static constexpr int NKD = PACK ? 4 * (MT - 1) + 2 : 4 * MT; // regs of a D-layout result as operand / for store
-    static constexpr int NK = FWD ? NKZ : NKD;            // k-steps per neighbour tap
+    static constexpr int NK = NKD;                        // k-steps per neighbour tap
     static constexpr int NTAP = KH * KW;
-    static constexpr int NFRAG = FWD ? NTAP * NKZ * MT : (NKZ + (NTAP - 1) * NKD) * MT;
+    static constexpr int NFRAG = (NKZ + (NTAP - 1) * NKD) * MT;
     static constexpr int ZSLOTS = 12, XSLOTS = 8;
     static constexpr int ZRING = NKZ * ZSLOTS * 64;       // floats
     static constexpr int XRING = NKD * XSLOTS * 64;
@@ -118,7 +115,7 @@ __device__ inline void pack_d(const v4f (&acc)[C::MT], float (&xpk)[C::NKD])
     }
 }
 
-// taps of the inverse's phase B (a+b >= 2), row-major; taps of the forward in (a asc, b DESC) order
+// taps of the inverse's phase B (a+b >= 2), row-major
 template <int KH, int KW>
 struct BTaps {
     static constexpr int count()
@@ -165,12 +162,12 @@ constexpr unsigned OFF_BAD_CHANNEL = 0x40000000u; // added to a valid offset it 
 // issues in the shadow of the 32-cycle MFMAs.  The loop is unrolled x4 so the 4-step I/O cadence
 // (read x ring / store / land z / issue loads) falls on fixed steps.
 // -----------------------------------------------------------------------------------------------
-template <int CQP, int KH, int KW, bool FWD, bool SEC>
+template <int CQP, int KH, int KW, bool SEC>
 __global__ __launch_bounds__(64) void finc_wave_kernel(const float *__restrict__ in, const float *__restrict__ packed,
                                                        float *__restrict__ out, int G, int CQ, int H, int W, int P,
                                                        int Tend, unsigned orient)
 {
-    using C = Cfg<CQP, KH, KW, FWD>;
+    using C = Cfg<CQP, KH, KW>;
     constexpr int MT = C::MT, NKZ = C::NKZ, NKD = C::NKD, NK = C::NK, NFRAG = C::NFRAG;
     constexpr int JS = 4 * (KH - 1);          // FIFO: floats per k-step (4 k-slots x (KH-1) source lanes)
     constexpr int SS = NK * JS;               // FIFO: floats per step slot
@@ -395,8 +392,8 @@ __global__ __launch_bounds__(64) void finc_wave_kernel(const float *__restrict__
             for (int j = 0; j < NK; ++j) fv[a][j] = fifo[ptr + j * JS];
         }
     };
-    // S_a = row_shr:a(src), lanes p < a take the FIFO value; then shift the delay lines.
-    auto shift_all = [&](const float (&src)[NK], bool fwd_delay) {
+    // S_a = row_shr:a(src), lanes p < a take the FIFO value; R[a][0](t+1) = S_a(t+1-a): a-1 steps of delay line.
+    auto shift_all = [&](const float (&src)[NK]) {
         if constexpr (KH > 1) {
             float sn[KH][NK];
             ShiftOp<1>::apply(sn[1], fv[1], src);
@@ -406,24 +403,15 @@ __global__ __launch_bounds__(64) void finc_wave_kernel(const float *__restrict__
             if constexpr (KH > 5) ShiftOp<5>::apply(sn[5], fv[5], src);
             if constexpr (KH > 6) ShiftOp<6>::apply(sn[6], fv[6], src);
 #pragma unroll
-            for (int a = 1; a < KH; ++a) {
-                // inverse: R[a][0](t+1) = S_a(t+1-a): a-1 steps of delay; forward (one step ahead): a steps
-                const int nd = fwd_delay ? a : a - 1;
-                if (nd == 0) {
+            for (int j = 0; j < NK; ++j) R[1][0][j] = sn[1][j];
 #pragma unroll
-                    for (int j = 0; j < NK; ++j) R[a][0][j] = sn[a][j];
-                } else {
-                    if (fwd_delay) {
+            for (int a = 2; a < KH; ++a) {
 #pragma unroll
-                        for (int j = 0; j < NK; ++j) R[a][0][j] = DL[a][nd - 1][j];
-                    }
+                for (int k = a - 2; k >= 1; --k)
 #pragma unroll
-                    for (int k = nd - 1; k >= 1; --k)
+                    for (int j = 0; j < NK; ++j) DL[a][k][j] = DL[a][k - 1][j];
 #pragma unroll
-                        for (int j = 0; j < NK; ++j) DL[a][k][j] = DL[a][k - 1][j];
-#pragma unroll
-                    for (int j = 0; j < NK; ++j) DL[a][0][j] = sn[a][j];
-                }
+                for (int j = 0; j < NK; ++j) DL[a][0][j] = sn[a][j];
             }
         }
     };
@@ -446,7 +434,7 @@ __global__ __launch_bounds__(64) void finc_wave_kernel(const float *__restrict__
     int nslot = ((-3 - p) % 12 + 12) % 12;    // z-ring slot of the position of step t+1
     int cn = -3 - p;                          // column of the position of step t+1 (negative: lane not started)
 
-    if constexpr (!FWD) {
+    {
         // =========================== inverse ===========================
         constexpr int FZ = 0;                          // z-term fragments: j*MT + mt
         constexpr int FT = NKZ * MT;                   // tap fragments: FT + (((a*KW+b)-1)*NK + j)*MT + mt
@@ -553,7 +541,7 @@ __global__ __launch_bounds__(64) void finc_wave_kernel(const float *__restrict__
                     }
                 }
             };
-            auto post2 = [&]() { if constexpr (FINC_ABLATE < 2) shift_all(xpk, false); };
+            auto post2 = [&]() { if constexpr (FINC_ABLATE < 2) shift_all(xpk); };
 
             // ---- RB1..: one region per remaining tap, side work attached to the first three
             auto chunk = [&](auto ci_c) {
@@ -596,154 +584,53 @@ __global__ __launch_bounds__(64) void finc_wave_kernel(const float *__restrict__
         }
         io_sread();
         io_swrite();
-    } else {
-        // =========================== forward ===========================
-        // fragments: ((a*KW+b)*NK + j)*MT + mt.  Operands of step t+1 are prepared while step t's MFMAs run.
-        constexpr int NCH = KH * KW;                   // chunk CI <-> tap (a = CI / KW, b = KW-1 - CI % KW)
-        v4f acA[MT], acB[MT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) { acA[mt] = (v4f){0.f, 0.f, 0.f, 0.f}; acB[mt] = (v4f){0.f, 0.f, 0.f, 0.f}; }
-        float vn[NK];
-#pragma unroll
-        for (int j = 0; j < NK; ++j) vn[j] = 0.f;
-
-        auto emit = [&](const v4f (&ac)[MT], int slot) {      // a finished pixel -> x ring
-            float xpk[NKD];
-            pack_d<C>(ac, xpk);
-#pragma unroll
-            for (int j = 0; j < NKD; ++j) xring[(j * C::XSLOTS + slot) * 64 + lane] = xpk[j];
-        };
-
-        auto step = [&](auto ph_c, v4f (&ac)[MT], const v4f (&acprev)[MT]) {
-            const bool wrapn = cn == 0;
-            const bool started = cn >= 0;
-            const bool any_wrap = __builtin_amdgcn_ballot_w64(wrapn) != 0;
-            const bool any_idle = __builtin_amdgcn_ballot_w64(!started) != 0;
-            float vraw[NK];
-            auto side = [&](auto k_c) {
-                constexpr int K = decltype(k_c)::value;
-                if constexpr (K == 0) {                // previous pixel out, next input requested
-                    emit(acprev, (xs + 7) & 7);
-#pragma unroll
-                    for (int j = 0; j < NK; ++j) vraw[j] = zring[(j * C::ZSLOTS + nslot) * 64 + lane];
-                }
-                if constexpr (K == 1) {
-#pragma unroll
-                    for (int j = 0; j < NK; ++j) vn[j] = vraw[j];
-                    if (any_idle) {
-#pragma unroll
-                        for (int j = 0; j < NK; ++j) vn[j] = started ? vn[j] : 0.f;
-                    }
-                    if constexpr (KH > 1) {
-                        fifo_push(vn);
-                        fifo_pop_all();
-                    }
-                }
-                if constexpr (K == 2) io_phase(ph_c);
-            };
-            auto chunk = [&](auto ci_c) {
-                constexpr int CI = decltype(ci_c)::value;
-                constexpr int a = CI / KW, b = KW - 1 - CI % KW;
-                if constexpr (CI == 0) {
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) ac[mt] = (v4f){0.f, 0.f, 0.f, 0.f};
-                }
-#pragma unroll
-                for (int j = 0; j < NK; ++j)
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-                        ac[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[((a * KW + b) * NK + j) * MT + mt], R[a][b][j],
-                                                                      ac[mt], 0, 0, 0);
-                // operand of this tap for the NEXT step (its MFMAs above have been issued: WAR-safe in order)
-                if constexpr (b >= 1) {
-#pragma unroll
-                    for (int j = 0; j < NK; ++j) R[a][b][j] = R[a][b - 1][j];
-                    if (any_wrap) {
-#pragma unroll
-                        for (int j = 0; j < NK; ++j) R[a][b][j] = wrapn ? 0.f : R[a][b][j];
-                    }
-                }
-                if constexpr (CI == 0) side(IC<0>{});
-                if constexpr (CI == (NCH > 1 ? 1 : 0)) side(IC<1>{});
-                if constexpr (CI == (NCH > 2 ? 2 : NCH - 1)) side(IC<2>{});
-                FINC_SB();
-            };
-            [&]<int... I>(std::integer_sequence<int, I...>) { (chunk(IC<I>{}), ...); }
-            (std::make_integer_sequence<int, NCH>{});
-            // column b = 0 of every row: the new input and its row_shr copies
-#pragma unroll
-            for (int j = 0; j < NK; ++j) R[0][0][j] = vn[j];
-            shift_all(vn, true);
-            ++cn; if (cn == W) cn = 0;
-            ++nslot; if (nslot == 12) nslot = 0;
-            xs = (xs + 1) & 7;
-            ++fslot; if (fslot == D) fslot = 0;
-        };
-
-        for (int t0 = -4; t0 < Tend; t0 += 4) {
-            step(IC<0>{}, acA, acB);
-            step(IC<1>{}, acB, acA);
-            step(IC<2>{}, acA, acB);
-            step(IC<3>{}, acB, acA);
-        }
-        emit(acB, (xs + 7) & 7);
-        io_sread();
-        io_swrite();
     }
 }
 
 // -----------------------------------------------------------------------------------------------
-// Fragment packing (fp64 math, one workgroup per group).
-//   inverse: Linv = L^-1 by forward substitution; z-term fragment = Linv; tap (a,b) fragment
-//            = -(Linv * Wc[:,:,KH-1-a,KW-1-b]).
-//   forward: tap (a,b) fragment = Wc[:,:,KH-1-a,KW-1-b].
-// Lane (q,i) of fragment (tap, j, mt) holds row 16mt+i, column = channel of k-slot q of k-step j.
+// Fragment packing (fp64 math, one workgroup per group): Linv = L^-1 by forward substitution;
+// z-term fragment = Linv; tap (a,b) fragment = -(Linv * Wc[:,:,KH-1-a,KW-1-b]).
+// Lane (q,i) of fragment (tap, j, mt) holds row 16mt+i, column = channel of k-slot q of k-step j
+// (z-term: 4j+q; taps: chan_d, the order in which the solved pixels leave the accumulators).
 // -----------------------------------------------------------------------------------------------
 __global__ void pack_kernel(const float *__restrict__ wc, float *__restrict__ packed, int Cq, int KH, int KW, int MT,
-                            int NKZ, int NKD, int pack_last, int forward, int nfrag)
+                            int NKZ, int NKD, int pack_last, int unused, int nfrag)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[]; // Linv [Cq][Cq]
     const int g = blockIdx.x;
     const float *wg = wc + (size_t)g * Cq * Cq * KH * KW;
     const int KK = KH * KW;
     double *Linv = sm;
-    if (!forward) {
-        // column j of Linv: solve L y = e_j  (L unit lower triangular)
-        for (int j = threadIdx.x; j < Cq; j += blockDim.x) {
-            for (int r = 0; r < Cq; ++r) {
-                double s = (r == j) ? 1.0 : 0.0;
-                for (int k = j; k < r; ++k)
-                    s -= (double)wg[((size_t)r * Cq + k) * KK + (KK - 1)] * Linv[k * Cq + j];
-                Linv[r * Cq + j] = (r < j) ? 0.0 : s;
-            }
+    (void)unused;
+    // column j of Linv: solve L y = e_j  (L unit lower triangular)
+    for (int j = threadIdx.x; j < Cq; j += blockDim.x) {
+        for (int r = 0; r < Cq; ++r) {
+            double s = (r == j) ? 1.0 : 0.0;
+            for (int k = j; k < r; ++k) s -= (double)wg[((size_t)r * Cq + k) * KK + (KK - 1)] * Linv[k * Cq + j];
+            Linv[r * Cq + j] = (r < j) ? 0.0 : s;
         }
-        __syncthreads();
     }
-    const int NK = forward ? NKZ : NKD;
+    __syncthreads();
     for (int e = threadIdx.x; e < nfrag * 64; e += blockDim.x) {
         const int lane = e & 63, f = e >> 6;
         const int q = lane >> 4, i = lane & 15;
         int tap, j, mt;
-        bool zterm = false;
-        if (forward) {
-            mt = f % MT; j = (f / MT) % NK; tap = f / (MT * NK);
-        } else if (f < NKZ * MT) {
-            zterm = true; mt = f % MT; j = f / MT; tap = 0;
+        const bool zterm = f < NKZ * MT;
+        if (zterm) {
+            mt = f % MT; j = f / MT; tap = 0;
         } else {
             const int ff = f - NKZ * MT;
-            mt = ff % MT; j = (ff / MT) % NK; tap = 1 + ff / (MT * NK);
+            mt = ff % MT; j = (ff / MT) % NKD; tap = 1 + ff / (MT * NKD);
         }
         const int row = 16 * mt + i;
-        const int col = (forward || zterm) ? 4 * j + q : chan_d(MT, pack_last != 0, j, q);
+        const int col = zterm ? 4 * j + q : chan_d(MT, pack_last != 0, j, q);
         double v = 0.0;
         if (row < Cq && col < Cq) {
-            const int a = tap / KW, b = tap % KW;
-            const int widx = (KH - 1 - a) * KW + (KW - 1 - b);
-            if (forward) {
-                v = (double)wg[((size_t)row * Cq + col) * KK + widx];
-            } else if (zterm) {
+            if (zterm) {
                 v = Linv[row * Cq + col];
             } else {
+                const int a = tap / KW, b = tap % KW;
+                const int widx = (KH - 1 - a) * KW + (KW - 1 - b);
                 double s = 0.0;
                 for (int k = 0; k <= row; ++k) s += Linv[row * Cq + k] * (double)wg[((size_t)k * Cq + col) * KK + widx];
                 v = -s;
@@ -760,21 +647,20 @@ typedef void (*wave_fn)(const float *, const float *, float *, int, int, int, in
 
 struct Inst {
     int cqp, kh, kw;
-    bool fwd;
     wave_fn fn;      // 16-byte-group I/O (any W % 4 == 0)
     wave_fn fn_sec;  // 32-byte-piece I/O (W % 8 == 0)
     int nkz, nkd, nk, mt, nfrag, pack;
 };
 
-template <int CQP, int KH, int KW, bool FWD>
+template <int CQP, int KH, int KW>
 constexpr Inst make_inst()
 {
-    using C = Cfg<CQP, KH, KW, FWD>;
-    return Inst{CQP, KH, KW, FWD, finc_wave_kernel<CQP, KH, KW, FWD, false>, finc_wave_kernel<CQP, KH, KW, FWD, true>, C::NKZ, C::NKD, C::NK, C::MT, C::NFRAG,
+    using C = Cfg<CQP, KH, KW>;
+    return Inst{CQP, KH, KW, finc_wave_kernel<CQP, KH, KW, false>, finc_wave_kernel<CQP, KH, KW, true>, C::NKZ, C::NKD, C::NK, C::MT, C::NFRAG,
                 C::PACK ? 1 : 0};
 }
 
-#define FINC_BOTH(cqp, kh, kw) make_inst<cqp, kh, kw, false>(), make_inst<cqp, kh, kw, true>()
+#define FINC_BOTH(cqp, kh, kw) make_inst<cqp, kh, kw>()
 
 const Inst g_insts[] = {
     FINC_BOTH(4, 3, 3),  FINC_BOTH(8, 3, 3),  FINC_BOTH(12, 3, 3), FINC_BOTH(16, 3, 3),
@@ -784,11 +670,11 @@ const Inst g_insts[] = {
     FINC_BOTH(4, 3, 5),
 };
 
-const Inst *find_inst(int Cq, int KH, int KW, bool forward)
+const Inst *find_inst(int Cq, int KH, int KW)
 {
     const int cqp = (Cq + 3) / 4 * 4;
     for (const Inst &i : g_insts)
-        if (i.cqp == cqp && i.kh == KH && i.kw == KW && i.fwd == forward) return &i;
+        if (i.cqp == cqp && i.kh == KH && i.kw == KW) return &i;
     return nullptr;
 }
 
@@ -801,9 +687,9 @@ size_t lds_bytes(const Inst &i, int W, int P)
 
 } // namespace
 
-bool finc_mfma_supported(int Cq, int H, int W, int KH, int KW, bool forward)
+bool finc_mfma_supported(int Cq, int H, int W, int KH, int KW)
 {
-    const Inst *i = find_inst(Cq, KH, KW, forward);
+    const Inst *i = find_inst(Cq, KH, KW);
     if (!i) return false;
     if (W % 4 != 0 || W < 4 || H < 1) return false;
     const int P = W < 16 ? W : 16;
@@ -815,29 +701,24 @@ bool finc_mfma_supported(int Cq, int H, int W, int KH, int KW, bool forward)
 
 size_t finc_mfma_packed_bytes(int G, int Cq, int KH, int KW)
 {
-    const Inst *a = find_inst(Cq, KH, KW, false);
-    const Inst *b = find_inst(Cq, KH, KW, true);
-    size_t n = 0;
-    if (a) n = (size_t)a->nfrag;
-    if (b && (size_t)b->nfrag > n) n = (size_t)b->nfrag;
-    return n * 64 * sizeof(float) * (size_t)G;
+    const Inst *a = find_inst(Cq, KH, KW);
+    return a ? (size_t)a->nfrag * 64 * sizeof(float) * (size_t)G : 0;
 }
 
-int finc_mfma_pack(const float *wc, void *packed, int G, int Cq, int KH, int KW, bool forward, hipStream_t st)
+int finc_mfma_pack(const float *wc, void *packed, int G, int Cq, int KH, int KW, hipStream_t st)
 {
-    const Inst *i = find_inst(Cq, KH, KW, forward);
+    const Inst *i = find_inst(Cq, KH, KW);
     if (!i) return FINC_ERR_UNSUPPORTED;
-    size_t sm = forward ? 16 : sizeof(double) * Cq * Cq;
-    hipLaunchKernelGGL(pack_kernel, dim3(G), dim3(256), sm, st, wc, (float *)packed, Cq, KH, KW, i->mt, i->nkz,
-                       i->nkd, i->pack, forward ? 1 : 0, i->nfrag);
+    hipLaunchKernelGGL(pack_kernel, dim3(G), dim3(256), sizeof(double) * Cq * Cq, st, wc, (float *)packed, Cq, KH, KW,
+                       i->mt, i->nkz, i->nkd, i->pack, 0, i->nfrag);
     FINC_CHECK_LAUNCH();
     return FINC_OK;
 }
 
-int finc_mfma_launch(const float *in, const void *packed, float *out, const FincShape &s, bool forward, hipStream_t st)
+int finc_mfma_launch(const float *in, const void *packed, float *out, const FincShape &s, hipStream_t st)
 {
-    const Inst *i = find_inst(s.Cq, s.KH, s.KW, forward);
-    if (!i || !finc_mfma_supported(s.Cq, s.H, s.W, s.KH, s.KW, forward)) return FINC_ERR_UNSUPPORTED;
+    const Inst *i = find_inst(s.Cq, s.KH, s.KW);
+    if (!i || !finc_mfma_supported(s.Cq, s.H, s.W, s.KH, s.KW)) return FINC_ERR_UNSUPPORTED;
     if (((uintptr_t)in & 15u) || ((uintptr_t)out & 15u)) return FINC_ERR_ALIGNMENT;
     const int P = s.W < 16 ? s.W : 16;
     const int NB = (s.H + P - 1) / P;
@@ -854,8 +735,8 @@ int finc_mfma_launch(const float *in, const void *packed, float *out, const Finc
             if (n_attr < 128) attr_done[n_attr++] = (const void *)fn;
         }
     }
-    hipLaunchKernelGGL(fn, dim3(s.B * s.G), dim3(64), lds, st, in, (const float *)packed, out, s.G, s.Cq, s.H, s.W,
-                       P, Tend, s.orient);
+    hipLaunchKernelGGL(fn, dim3(s.B * s.G), dim3(64), lds, st, in, (const float *)packed, out, s.G, s.Cq, s.H, s.W, P,
+                       Tend, s.orient);
     FINC_CHECK_LAUNCH();
     return FINC_OK;
 }

@@ -103,7 +103,10 @@ class PaddedConv2d(FlowLayer):
             self.conv.weight.grad = self.conv.weight.grad * self.mask.to(self.conv.weight.grad.device)
 
     def forward(self, x, context=None, compute_expensive=None):
-        out = ops.conv_forward(x, self.conv.weight, 1, self._orient)
+        if torch.is_grad_enabled() and (x.requires_grad or self.conv.weight.requires_grad):
+            out = ops.conv_forward(x, self.conv.weight, 1, self._orient)
+        else:  # density evaluation / sampling checks: cached fragments, one launch
+            out = self._cache.forward(x.contiguous(), [self.conv.weight], 1, self._orient)
         return out, 0.0
 
     def reverse(self, x, context=None, compute_expensive=None):
@@ -136,8 +139,11 @@ class FastFlowUnit(nn.Module):
                 self.conv_br.conv.weight]
 
     def forward(self, x, context=None):
-        w = torch.cat(self._weights(), dim=0)
-        out = ops.conv_forward(x, w, 4, ops.ORIENT_FASTFLOW)
+        if torch.is_grad_enabled() and (x.requires_grad or any(w.requires_grad for w in self._weights())):
+            w = torch.cat(self._weights(), dim=0)
+            out = ops.conv_forward(x, w, 4, ops.ORIENT_FASTFLOW)
+        else:  # density evaluation / sampling checks: cached fragments, one launch
+            out = self._cache.forward(x.contiguous(), self._weights(), 4, ops.ORIENT_FASTFLOW)
         return out, 0.0
 
     def reverse(self, x, context=None):

@@ -117,11 +117,13 @@ def finc_backward(grad_z, x, w_canon, G, orient, need_gx=True, need_gw=True):
         if gw is not None:
             gw.zero_()
         return gx, gw
+    L = _lib.lib()
     with torch.cuda.device(grad_z.device):
-        st = _lib.lib().finc_backward_f32(grad_z.data_ptr(), x.data_ptr() if x is not None else None,
-                                          w_canon.data_ptr(), gx.data_ptr() if gx is not None else None,
-                                          gw.data_ptr() if gw is not None else None, B, G, Cq, H, W, KH, KW, orient,
-                                          _stream_ptr(grad_z))
+        ws = _workspace(grad_z.device, L.finc_workspace_bytes(G, Cq, KH, KW))
+        st = L.finc_backward_f32(grad_z.data_ptr(), x.data_ptr() if x is not None else None,
+                                 w_canon.data_ptr(), gx.data_ptr() if gx is not None else None,
+                                 gw.data_ptr() if gw is not None else None, B, G, Cq, H, W, KH, KW, orient,
+                                 ws.data_ptr(), ws.numel(), _stream_ptr(grad_z))
     _lib.check(st, "finc_backward_f32")
     return gx, gw
 
@@ -149,12 +151,14 @@ class PackedWeights:
         self.key = None
         self.w_canon = None
         self.packed_inv = None
+        self.packed_fwd = None
 
     def invalidate(self):
         """Force a rebuild on the next call.  Needed after writes that do not bump Tensor._version
         (torch.distributed collectives, writes through `.data`)."""
         self.key = None
         self.packed_inv = None
+        self.packed_fwd = None
 
     def get(self, weights, G, orient):
         key = tuple((w.data_ptr(), w._version) for w in weights) + (orient,)
@@ -163,8 +167,28 @@ class PackedWeights:
             self.w_canon = canonicalize(ws, G, orient)
             check_invariant(self.w_canon, G)
             self.packed_inv = None
+            self.packed_fwd = None
             self.key = key
         return self.w_canon
+
+    def forward(self, x, weights, G, orient, out=None):
+        """Inference-time forward (no autograd graph): cached canonical bank + cached strip-kernel fragments."""
+        w_canon = self.get(weights, G, orient)
+        _require_device(x, "input")
+        B, Cq, H, W, KH, KW = _dims(x, w_canon, G)
+        L = _lib.lib()
+        if x.numel() == 0 or L.finc_forward_algo_for(Cq, H, W, KH, KW) != _lib.ALGO["mfma"]:
+            return finc_forward(x, w_canon, G, orient, out=out)
+        with torch.cuda.device(x.device):
+            if self.packed_fwd is None:
+                self.packed_fwd = torch.empty(L.finc_workspace_bytes(G, Cq, KH, KW), dtype=torch.uint8, device=x.device)
+                _lib.check(L.finc_pack_forward_weights_f32(w_canon.data_ptr(), self.packed_fwd.data_ptr(), G, Cq, KH, KW,
+                                                           _stream_ptr(x)), "finc_pack_forward_weights_f32")
+            if out is None:
+                out = torch.empty_like(x)
+            _lib.check(L.finc_forward_packed_f32(x.data_ptr(), self.packed_fwd.data_ptr(), out.data_ptr(), B, G, Cq, H, W,
+                                                 KH, KW, orient, _stream_ptr(x)), "finc_forward_packed_f32")
+        return out
 
     def inverse(self, z, weights, G, orient, out=None):
         w_canon = self.get(weights, G, orient)

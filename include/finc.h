@@ -130,9 +130,11 @@ int finc_forward_packed_f32(const float *x, const void *packed, float *z, int B,
  *   grad_w_canon[o][i][kh][kw] = sum_{b,h,w} grad_z[b,o,h,w] * x[b,i,h-(KH-1-kh),w-(KW-1-kw)]
  * with the corner-tap mask applied in-kernel (masked entries are written as 0).
  * grad_w is OVERWRITTEN (not accumulated).  Either output may be NULL to skip it.
+ * `workspace` (finc_workspace_bytes()) lets grad_x run on the MFMA strip kernel; NULL selects the direct kernel.
  */
 int finc_backward_f32(const float *grad_z, const float *x, const float *w_canon, float *grad_x, float *grad_w_canon,
-                      int B, int G, int Cq, int H, int W, int KH, int KW, unsigned orient, finc_stream_t stream);
+                      int B, int G, int Cq, int H, int W, int KH, int KW, unsigned orient, void *workspace,
+                      size_t workspace_bytes, finc_stream_t stream);
 
 #ifdef __cplusplus
 }

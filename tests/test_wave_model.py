@@ -21,6 +21,3 @@ def test_wave_schedule(CQ, H, W, KH, KW):
     xi = wave_model.run(z[0].astype(np.float64), wc, fwd=False)
     assert not np.isnan(xi).any(), "a pixel was never stored"
     assert rel_err(xi, oracle.inverse_f64(z, wc, 1)[0]) < 1e-12
-    zf = wave_model.run(x[0].astype(np.float64), wc, fwd=True)
-    assert not np.isnan(zf).any()
-    assert rel_err(zf, z[0]) < 1e-6

@@ -266,7 +266,8 @@ def run(inp, wc, fwd=False):
     xs = (-4 - p) & 7
     nslot = ((-3 - p) % 12 + 12) % 12
     cn = -3 - p
-    if not fwd:
+    assert not fwd, 'the forward is finc_conv.hip (no skewed wavefront); only the inverse is modelled'
+    if True:
         acc = [np.zeros((LANES, 4)) for _ in range(MT)]
         for t in range(-4, Tend):
             wrapn = cn == 0
@@ -309,44 +310,5 @@ def run(inp, wc, fwd=False):
             nslot = np.where(nslot + 1 == 12, 0, nslot + 1)
             xs = (xs + 1) & 7
             fslot = 0 if fslot + 1 == D else fslot + 1
-        io_sread(); io_swrite()
-    else:
-        vn = np.zeros((NK, LANES))
-        acprev = [np.zeros((LANES, 4)) for _ in range(MT)]
-
-        def emit(ac, slot):
-            xpk = pack_d(ac, c)
-            for j in range(NKD):
-                xring[j, slot, lanes] = xpk[j]
-
-        for t in range(-4, Tend):
-            wrapn = cn == 0
-            ac = [np.zeros((LANES, 4)) for _ in range(MT)]
-            fvs = {}
-            for ci in range(KH * KW):
-                a, b = ci // KW, KW - 1 - ci % KW
-                for j in range(NK):
-                    for mt in range(MT):
-                        ac[mt] = mm((a, b), j, mt, R[a, b, j], ac[mt])
-                if b >= 1:
-                    R[a, b] = np.where(wrapn, 0.0, R[a, b - 1])
-                if ci == 0:
-                    emit(acprev, (xs + 7) & 7)
-                    vraw = np.stack([zring[j, nslot, lanes] for j in range(NK)])
-                if ci == (1 if KH * KW > 1 else 0):
-                    vn = np.where(cn >= 0, vraw, 0.0)
-                    if KH > 1:
-                        fifo_push(vn)
-                        fvs = {a2: fifo_pop(a2) for a2 in range(1, KH)}
-                if ci == (2 if KH * KW > 2 else KH * KW - 1):
-                    io_phase(t & 3)
-            R[0, 0] = vn
-            shift_all(fvs, vn, True)
-            acprev = ac
-            cn = np.where(cn + 1 == W, 0, cn + 1)
-            nslot = np.where(nslot + 1 == 12, 0, nslot + 1)
-            xs = (xs + 1) & 7
-            fslot = 0 if fslot + 1 == D else fslot + 1
-        emit(acprev, (xs + 7) & 7)
         io_sread(); io_swrite()
     return out
