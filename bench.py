@@ -44,7 +44,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS) + ["c4"])
     ap.add_argument("--cpu-sample", type=int, default=None, help="images in the CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     return ap.parse_args()
@@ -99,8 +99,64 @@ def load_traffic(workload):
     return None
 
 
+def bench_stack(args):
+    """--workload c4: BASELINE configs[3], sampling 128 images through the CIFAR Glow stack of
+    fastflow_cifar.py:35-63 (num_blocks=3, block_size=32, actnorm, split prior: 96 FastFlowUnits at 16x16 / 8x8 /
+    4x4 + ActNorm + 1x1 + coupling nets).  A step = model.sample(128), replayed from one HIP graph when capture
+    succeeds.  The reference's published whole-stack numbers (timing_comparision.py:10-14) are for a different stack
+    size and batch 100, so vs_baseline stays null."""
+    import numpy as np
+    import torch
+    from fincflow_amd import FastFlowUnit, glow
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    torch.manual_seed(0)
+    np.random.seed(0)
+    n = 128
+    model = glow.create_model(num_blocks=3, block_size=32, actnorm=True, split_prior=True).to(dev).eval()
+    with torch.no_grad():
+        for m in model:                                    # ActNorm is data-initialised by the first forward only
+            if isinstance(m, glow.ActNorm):
+                m.initialized.fill_(1)
+        for _ in range(3):
+            s = model.sample(n)
+        torch.cuda.synchronize()
+        graph, mode = None, "eager"
+        try:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                s = model.sample(n)
+            g.replay()
+            torch.cuda.synchronize()
+            graph, mode = g, "hip-graph"
+        except Exception as e:                             # capture is an optimisation, not a requirement
+            sys.stderr.write(f"graph capture failed, running eager: {e}\n")
+            torch.cuda.synchronize()
+        fn = (lambda: graph.replay()) if graph is not None else (lambda: model.sample(n))
+        for _ in range(args.warmup):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            fn()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+    units = sum(isinstance(m, FastFlowUnit) for m in model)
+    print(json.dumps({
+        "metric": "sampled images/sec, CIFAR Glow stack (fastflow_cifar.py create_model, 96 FastFlowUnits)",
+        "value": n * args.steps / dt, "unit": "images/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BASELINE configs[3]: model.sample(128), num_blocks=3, block_size=32, actnorm, split_prior; "
+                               f"{units} FastFlowUnits (HIP) + ActNorm/Conv1x1/Coupling (PyTorch-ROCm); random init",
+                   "mode": mode, "finite": bool(torch.isfinite(s).all())},
+        "roofline": None, "cpu_baseline": None}), flush=True)
+
+
 def main():
     args = parse()
+    if args.workload == "c4":
+        return bench_stack(args)
     import torch
     import torch.distributed as dist
     from fincflow_amd import FastFlowUnit
@@ -203,14 +259,14 @@ def main():
                         "logdet": 0.0, "launch_ms": fwd_launch_ms,
                         "frac_hbm_peak": alg_bytes / (fwd_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                         "frac_fp32_peak": alg_flops / (fwd_launch_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS},
-            "roofline": {"kernel": "finc_wave_kernel<24,3,3,inverse>", "bound": "hbm", "achieved": inv_gbs,
+            "roofline": {"kernel": f"finc_wave_kernel<{(Cq + 3) // 4 * 4},{K},{K},SEC> (inverse)", "bound": "hbm", "achieved": inv_gbs,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": inv_gbs / HBM_PEAK_GBS,
                          "traffic": (traffic or {}).get("inverse_hbm_bytes_per_launch"),
                          "traffic_source": (traffic or {}).get("source"),
                          "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": inv_launch_ms,
                          "frac_fp32_peak": alg_flops / (inv_launch_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS},
         }
-        if not args.no_cpu:
+        if not args.no_cpu and world == 1:          # the CPU baseline is an N=1 measurement (rank 0 only)
             sample = args.cpu_sample or (4 * (os.cpu_count() or 1) if args.workload == "c3" else B)
             line["cpu_baseline"] = cpu_baseline(min(sample, B), C, H, W, K, std)
         print(json.dumps(line), flush=True)
