@@ -164,12 +164,19 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    ndev = max(torch.cuda.device_count(), 1)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+        # one rank per GPU over RCCL ("nccl" IS RCCL on ROCm).  FINC_BENCH_BACKEND=gloo lets the N>1 code path be
+        # rehearsed with several ranks on ONE GPU (RCCL refuses two ranks per device); never used for numbers.
+        backend = os.environ.get("FINC_BENCH_BACKEND", "nccl")
+        torch.cuda.set_device(local_rank % ndev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank % ndev))
+        else:
+            dist.init_process_group(backend)
+    dev = torch.device("cuda", (local_rank % ndev) if world > 1 else 0)
     torch.cuda.set_device(dev)
 
     B, C, H, W, K, std = WORKLOADS[args.workload]
