@@ -142,6 +142,9 @@ struct BTaps {
 };
 
 #define FINC_SB() __builtin_amdgcn_sched_barrier(0)
+// Put at the top of a rarely taken, wave-uniform branch body: an opaque volatile asm cannot be speculated, so the
+// compiler keeps a real (scalar) branch instead of if-converting the body into per-step v_cndmask work.
+#define FINC_COLD() asm volatile("; cold path")
 // Timing-only ablation builds (scripts/ablate.sh): 1 = no HBM I/O, 2 = also no post-processing of the solved
 // pixel, 3 = also no operand ageing / z reads.  Results are wrong for any value but 0; never shipped.
 #ifndef FINC_ABLATE
@@ -218,7 +221,6 @@ __global__ __launch_bounds__(64) void finc_wave_kernel(const float *__restrict__
     int lph = fl4 & 1;                        // SEC: window parity; this lane loads when it is 0
     int scol = 4 * (fl4 - 2), srow = p;       // next group to store
     int lslot = SEC ? ((4 * (fl4 - 1)) % 12 + 12) % 12 : ((4 * fl4) % 12 + 12) % 12; // z-ring slot of the next landing
-    int sslot = (4 * (fl4 - 2)) & 7;          // x-ring slot (0,4) of the group to store
     int sph = fl4 & 1;                        // SEC: parity of the group read next (odd: the pair is complete)
     unsigned zoff[NKZ], coff[NKD];            // per-lane channel byte offsets inside the slab
 #pragma unroll
@@ -244,33 +246,40 @@ __global__ __launch_bounds__(64) void finc_wave_kernel(const float *__restrict__
     // A W-flipped group (TR/BR) is mirrored by choosing the ring SLOT of each element, never by moving data:
     // a select on a loaded value would drag the s_waitcnt for the whole HBM latency up to the issue point.
     const int k0 = fw ? 3 : 0, k1 = fw ? 2 : 1, k2 = fw ? 1 : 2, k3 = fw ? 0 : 3;
+    // x-ring read indices of the group to store: slot of element k = (4gs + k + p) & 7 = ((p+k)&7) ^ 4*(gs&1)
+    const int sidx[4] = {((p + k0) & 7) * 64 + lane, ((p + k1) & 7) * 64 + lane, ((p + k2) & 7) * 64 + lane,
+                         ((p + k3) & 7) * 64 + lane};
+    int stog = 256 * (fl4 & 1);               // 4 slots x 64 floats, toggled once per window (gs parity)
 
+    // Load offsets are kept incrementally: canonical column +8 (+4) is a constant byte step in memory, a row change
+    // another constant; the per-channel part j*4*HW*4 is uniform and rides in the buffer instruction's scalar offset.
+    const int lstep = (SEC ? 32 : 16) * (fw ? -1 : 1);                       // bytes per chunk along the row
+    const int lwrap = (fh ? -P : P) * W * 4 - (fw ? -1 : 1) * W * 4;         // extra bytes when the chunk wraps to row+P
+    int loff = ((fh ? H - 1 - lrow : lrow) * W + (fw ? W - (SEC ? 8 : 4) - lcol : lcol)) * 4 + q * HW * 4;
+    const unsigned zlast = (4 * (NKZ - 1) + q) < CQ ? 0u : OFF_BAD_CHANNEL;  // only the last k-step can hold a padded channel
     auto io_issue = [&]() {
         const bool ok = lcol >= 0 && lrow < H && p < P;
-        const int mrow = fh ? H - 1 - lrow : lrow;
+        const unsigned vb = ok ? (unsigned)loff : OFF_INVALID;
         if constexpr (SEC) {
-            // memory-ascending pieces m = 0,1 of the 32 bytes; piece m is canonical group (fw ? 1-m : m)
-            const int mcol = fw ? W - 8 - lcol : lcol;
-            const unsigned off = (unsigned)(mrow * W + mcol) * 4u;
             if (lph == 0) {                   // one parity class per window (divergent: other lanes keep their data)
 #pragma unroll
                 for (int j = 0; j < NKZ; ++j) {
-                    const unsigned vo = ok ? off + zoff[j] : OFF_INVALID;
-                    zb[j][0] = __builtin_amdgcn_raw_buffer_load_b128(rin, vo, 0, 0);
-                    zb[j][1] = __builtin_amdgcn_raw_buffer_load_b128(rin, vo + 16u, 0, 0);
+                    const unsigned vo = j == NKZ - 1 ? vb + zlast : vb;
+                    zb[j][0] = __builtin_amdgcn_raw_buffer_load_b128(rin, vo, j * 16 * HW, 0);
+                    zb[j][1] = __builtin_amdgcn_raw_buffer_load_b128(rin, vo + 16u, j * 16 * HW, 0);
                 }
                 lcol += 8;
-                if (lcol == W) { lcol = 0; lrow += P; }
+                loff += lstep;
+                if (lcol == W) { lcol = 0; lrow += P; loff += lwrap; }
             }
             lph ^= 1;
         } else {
-            const int mcol = fw ? W - 4 - lcol : lcol;
-            const unsigned off = (unsigned)(mrow * W + mcol) * 4u;
 #pragma unroll
             for (int j = 0; j < NKZ; ++j)
-                zb[j][0] = __builtin_amdgcn_raw_buffer_load_b128(rin, ok ? off + zoff[j] : OFF_INVALID, 0, 0);
+                zb[j][0] = __builtin_amdgcn_raw_buffer_load_b128(rin, j == NKZ - 1 ? vb + zlast : vb, j * 16 * HW, 0);
             lcol += 4;
-            if (lcol == W) { lcol = 0; lrow += P; }
+            loff += lstep;
+            if (lcol == W) { lcol = 0; lrow += P; loff += lwrap; }
         }
     };
     auto io_land = [&]() {
@@ -303,8 +312,9 @@ __global__ __launch_bounds__(64) void finc_wave_kernel(const float *__restrict__
         const int mcol = fw ? W - (SEC ? 8 : 4) - ccol : ccol;
         st_off = ok ? (unsigned)(mrow * W + mcol) * 4u : OFF_INVALID;
         st_fire = !SEC || sph != 0;
-        const float *b0 = xring + (sslot + k0) * 64 + lane, *b1 = xring + (sslot + k1) * 64 + lane;
-        const float *b2 = xring + (sslot + k2) * 64 + lane, *b3 = xring + (sslot + k3) * 64 + lane;
+        // the x ring is indexed by TIME (slot = step & 7): element k of this group was written at step 4gs+k+p
+        const float *b0 = xring + (sidx[0] ^ stog), *b1 = xring + (sidx[1] ^ stog);
+        const float *b2 = xring + (sidx[2] ^ stog), *b3 = xring + (sidx[3] ^ stog);
 #pragma unroll
         for (int j = 0; j < NKD; ++j) {
             sv[j][0] = b0[j * C::XSLOTS * 64];
@@ -313,7 +323,7 @@ __global__ __launch_bounds__(64) void finc_wave_kernel(const float *__restrict__
             sv[j][3] = b3[j * C::XSLOTS * 64];
         }
         sph ^= 1;
-        sslot ^= 4;
+        stog ^= 256;
         scol += 4;
         if (scol == W) { scol = 0; srow += P; }
     };
@@ -354,10 +364,20 @@ __global__ __launch_bounds__(64) void finc_wave_kernel(const float *__restrict__
     };
 
     // ---- neighbour operands --------------------------------------------------------------------
-    float R[KH][KW][NK];                      // R[a][b]: B operand of tap (a,b) for the current step
-    float DL[KH][KH][NK];                     // DL[a][k]: row_shr:a copies that are k+1 steps old
+    // S_a(tau) = row_shr:a of the pixels solved at step tau (S_0 = the pixels themselves).  Tap (a,b) of step t reads
+    // S_a(t-a-b).  ROT (every operand dies within 4 steps, i.e. KH-1+KW < 6): the S_a live in period-4 rings indexed
+    // by (step & 3), which is a compile-time constant in the x4-unrolled loop, so ageing an operand costs NO
+    // instruction.  Otherwise: explicit ageing arrays R (copy per step) and delay lines DL.
+    constexpr bool ROT = (KH - 1 + KW) < 6;
+    float Q[KH][4][NK];                       // ROT: Q[a][tau & 3] = S_a(tau)
+    float R[KH][KW][NK];                      // !ROT: R[a][b] = operand of tap (a,b) for the current step
+    float DL[KH][KH][NK];                     // !ROT: DL[a][k]: row_shr:a copies that are k+1 steps old
 #pragma unroll
     for (int a = 0; a < KH; ++a) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int j = 0; j < NK; ++j) Q[a][k][j] = 0.f;
 #pragma unroll
         for (int b = 0; b < KW; ++b)
 #pragma unroll
@@ -374,26 +394,53 @@ __global__ __launch_bounds__(64) void finc_wave_kernel(const float *__restrict__
         for (int j = 0; j < NK; ++j) fv[a][j] = 0.f;
 
     // FIFO: lanes P-(KH-1)..P-1 push their operand regs every step; lanes p < a pop lane P-a+p of D-1 steps ago.
+    // pointer = base + slot * stride with per-lane constants (stride 0 / base = trash word for lanes not taking
+    // part): one v_mad per pointer per step.
     const int push_l = p - (P - (KH - 1));
     const bool do_push = KH > 1 && push_l >= 0 && p < P;
-    const int push_base = q * (KH - 1) + push_l;
-    int fslot = 0;
-    auto fifo_push = [&](const float (&v)[NK]) {
-        const int ptr = do_push ? fslot * SS + push_base : trash;
+    const int push_base = do_push ? q * (KH - 1) + push_l : trash;
+    const int push_stride = do_push ? SS : 0;
+    int pop_base[KH], pop_stride[KH];
 #pragma unroll
-        for (int j = 0; j < NK; ++j) fifo[ptr + j * JS] = v[j];
+    for (int a = 1; a < KH; ++a) {
+        pop_base[a] = p < a ? q * (KH - 1) + (KH - 1 - a + p) : trash;
+        pop_stride[a] = p < a ? SS : 0;
+    }
+    int fslot = 0;
+    float *push_p = fifo + push_base;         // = fifo + push_base + fslot * push_stride, kept incrementally (bytes)
+    float *pop_p[KH];                         // = fifo + pop_base + ((fslot+1) % D) * pop_stride
+#pragma unroll
+    for (int a = 1; a < KH; ++a) pop_p[a] = fifo + pop_base[a] + (D > 1 ? pop_stride[a] : 0);
+    auto fifo_push = [&](const float (&v)[NK]) {
+#pragma unroll
+        for (int j = 0; j < NK; ++j) push_p[j * JS] = v[j];
     };
     auto fifo_pop_all = [&]() {
-        const int ps = fslot + 1 == D ? 0 : fslot + 1;
 #pragma unroll
         for (int a = 1; a < KH; ++a) {
-            const int ptr = p < a ? ps * SS + q * (KH - 1) + (KH - 1 - a + p) : trash;
 #pragma unroll
-            for (int j = 0; j < NK; ++j) fv[a][j] = fifo[ptr + j * JS];
+            for (int j = 0; j < NK; ++j) fv[a][j] = pop_p[a][j * JS];
         }
     };
-    // S_a = row_shr:a(src), lanes p < a take the FIFO value; R[a][0](t+1) = S_a(t+1-a): a-1 steps of delay line.
-    auto shift_all = [&](const float (&src)[NK]) {
+    auto fifo_advance = [&]() {               // one v_add per pointer; the rewinds are real scalar branches (1 in D steps)
+        ++fslot;
+        push_p += push_stride;
+#pragma unroll
+        for (int a = 1; a < KH; ++a) pop_p[a] += pop_stride[a];
+        if (fslot == D) {
+            FINC_COLD();
+            fslot = 0;
+            push_p = fifo + push_base;
+        }
+        if (fslot + 1 == D) {
+            FINC_COLD();
+#pragma unroll
+            for (int a = 1; a < KH; ++a) pop_p[a] = fifo + pop_base[a];
+        }
+    };
+    // S_a(t) for a >= 1: row_shr:a(src), lanes p < a take the FIFO value.
+    auto shift_all = [&](const float (&src)[NK], auto ph_c) {
+        constexpr int PHX = decltype(ph_c)::value;
         if constexpr (KH > 1) {
             float sn[KH][NK];
             ShiftOp<1>::apply(sn[1], fv[1], src);
@@ -402,16 +449,23 @@ __global__ __launch_bounds__(64) void finc_wave_kernel(const float *__restrict__
             if constexpr (KH > 4) ShiftOp<4>::apply(sn[4], fv[4], src);
             if constexpr (KH > 5) ShiftOp<5>::apply(sn[5], fv[5], src);
             if constexpr (KH > 6) ShiftOp<6>::apply(sn[6], fv[6], src);
+            if constexpr (ROT) {
 #pragma unroll
-            for (int j = 0; j < NK; ++j) R[1][0][j] = sn[1][j];
+                for (int a = 1; a < KH; ++a)
 #pragma unroll
-            for (int a = 2; a < KH; ++a) {
+                    for (int j = 0; j < NK; ++j) Q[a][PHX][j] = sn[a][j];
+            } else {                           // R[a][0](t+1) = S_a(t+1-a): a-1 steps of delay line
 #pragma unroll
-                for (int k = a - 2; k >= 1; --k)
+                for (int j = 0; j < NK; ++j) R[1][0][j] = sn[1][j];
 #pragma unroll
-                    for (int j = 0; j < NK; ++j) DL[a][k][j] = DL[a][k - 1][j];
+                for (int a = 2; a < KH; ++a) {
 #pragma unroll
-                for (int j = 0; j < NK; ++j) DL[a][0][j] = sn[a][j];
+                    for (int k = a - 2; k >= 1; --k)
+#pragma unroll
+                        for (int j = 0; j < NK; ++j) DL[a][k][j] = DL[a][k - 1][j];
+#pragma unroll
+                    for (int j = 0; j < NK; ++j) DL[a][0][j] = sn[a][j];
+                }
             }
         }
     };
@@ -430,9 +484,11 @@ __global__ __launch_bounds__(64) void finc_wave_kernel(const float *__restrict__
         io_issue();  // left in flight, lands in window -1
     }
 
-    int xs = (-4 - p) & 7;                    // x-ring slot of the position of step t (t starts at -4)
-    int nslot = ((-3 - p) % 12 + 12) % 12;    // z-ring slot of the position of step t+1
-    int cn = -3 - p;                          // column of the position of step t+1 (negative: lane not started)
+    int nslot = ((-3 - p) % 12 + 12) % 12;    // z-ring slot of the position of step t+1 ...
+    const float *zrd = zring + nslot * 64 + lane; // ... and its address
+    int tp1 = -3;                             // t+1 (scalar).  Lane p has started its chain iff p <= t+1 ...
+    int tm = -3;                              // ... and its NEXT position starts a row iff p == (t+1) mod W =: tm
+    int xwin = 256 + lane;                    // x-ring write index of this window: 256*((t>>2)&1) + lane, t = -4
 
     {
         // =========================== inverse ===========================
@@ -444,69 +500,94 @@ __global__ __launch_bounds__(64) void finc_wave_kernel(const float *__restrict__
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[mt] = (v4f){0.f, 0.f, 0.f, 0.f};
 
-        auto phase_a = [&](int j0, int j1) {
+        auto phase_a = [&](auto pha_c, int j0, int j1) {
+            constexpr int PHA = decltype(pha_c)::value;
 #pragma unroll
             for (int j = j0; j < j1; ++j)
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     if constexpr (KW > 1)
                         acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[FT + ((0 * KW + 1 - 1) * NK + j) * MT + mt],
-                                                                       R[0][1][j], acc[mt], 0, 0, 0);
+                                                                       ROT ? Q[0][(PHA + 3) & 3][j] : R[0][1][j], acc[mt],
+                                                                       0, 0, 0);
                     if constexpr (KH > 1)
                         acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[FT + ((1 * KW + 0 - 1) * NK + j) * MT + mt],
-                                                                       R[1][0][j], acc[mt], 0, 0, 0);
+                                                                       ROT ? Q[1][(PHA + 3) & 3][j] : R[1][0][j], acc[mt],
+                                                                       0, 0, 0);
                 }
         };
 
         auto step = [&](auto ph_c) {
-            const bool wrapn = cn == 0;                // the next position starts a row
-            const bool started = cn >= 0;
+            constexpr int PH = decltype(ph_c)::value;   // == t & 3
             // the masks cost VALU issue that f32 MFMAs do not hide: apply them only on the steps where a lane
-            // wraps (16 of every W steps) / has not started yet (the first 16 steps)
-            const bool any_wrap = __builtin_amdgcn_ballot_w64(wrapn) != 0;
-            const bool any_idle = __builtin_amdgcn_ballot_w64(!started) != 0;
+            // wraps (P of every W steps) / has not started yet (the first P steps); both tests are scalar
+            const bool any_wrap = tm >= 0 && tm < P;
+            const bool any_idle = tp1 < P - 1;
             float zraw[NKZ], zv[NKZ], xpk[NKD];
             v4f accn[MT];
 
             // ---- RA1: z of the next position is requested; operands that do not depend on this step age
 #pragma unroll
-            for (int j = 0; j < NKZ; ++j) zraw[j] = FINC_ABLATE >= 3 ? af[j] : zring[(j * C::ZSLOTS + nslot) * 64 + lane];
+            for (int j = 0; j < NKZ; ++j) zraw[j] = FINC_ABLATE >= 3 ? af[j] : zrd[j * C::ZSLOTS * 64];
+            if constexpr (!ROT) {
 #pragma unroll
-            for (int a = 0; a < KH; ++a) {
-                if constexpr (FINC_ABLATE >= 3) break;
+                for (int a = 0; a < KH; ++a) {
 #pragma unroll
-                for (int b = KW - 1; b >= 1; --b) {
-                    if (a + b >= 2) {
-#pragma unroll
-                        for (int j = 0; j < NK; ++j) R[a][b][j] = R[a][b - 1][j];
-                    }
-                }
-                if (a >= 2) {
-#pragma unroll
-                    for (int j = 0; j < NK; ++j) R[a][0][j] = DL[a][a - 2][j];
-                }
-            }
-            if (any_wrap) {
-#pragma unroll
-                for (int a = 0; a < KH; ++a)
-#pragma unroll
-                    for (int b = 1; b < KW; ++b) {
+                    for (int b = KW - 1; b >= 1; --b) {
                         if (a + b >= 2) {
 #pragma unroll
-                            for (int j = 0; j < NK; ++j) R[a][b][j] = wrapn ? 0.f : R[a][b][j];
+                            for (int j = 0; j < NK; ++j) R[a][b][j] = R[a][b - 1][j];
                         }
                     }
+                    if (a >= 2) {
+#pragma unroll
+                        for (int j = 0; j < NK; ++j) R[a][0][j] = DL[a][a - 2][j];
+                    }
+                }
+                if (any_wrap) {
+                    FINC_COLD();
+                    const bool wrapn = p == tm;
+#pragma unroll
+                    for (int a = 0; a < KH; ++a)
+#pragma unroll
+                        for (int b = 1; b < KW; ++b) {
+                            if (a + b >= 2) {
+#pragma unroll
+                                for (int j = 0; j < NK; ++j) R[a][b][j] = wrapn ? 0.f : R[a][b][j];
+                            }
+                        }
+                }
             }
-            phase_a(0, NK / 2);
+            phase_a(ph_c, 0, NK / 2);
             FINC_SB();
             // ---- RA2
 #pragma unroll
             for (int j = 0; j < NKZ; ++j) zv[j] = zraw[j];
             if (any_idle) {
+                FINC_COLD();
+                const bool started = p <= tp1;
 #pragma unroll
                 for (int j = 0; j < NKZ; ++j) zv[j] = started ? zv[j] : 0.f;
             }
-            phase_a(NK / 2, NK);
+            phase_a(ph_c, NK / 2, NK);
+            if constexpr (ROT) {
+                // the operands phase A just read unmasked (b = 0 / 1 of this step) become b >= 1 taps of a step that
+                // starts a row: zero them, for the wrapping lanes only, after phase A has issued and before phase B
+                if (any_wrap) {
+                    FINC_COLD();
+                    const bool wrapn = p == tm;
+#pragma unroll
+                    for (int a = 0; a < KH; ++a)
+#pragma unroll
+                        for (int b = 1; b < KW; ++b) {
+                            if (a + b >= 2) {
+#pragma unroll
+                                for (int j = 0; j < NK; ++j)
+                                    Q[a][(PH + 9 - a - b) & 3][j] = wrapn ? 0.f : Q[a][(PH + 9 - a - b) & 3][j];
+                            }
+                        }
+                }
+            }
             FINC_SB();
             // ---- RB0: z-term of the next step
 #pragma unroll
@@ -527,21 +608,24 @@ __global__ __launch_bounds__(64) void finc_wave_kernel(const float *__restrict__
                 }
                 pack_d<C>(acc, xpk);
 #pragma unroll
-                for (int j = 0; j < NKD; ++j) xring[(j * C::XSLOTS + xs) * 64 + lane] = xpk[j];
+                for (int j = 0; j < NKD; ++j) xring[j * C::XSLOTS * 64 + PH * 64 + xwin] = xpk[j]; // slot = t & 7
                 if constexpr (KH > 1) {
                     fifo_push(xpk);
                     fifo_pop_all();
                 }
-                if constexpr (KW > 1) {
-#pragma unroll
-                    for (int j = 0; j < NK; ++j) R[0][1][j] = xpk[j];
+                if constexpr (KW > 1) {                // S_0(t): tap (0,1) of the next step
                     if (any_wrap) {
+                        FINC_COLD();
+                        const bool wrapn = p == tm;
 #pragma unroll
-                        for (int j = 0; j < NK; ++j) R[0][1][j] = wrapn ? 0.f : R[0][1][j];
+                        for (int j = 0; j < NK; ++j) (ROT ? Q[0][PH][j] : R[0][1][j]) = wrapn ? 0.f : xpk[j];
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < NK; ++j) (ROT ? Q[0][PH][j] : R[0][1][j]) = xpk[j];
                     }
                 }
             };
-            auto post2 = [&]() { if constexpr (FINC_ABLATE < 2) shift_all(xpk); };
+            auto post2 = [&]() { if constexpr (FINC_ABLATE < 2) shift_all(xpk, ph_c); };
 
             // ---- RB1..: one region per remaining tap, side work attached to the first three
             auto chunk = [&](auto ci_c) {
@@ -552,7 +636,8 @@ __global__ __launch_bounds__(64) void finc_wave_kernel(const float *__restrict__
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
                         accn[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[FT + ((a * KW + b - 1) * NK + j) * MT + mt],
-                                                                        R[a][b][j], accn[mt], 0, 0, 0);
+                                                                        ROT ? Q[a][(PH + 9 - a - b) & 3][j] : R[a][b][j],
+                                                                        accn[mt], 0, 0, 0);
                 if constexpr (CI == 0) post1();
                 if constexpr (CI == (NCH > 1 ? 1 : 0)) io_phase(ph_c);
                 if constexpr (CI == (NCH > 2 ? 2 : NCH - 1)) post2();
@@ -570,10 +655,12 @@ __global__ __launch_bounds__(64) void finc_wave_kernel(const float *__restrict__
             // ---- advance
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) acc[mt] = accn[mt];
-            ++cn; if (cn == W) cn = 0;
-            ++nslot; if (nslot == 12) nslot = 0;
-            xs = (xs + 1) & 7;
-            ++fslot; if (fslot == D) fslot = 0;
+            ++tp1;
+            ++tm; if (tm == W) tm = 0;
+            ++nslot; zrd += 64;
+            if (nslot == 12) { nslot = 0; zrd -= 12 * 64; }
+            if constexpr (PH == 3) xwin ^= 256;
+            fifo_advance();
         };
 
         for (int t0 = -4; t0 < Tend; t0 += 4) {

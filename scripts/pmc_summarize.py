@@ -5,9 +5,12 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursive=True):
     for row in csv.DictReader(open(f)):
         k = row["Kernel_Name"]
-        if "finc_wave_kernel" not in k:
+        if "finc_wave_kernel" in k:
+            k = "inverse"
+        elif "finc_conv_kernel" in k:
+            k = "forward"
+        else:
             continue
-        k = "inverse" if "3, false" in k or "5, false" in k or "2, false" in k else "forward"
         acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
 out = {k: {c: sum(v) / len(v) for c, v in d.items()} for k, d in acc.items()}
 out["n_dispatches"] = {k: {c: len(v) for c, v in d.items()} for k, d in acc.items()}
