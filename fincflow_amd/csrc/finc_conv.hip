@@ -45,13 +45,23 @@ __device__ inline float row_shl(float src)
                                                                  true));
 }
 
-template <int CQP, int KH, int KW>
-__global__ __launch_bounds__(64) void finc_conv_kernel(const float *__restrict__ in, const float *__restrict__ packed,
-                                                       float *__restrict__ out, int G, int CQ, int H, int W, int NS,
-                                                       unsigned orient)
+// NW > 1 ("K-split"): the workgroup has NW waves; wave w owns the input-channel k-steps [w*JL, (w+1)*JL) of every
+// tap -- 1/NW of the fragments and of the input rows -- and the partial output tiles are summed through LDS once per
+// row.  That is how a filter bank that does not fit one wave's registers (Cq=48, 5x5: 900 fragments) still runs with
+// every fragment register-resident.
+template <int CQP, int KH, int KW, int NW>
+__global__ __launch_bounds__(64 * NW) void finc_conv_kernel(const float *__restrict__ in,
+                                                            const float *__restrict__ packed, float *__restrict__ out,
+                                                            int G, int CQ, int H, int W, int NS, unsigned orient)
 {
-    constexpr int MT = (CQP + 15) / 16, NKZ = CQP / 4, NTAP = KH * KW, NFRAG = NTAP * NKZ * MT;
-    const int lane = threadIdx.x;
+    constexpr int MT = (CQP + 15) / 16, NKZT = CQP / 4, NTAP = KH * KW;
+    static_assert(NKZT % NW == 0 && (MT * 4) % NW == 0, "K-split must divide the k-steps and the output registers");
+    constexpr int NKZ = NKZT / NW;                        // k-steps this wave owns
+    constexpr int NFRAG = NTAP * NKZ * MT;                // fragments this wave holds
+    constexpr int DREG = MT * 4 / NW;                     // output registers this wave finalises and stores
+    __shared__ float xch[NW > 1 ? 2 * NW * NW * DREG * 64 : 1]; // [parity][dst wave][src wave][reg][lane]
+    const int wv = NW > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
+    const int lane = threadIdx.x & 63;
     const int q = lane >> 4, p = lane & 15;
     const int strip = blockIdx.x % NS;
     const int bg = blockIdx.x / NS;
@@ -67,9 +77,13 @@ __global__ __launch_bounds__(64) void finc_conv_kernel(const float *__restrict__
 
     float af[NFRAG];
     {
-        const float *pk = packed + (size_t)g * NFRAG * 64 + lane;
+        // global fragment index ((tap*NKZT + j)*MT + mt); this wave's j = wv*NKZ + jl
+        const float *pk = packed + (size_t)g * (NTAP * NKZT * MT) * 64 + lane;
 #pragma unroll
-        for (int f = 0; f < NFRAG; ++f) af[f] = pk[f * 64];
+        for (int f = 0; f < NFRAG; ++f) {
+            const int mt = f % MT, jl = (f / MT) % NKZ, tap = f / (MT * NKZ);
+            af[f] = pk[((tap * NKZT + wv * NKZ + jl) * MT + mt) * 64];
+        }
 #pragma unroll
         for (int f = 0; f < NFRAG; ++f) asm volatile("" : "+a"(af[f])); // MFMA A operands: keep them out of the VGPRs
     }
@@ -86,8 +100,9 @@ __global__ __launch_bounds__(64) void finc_conv_kernel(const float *__restrict__
     unsigned lin[NKZ], lhal[NKZ], lout[MT][4];
 #pragma unroll
     for (int j = 0; j < NKZ; ++j) {
-        const bool chok = (4 * j + q) < CQ;
-        const unsigned ch = (unsigned)(4 * j + q) * HW * 4u;
+        const int cin = 4 * (wv * NKZ + j) + q;               // input channel of k-slot q of this wave's k-step j
+        const bool chok = cin < CQ;
+        const unsigned ch = (unsigned)cin * HW * 4u;
         lin[j] = (colok && chok) ? coloff + ch : OFF_BAD_CHANNEL;
         lhal[j] = (hok && chok) ? hcoloff + ch : OFF_BAD_CHANNEL;
     }
@@ -128,15 +143,46 @@ __global__ __launch_bounds__(64) void finc_conv_kernel(const float *__restrict__
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[s][mt] = (v4f){0.f, 0.f, 0.f, 0.f};
 
+    int parity = 0;
     auto store_row = [&](const v4f (&ac)[MT], int h) {   // h = the row those accumulators belong to
         const unsigned ro = rowoff(h);
+        float vv[MT * 4];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const float v0 = ac[mt].x, v1 = ac[mt].y, v2 = ac[mt].z, v3 = ac[mt].w;
-            const float vv[4] = {v0, v1, v2, v3};
+            vv[4 * mt + 0] = v0; vv[4 * mt + 1] = v1; vv[4 * mt + 2] = v2; vv[4 * mt + 3] = v3;
+        }
+        if constexpr (NW == 1) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r)
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vv[r]), rout, ro + lout[mt][r], 0, 0);
+            for (int d = 0; d < MT * 4; ++d)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vv[d]), rout, ro + lout[d / 4][d % 4], 0,
+                                                      0);
+        } else {
+            // exchange: register d of the output belongs to wave d / DREG; everybody ships the registers it does not
+            // own, one barrier, the owner adds the NW-1 partials it received and stores (double-buffered by parity)
+            float *xb = xch + parity * (NW * NW * DREG * 64);
+#pragma unroll
+            for (int d = 0; d < MT * 4; ++d) {
+                const int dst = d / DREG;
+                if (dst != wv) xb[((dst * NW + wv) * DREG + d % DREG) * 64 + lane] = vv[d];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int dl = 0; dl < DREG; ++dl) {
+                float sum = 0.f;
+#pragma unroll
+                for (int d = 0; d < MT * 4; ++d)
+                    if (d / DREG == wv && d % DREG == dl) sum = vv[d];       // own partial (wv is wave-uniform)
+#pragma unroll
+                for (int src = 0; src < NW; ++src)
+                    if (src != wv) sum += xb[((wv * NW + src) * DREG + dl) * 64 + lane];
+                unsigned off = OFF_BAD_CHANNEL;
+#pragma unroll
+                for (int d = 0; d < MT * 4; ++d)
+                    if (d / DREG == wv && d % DREG == dl) off = lout[d / 4][d % 4];
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, sum), rout, ro + off, 0, 0);
+            }
+            parity ^= 1;
         }
     };
 
@@ -214,17 +260,17 @@ typedef void (*conv_fn)(const float *, const float *, float *, int, int, int, in
 struct ConvInst {
     int cqp, kh, kw;
     conv_fn fn;
-    int mt, nkz, nfrag;
+    int mt, nkz, nfrag, nw;
 };
-template <int CQP, int KH, int KW>
+template <int CQP, int KH, int KW, int NW = 1>
 constexpr ConvInst make_conv()
 {
-    return ConvInst{CQP, KH, KW, finc_conv_kernel<CQP, KH, KW>, (CQP + 15) / 16, CQP / 4,
-                    KH * KW * (CQP / 4) * ((CQP + 15) / 16)};
+    return ConvInst{CQP, KH, KW, finc_conv_kernel<CQP, KH, KW, NW>, (CQP + 15) / 16, CQP / 4,
+                    KH * KW * (CQP / 4) * ((CQP + 15) / 16), NW};
 }
 const ConvInst g_conv[] = {
     make_conv<4, 3, 3>(),  make_conv<8, 3, 3>(),  make_conv<12, 3, 3>(), make_conv<16, 3, 3>(), make_conv<24, 3, 3>(),
-    make_conv<32, 3, 3>(), make_conv<48, 3, 3>(), make_conv<4, 2, 2>(),  make_conv<16, 2, 2>(), make_conv<4, 5, 5>(),
+    make_conv<32, 3, 3>(), make_conv<48, 3, 3, 2>(), make_conv<48, 5, 5, 4>(), make_conv<4, 2, 2>(),  make_conv<16, 2, 2>(), make_conv<4, 5, 5>(),
     make_conv<16, 5, 5>(), make_conv<4, 3, 5>(),  make_conv<4, 1, 3>(),  make_conv<4, 3, 1>(),
 };
 const ConvInst *find_conv(int Cq, int KH, int KW)
@@ -268,7 +314,7 @@ int finc_conv_launch(const float *in, const void *packed, float *out, const Finc
     const ConvInst *i = find_conv(s.Cq, s.KH, s.KW);
     if (!i || !finc_conv_supported(s.Cq, s.H, s.W, s.KH, s.KW)) return FINC_ERR_UNSUPPORTED;
     const int NS = (s.W + 15) / 16;
-    hipLaunchKernelGGL(i->fn, dim3(s.B * s.G * NS), dim3(64), 0, st, in, (const float *)packed, out, s.G, s.Cq, s.H,
+    hipLaunchKernelGGL(i->fn, dim3(s.B * s.G * NS), dim3(64 * i->nw), 0, st, in, (const float *)packed, out, s.G, s.Cq, s.H,
                        s.W, NS, s.orient);
     FINC_CHECK_LAUNCH();
     return FINC_OK;

@@ -44,20 +44,28 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 typedef unsigned v2u __attribute__((ext_vector_type(2)));
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
 
-template <int CQP_, int KH_, int KW_>
+template <int CQP_, int KH_, int KW_, int NW_ = 1>
 struct Cfg {
-    static constexpr int CQP = CQP_, KH = KH_, KW = KW_;
+    static constexpr int CQP = CQP_, KH = KH_, KW = KW_, NW = NW_;
     static constexpr int MT = (CQP + 15) / 16;            // 16-row output-channel tiles
-    static constexpr int NKZ = CQP / 4;                   // k-steps of a streamed operand (k-slot q <-> channel 4j+q)
+    static constexpr int NKZT = CQP / 4;                  // k-steps of a streamed operand (k-slot q <-> channel 4j+q)
     static constexpr int LASTV = (CQP - 16 * (MT - 1)) / 4; // k-slots of the last D tile that hold real channels
     static constexpr bool PACK = LASTV <= 2;              // fold the last tile's 4 half-empty regs into 2
-    static constexpr int NKD = PACK ? 4 * (MT - 1) + 2 : 4 * MT; // regs of a D-layout result as operand / for store
-    static constexpr int NK = NKD;                        // k-steps per neighbour tap
+    static constexpr int NKDT = PACK ? 4 * (MT - 1) + 2 : 4 * MT; // regs of a D-layout result as operand / for store
+    // NW > 1 ("K-split"): wave w of the workgroup owns k-steps [w*NKZ, (w+1)*NKZ) of the z-term and
+    // [w*NKD, (w+1)*NKD) of every tap, i.e. 1/NW of the fragments; the output registers it finalises after the
+    // per-step exchange are exactly the D registers that are its own operands.
+    static_assert(NW == 1 || (!PACK && NKZT % NW == 0 && NKDT % NW == 0), "K-split needs full tiles and divisibility");
+    static constexpr int NKZ = NKZT / NW;                 // per wave
+    static constexpr int NKD = NKDT / NW;
+    static constexpr int NK = NKD;                        // k-steps per neighbour tap (per wave)
     static constexpr int NTAP = KH * KW;
-    static constexpr int NFRAG = (NKZ + (NTAP - 1) * NKD) * MT;
+    static constexpr int NFRAG = (NKZ + (NTAP - 1) * NKD) * MT;   // fragments a wave holds
+    static constexpr int NFRAGT = (NKZT + (NTAP - 1) * NKDT) * MT; // fragments packed per group
     static constexpr int ZSLOTS = 12, XSLOTS = 8;
     static constexpr int ZRING = NKZ * ZSLOTS * 64;       // floats
     static constexpr int XRING = NKD * XSLOTS * 64;
+    static constexpr int XCH = NW > 1 ? NW * NW * NKD * 64 : 0;   // exchange buffer [dst][src][reg][lane]
 };
 
 // channel held by k-slot q of k-step j of a D-layout-derived operand
@@ -90,7 +98,7 @@ struct ShiftOp {
 
 // D-layout accumulators -> operand/store registers (identity or pair-packing of the last tile)
 template <class C>
-__device__ inline void pack_d(const v4f (&acc)[C::MT], float (&xpk)[C::NKD])
+__device__ inline void pack_d(const v4f (&acc)[C::MT], float (&xpk)[C::NKDT])
 {
     constexpr int full = C::PACK ? C::MT - 1 : C::MT;
 #pragma unroll
@@ -165,21 +173,19 @@ constexpr unsigned OFF_BAD_CHANNEL = 0x40000000u; // added to a valid offset it 
 // issues in the shadow of the 32-cycle MFMAs.  The loop is unrolled x4 so the 4-step I/O cadence
 // (read x ring / store / land z / issue loads) falls on fixed steps.
 // -----------------------------------------------------------------------------------------------
-template <int CQP, int KH, int KW, bool SEC>
-__global__ __launch_bounds__(64) void finc_wave_kernel(const float *__restrict__ in, const float *__restrict__ packed,
-                                                       float *__restrict__ out, int G, int CQ, int H, int W, int P,
-                                                       int Tend, unsigned orient)
+template <int CQP, int KH, int KW, bool SEC, int NW = 1>
+__global__ __launch_bounds__(64 * NW) void finc_wave_kernel(const float *__restrict__ in,
+                                                            const float *__restrict__ packed, float *__restrict__ out,
+                                                            int G, int CQ, int H, int W, int P, int Tend,
+                                                            unsigned orient)
 {
-    using C = Cfg<CQP, KH, KW>;
+    using C = Cfg<CQP, KH, KW, NW>;
     constexpr int MT = C::MT, NKZ = C::NKZ, NKD = C::NKD, NK = C::NK, NFRAG = C::NFRAG;
     constexpr int JS = 4 * (KH - 1);          // FIFO: floats per k-step (4 k-slots x (KH-1) source lanes)
     constexpr int SS = NK * JS;               // FIFO: floats per step slot
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float *zring = lds;
-    float *xring = lds + C::ZRING;
-    float *fifo = xring + C::XRING;
-
-    const int lane = threadIdx.x;
+    const int wv = NW > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;  // wave of the workgroup (K-split)
+    const int lane = threadIdx.x & 63;
     const int q = lane >> 4, p = lane & 15;
     const int bg = blockIdx.x;
     const int g = bg % G;
@@ -193,14 +199,30 @@ __global__ __launch_bounds__(64) void finc_wave_kernel(const float *__restrict__
         __builtin_amdgcn_make_buffer_rsrc((void *)(out + (size_t)bg * CQ * HW), 0, (int)slab_bytes, 0x00020000);
     const int D = W - P + 1;                  // FIFO depth (steps between a band's last rows and the next band's first)
     const int fifo_n = D * SS;
+    // LDS: [exchange buffer (K-split only)] then per wave: z ring | x ring | FIFO + trash
+    const int wave_lds = C::ZRING + C::XRING + fifo_n + SS + 64;
+    float *xch = lds;
+    float *zring = lds + C::XCH + wv * wave_lds;
+    float *xring = zring + C::ZRING;
+    float *fifo = xring + C::XRING;
     const int trash = fifo_n + lane;          // per-lane scratch word(s): lanes that neither push nor pop point here
 
     // ---- filter fragments -> registers -------------------------------------------------------
     float af[NFRAG];
     {
-        const float *pk = packed + (size_t)g * NFRAG * 64 + lane;
+        // packed index: z-term (j*MT + mt), then taps ((tap-1)*NKDT + j)*MT + mt, j global; this wave's j = wv*N + jl
+        const float *pk = packed + (size_t)g * C::NFRAGT * 64 + lane;
 #pragma unroll
-        for (int f = 0; f < NFRAG; ++f) af[f] = pk[f * 64];
+        for (int f = 0; f < NFRAG; ++f) {
+            int gi;
+            if (f < NKZ * MT) {
+                gi = (wv * NKZ + f / MT) * MT + f % MT;
+            } else {
+                const int ff = f - NKZ * MT;
+                gi = C::NKZT * MT + ((ff / (MT * NKD)) * C::NKDT + wv * NKD + (ff / MT) % NKD) * MT + ff % MT;
+            }
+            af[f] = pk[gi * 64];
+        }
         // The fragments are only ever MFMA A operands, which may be AGPRs; everything the VALU touches must be a
         // VGPR and there are only 256 of each.  Pin the fragments to AGPRs so the allocator does not shuffle
         // operands between the two files (v_accvgpr_* moves are VALU issue that f32 MFMAs do not hide).
@@ -227,7 +249,7 @@ __global__ __launch_bounds__(64) void finc_wave_kernel(const float *__restrict__
     for (int j = 0; j < NKZ; ++j) zoff[j] = (4 * j + q) < CQ ? (unsigned)(4 * j + q) * HW * 4u : OFF_BAD_CHANNEL;
 #pragma unroll
     for (int j = 0; j < NKD; ++j) {
-        const int c = chan_d(MT, C::PACK, j, q);
+        const int c = chan_d(MT, C::PACK, wv * NKD + j, q);
         coff[j] = c < CQ ? (unsigned)c * HW * 4u : OFF_BAD_CHANNEL;
     }
     v4u zb[NKZ][NPC];                         // in flight HBM -> z ring (raw: nothing may touch it until it lands)
@@ -255,8 +277,8 @@ __global__ __launch_bounds__(64) void finc_wave_kernel(const float *__restrict__
     // another constant; the per-channel part j*4*HW*4 is uniform and rides in the buffer instruction's scalar offset.
     const int lstep = (SEC ? 32 : 16) * (fw ? -1 : 1);                       // bytes per chunk along the row
     const int lwrap = (fh ? -P : P) * W * 4 - (fw ? -1 : 1) * W * 4;         // extra bytes when the chunk wraps to row+P
-    int loff = ((fh ? H - 1 - lrow : lrow) * W + (fw ? W - (SEC ? 8 : 4) - lcol : lcol)) * 4 + q * HW * 4;
-    const unsigned zlast = (4 * (NKZ - 1) + q) < CQ ? 0u : OFF_BAD_CHANNEL;  // only the last k-step can hold a padded channel
+    int loff = ((fh ? H - 1 - lrow : lrow) * W + (fw ? W - (SEC ? 8 : 4) - lcol : lcol)) * 4 + (4 * wv * NKZ + q) * HW * 4;
+    const unsigned zlast = (4 * (wv * NKZ + NKZ - 1) + q) < CQ ? 0u : OFF_BAD_CHANNEL;  // only the last k-step can hold a padded channel
     auto io_issue = [&]() {
         const bool ok = lcol >= 0 && lrow < H && p < P;
         const unsigned vb = ok ? (unsigned)loff : OFF_INVALID;
@@ -524,6 +546,7 @@ __global__ __launch_bounds__(64) void finc_wave_kernel(const float *__restrict__
             const bool any_wrap = tm >= 0 && tm < P;
             const bool any_idle = tp1 < P - 1;
             float zraw[NKZ], zv[NKZ], xpk[NKD];
+            float xown[NKD];                          // K-split: this wave's own share of the registers it finalises
             v4f accn[MT];
 
             // ---- RA1: z of the next position is requested; operands that do not depend on this step age
@@ -597,16 +620,45 @@ __global__ __launch_bounds__(64) void finc_wave_kernel(const float *__restrict__
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
                     accn[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[FZ + j * MT + mt], zv[j], accn[mt], 0, 0, 0);
+            if constexpr (NW > 1) {
+                // K-split exchange: acc holds this wave's share of ALL output registers.  Ship the registers other waves
+                // own, keep ours; after the barrier post1 adds the NW-1 shares it received.
+                float vv[MT * 4];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const float v0 = acc[mt].x, v1 = acc[mt].y, v2 = acc[mt].z, v3 = acc[mt].w;
+                    vv[4 * mt + 0] = v0; vv[4 * mt + 1] = v1; vv[4 * mt + 2] = v2; vv[4 * mt + 3] = v3;
+                }
+#pragma unroll
+                for (int d = 0; d < MT * 4; ++d) {
+                    const int dst = d / NKD;
+                    if (dst != wv) xch[((dst * NW + wv) * NKD + d % NKD) * 64 + lane] = vv[d];
+                    else xown[d % NKD] = vv[d];
+                }
+                FINC_SB();
+                __syncthreads();
+            }
             FINC_SB();
 
             auto post1 = [&]() {                       // the pixel solved this step leaves the accumulators
-                if constexpr (FINC_ABLATE >= 2) {          // keep every accumulator alive, do nothing else
+                if constexpr (FINC_ABLATE >= 2 && NW == 1) { // keep every accumulator alive, do nothing else
                     pack_d<C>(acc, xpk);
 #pragma unroll
                     for (int j = 0; j < NKD; ++j) asm volatile("" ::"v"(xpk[j]));
                     return;
                 }
-                pack_d<C>(acc, xpk);
+                if constexpr (NW == 1) {
+                    pack_d<C>(acc, xpk);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NKD; ++j) {
+                        float sum = xown[j];
+#pragma unroll
+                        for (int src = 0; src < NW; ++src)
+                            if (src != wv) sum += xch[((wv * NW + src) * NKD + j) * 64 + lane];
+                        xpk[j] = sum;
+                    }
+                }
 #pragma unroll
                 for (int j = 0; j < NKD; ++j) xring[j * C::XSLOTS * 64 + PH * 64 + xwin] = xpk[j]; // slot = t & 7
                 if constexpr (KH > 1) {
@@ -655,6 +707,7 @@ __global__ __launch_bounds__(64) void finc_wave_kernel(const float *__restrict__
             // ---- advance
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) acc[mt] = accn[mt];
+            if constexpr (NW > 1) __syncthreads();     // every wave has read its shares: the buffer may be rewritten
             ++tp1;
             ++tm; if (tm == W) tm = 0;
             ++nslot; zrd += 64;
@@ -736,15 +789,16 @@ struct Inst {
     int cqp, kh, kw;
     wave_fn fn;      // 16-byte-group I/O (any W % 4 == 0)
     wave_fn fn_sec;  // 32-byte-piece I/O (W % 8 == 0)
-    int nkz, nkd, nk, mt, nfrag, pack;
+    int nkz, nkd, nk, mt, nfrag, pack; // nkz/nkd/nfrag: per GROUP (packing); nk: per wave
+    int nw, wnkz, wnkd;                // K-split: waves per workgroup, per-wave k-steps
 };
 
-template <int CQP, int KH, int KW>
+template <int CQP, int KH, int KW, int NW = 1>
 constexpr Inst make_inst()
 {
-    using C = Cfg<CQP, KH, KW>;
-    return Inst{CQP, KH, KW, finc_wave_kernel<CQP, KH, KW, false>, finc_wave_kernel<CQP, KH, KW, true>, C::NKZ, C::NKD, C::NK, C::MT, C::NFRAG,
-                C::PACK ? 1 : 0};
+    using C = Cfg<CQP, KH, KW, NW>;
+    return Inst{CQP, KH, KW, finc_wave_kernel<CQP, KH, KW, false, NW>, finc_wave_kernel<CQP, KH, KW, true, NW>, C::NKZT, C::NKDT,
+                C::NK, C::MT, C::NFRAGT, C::PACK ? 1 : 0, NW, C::NKZ, C::NKD};
 }
 
 #define FINC_BOTH(cqp, kh, kw) make_inst<cqp, kh, kw>()
@@ -755,6 +809,7 @@ const Inst g_insts[] = {
     FINC_BOTH(4, 2, 2),  FINC_BOTH(16, 2, 2),
     FINC_BOTH(4, 5, 5),  FINC_BOTH(16, 5, 5),
     FINC_BOTH(4, 3, 5),
+    make_inst<48, 3, 3, 2>(), make_inst<48, 5, 5, 4>(), make_inst<32, 5, 5, 4>(),
 };
 
 const Inst *find_inst(int Cq, int KH, int KW)
@@ -769,7 +824,9 @@ size_t lds_bytes(const Inst &i, int W, int P)
 {
     const size_t D = (size_t)(W - P + 1);
     const size_t ss = (size_t)i.nk * 4 * (i.kh - 1);
-    return sizeof(float) * ((size_t)i.nkz * 12 * 64 + (size_t)i.nkd * 8 * 64 + D * ss + ss + 64);
+    const size_t per_wave = (size_t)i.wnkz * 12 * 64 + (size_t)i.wnkd * 8 * 64 + D * ss + ss + 64;
+    const size_t xch = i.nw > 1 ? (size_t)i.nw * i.nw * i.wnkd * 64 : 0;
+    return sizeof(float) * (xch + (size_t)i.nw * per_wave);
 }
 
 } // namespace
@@ -822,7 +879,7 @@ int finc_mfma_launch(const float *in, const void *packed, float *out, const Finc
             if (n_attr < 128) attr_done[n_attr++] = (const void *)fn;
         }
     }
-    hipLaunchKernelGGL(fn, dim3(s.B * s.G), dim3(64), lds, st, in, (const float *)packed, out, s.G, s.Cq, s.H, s.W, P,
+    hipLaunchKernelGGL(fn, dim3(s.B * s.G), dim3(64 * i->nw), lds, st, in, (const float *)packed, out, s.G, s.Cq, s.H, s.W, P,
                        Tend, s.orient);
     FINC_CHECK_LAUNCH();
     return FINC_OK;

@@ -44,8 +44,11 @@ def test_algo_selection_is_host_side_and_consistent():
     assert L.finc_inverse_algo_for(12, 32, 32, 3, 3) == MFMA
     assert L.finc_inverse_algo_for(24, 64, 64, 3, 3) == MFMA
     assert L.finc_forward_algo_for(24, 64, 64, 3, 3) == MFMA
-    # c5 (Cq=48, 5x5): fragments do not fit the register file of one wave -> reference-order kernel
-    assert L.finc_inverse_algo_for(48, 128, 128, 5, 5) == STRICT
+    # c5 (Cq=48, 5x5): 900 fragments do not fit one wave -> K-split over the 4 waves of a workgroup, still MFMA
+    assert L.finc_inverse_algo_for(48, 128, 128, 5, 5) == MFMA
+    assert L.finc_forward_algo_for(48, 128, 128, 5, 5) == MFMA
+    # no instantiation at all (Cq=64, 7x7) -> reference-order kernel
+    assert L.finc_inverse_algo_for(64, 32, 32, 7, 7) == STRICT
     # W not a multiple of 4 -> reference-order kernel
     assert L.finc_inverse_algo_for(24, 64, 63, 3, 3) == STRICT
     assert L.finc_workspace_bytes(4, 24, 3, 3) >= 4 * 108 * 64 * 4
@@ -64,7 +67,7 @@ def test_argument_validation_without_touching_the_gpu():
     # MFMA algo without a workspace
     assert L.finc_inverse_f32(one, one, ctypes.c_void_p(32), 1, 4, 24, 64, 64, 3, 3, 0xE4, 2, None, 0, None) == 4
     # MFMA algo on a shape it has no instantiation for
-    assert L.finc_inverse_f32(one, one, ctypes.c_void_p(32), 1, 4, 48, 128, 128, 5, 5, 0xE4, 2, one, 1 << 30, None) == 3
+    assert L.finc_inverse_f32(one, one, ctypes.c_void_p(32), 1, 4, 64, 32, 32, 7, 7, 0xE4, 2, one, 1 << 30, None) == 3
 
 
 def test_check_raises_python_exceptions():

@@ -268,6 +268,30 @@ def test_ragged_and_degenerate_shapes(shape, dev):
         assert rel_err(ops.finc_forward(t(z, dev), wc, algo=algo).cpu().numpy(), oracle.forward_f32(z, wco)) <= TOL
 
 
+@pytest.mark.parametrize("shape", [(2, 192, 20, 24, 3), (1, 192, 9, 40, 5), (2, 192, 32, 32, 5)])
+def test_ksplit_forward_and_grad_input(shape, dev):
+    """Cq=48: the filter bank does not fit one wave, the strip kernel splits K over 2 (3x3) / 4 (5x5) waves and
+    reduces through LDS.  Forward and grad-input against the oracle / its transpose identity."""
+    from fincflow_amd import _lib, ops
+    B, C, H, W, K = shape
+    assert _lib.lib().finc_forward_algo_for(C // 4, H, W, K, K) == 2
+    rng = np.random.default_rng(sum(shape))
+    ws = oracle.make_stored_weights(4, C // 4, K, K, std=0.02, seed=sum(shape))
+    wco = oracle.canonicalize(ws, 4, ORIENT_FASTFLOW)
+    wc = canon(ws, 4, ORIENT_FASTFLOW, dev)
+    x = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    z = ops.finc_forward(t(x, dev), wc)
+    assert rel_err(z.cpu().numpy(), oracle.forward_f32(x, wco, nthreads=8)) <= TOL
+    assert torch.equal(z, ops.finc_forward(t(x, dev), wc, algo="mfma"))
+    # <grad_x, dx> == <gz, forward(dx)>: the adjoint identity pins grad-input without a second reference
+    gz = torch.randn_like(z)
+    gx, _ = ops.finc_backward(gz, None, wc, 4, ORIENT_FASTFLOW, need_gx=True, need_gw=False)
+    dx = torch.randn_like(z)
+    lhs = float((gx.double() * dx.double()).sum())
+    rhs = float((gz.double() * ops.finc_forward(dx, wc).double()).sum())
+    assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), abs(rhs), 1.0)
+
+
 def test_empty_batch(dev):
     from fincflow_amd import ops
     wc = canon(oracle.make_stored_weights(4, 2, 3, 3), 4, ORIENT_FASTFLOW, dev)
@@ -290,7 +314,9 @@ def test_full_size_properties(cfg, dev):
     x = torch.randn(B, C, H, W, device=dev)
     z = ops.finc_forward(x, wc)
     xr = ops.finc_inverse(z, wc)
-    assert rel_err(xr.cpu().numpy(), x.cpu().numpy()) <= TOL                      # (a)
+    assert rel_err(xr.cpu().numpy(), x.cpu().numpy()) <= TOL
+    xs = ops.finc_inverse(z, wc, algo="strict")
+    assert rel_err(xr.cpu().numpy(), xs.cpu().numpy()) <= TOL                      # (a)
     zs = torch.randn(B, C, H, W, device=dev)
     xs = ops.finc_inverse(zs, wc)
     assert rel_err(ops.finc_forward(xs, wc).cpu().numpy(), zs.cpu().numpy()) <= TOL  # (b)
@@ -306,11 +332,28 @@ def test_full_size_properties(cfg, dev):
     assert rel_err(z[pick].cpu().numpy(), refz) <= TOL
 
 
-def test_c5_shape_one_image_strict_fallback(dev):
-    """configs[4] (5x5, C=192, 128x128): no MFMA instantiation yet -> reference-order kernel.  One image,
-    checked against the oracle on a crop-independent property (round trip) and directly on one group."""
+@pytest.mark.parametrize("shape", [(2, 192, 20, 24, 3), (1, 192, 37, 16, 5), (2, 192, 16, 32, 5), (1, 128, 19, 40, 5)])
+def test_ksplit_inverse(shape, dev):
+    """Cq=48 / 32 with 3x3 / 5x5: the inverse splits K over 2 / 4 waves of a workgroup (own rings, FIFO and fragment
+    slice per wave; partial tiles exchanged through LDS every step).  Against the oracle's fp64 path."""
     from fincflow_amd import _lib, ops
-    assert _lib.lib().finc_inverse_algo_for(48, 128, 128, 5, 5) == 1
+    B, C, H, W, K = shape
+    assert _lib.lib().finc_inverse_algo_for(C // 4, H, W, K, K) == 2
+    rng = np.random.default_rng(sum(shape))
+    ws = oracle.make_stored_weights(4, C // 4, K, K, std=0.02, seed=sum(shape))
+    wco = oracle.canonicalize(ws, 4, ORIENT_FASTFLOW)
+    wc = canon(ws, 4, ORIENT_FASTFLOW, dev)
+    z = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    x = ops.finc_inverse(t(z, dev), wc)
+    assert rel_err(x.cpu().numpy(), oracle.inverse_via_f64(z, wco, nthreads=8)) <= TOL
+    assert rel_err(ops.finc_forward(x, wc).cpu().numpy(), z) <= TOL
+
+
+def test_c5_shape_one_image(dev):
+    """configs[4] (5x5, C=192, 128x128), one image per call: K-split MFMA kernels in both directions, round trip and
+    agreement with the reference-order kernel."""
+    from fincflow_amd import _lib, ops
+    assert _lib.lib().finc_inverse_algo_for(48, 128, 128, 5, 5) == 2
     # std 0.02, not 0.05: at 5x5 / Cq=48 the init std of layers/conv.py:64 makes the inverse itself unstable
     # (|inverse(N(0,1))| reaches 3e7 by 48x48 in fp64); 0.02 gives the same operator norm as 3x3 / Cq=24.
     ws = oracle.make_stored_weights(4, 48, 5, 5, std=0.02)
@@ -320,3 +363,5 @@ def test_c5_shape_one_image_strict_fallback(dev):
     z = ops.finc_forward(x, wc)
     xr = ops.finc_inverse(z, wc)
     assert rel_err(xr.cpu().numpy(), x.cpu().numpy()) <= TOL
+    xs = ops.finc_inverse(z, wc, algo="strict")
+    assert rel_err(xr.cpu().numpy(), xs.cpu().numpy()) <= TOL
