@@ -716,7 +716,36 @@ __global__ __launch_bounds__(64 * NW) void finc_wave_kernel(const float *__restr
             fifo_advance();
         };
 
-        for (int t0 = -4; t0 < Tend; t0 += 4) {
+        // Window -4 (steps -4..-1) solves nothing: every lane is still before its first pixel.  Only its HBM side
+        // and the z-term of lane 0's first pixel (phase B of step -1) matter, so it runs without the other 3.9 steps.
+        io_sread();
+        io_swrite();
+        io_land();
+        io_issue();
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {                  // steps -4, -3, -2: bookkeeping only (the FIFO ring is zero)
+            ++tp1; ++tm;
+            ++nslot; zrd += 64;
+            if (nslot == 12) { nslot = 0; zrd -= 12 * 64; }
+            fifo_advance();
+        }
+        {                                              // step -1: acc = Linv * z of the position lanes with p == 0 start at
+            const bool started = p <= tp1;             // tp1 == 0 here
+#pragma unroll
+            for (int j = 0; j < NKZ; ++j) {
+                const float v = zrd[j * C::ZSLOTS * 64];
+                const float zvj = started ? v : 0.f;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[FZ + j * MT + mt], zvj, acc[mt], 0, 0, 0);
+            }
+            ++tp1; ++tm;
+            ++nslot; zrd += 64;
+            if (nslot == 12) { nslot = 0; zrd -= 12 * 64; }
+            xwin ^= 256;
+            fifo_advance();
+        }
+        for (int t0 = 0; t0 < Tend; t0 += 4) {
             step(IC<0>{});
             step(IC<1>{});
             step(IC<2>{});
