@@ -226,6 +226,16 @@ int finc_forward_packed_f32(const float *x, const void *packed, float *z, int B,
     return run_packed(x, packed, z, B, G, Cq, H, W, KH, KW, orient, stream, true);
 }
 
+static size_t align256(size_t n) { return (n + 255) & ~(size_t)255; }
+
+size_t finc_backward_workspace_bytes(int B, int G, int Cq, int H, int W, int KH, int KW)
+{
+    if (B <= 0 || G <= 0 || Cq <= 0 || H <= 0 || W <= 0 || KH <= 0 || KW <= 0) return 256;
+    FincShape s{B, G, Cq, H, W, KH, KW, 0};
+    const size_t n = align256(finc_conv_packed_bytes(G, Cq, KH, KW)) + finc_gradw_workspace_bytes(s);
+    return n < 256 ? 256 : n;
+}
+
 int finc_backward_f32(const float *grad_z, const float *x, const float *w_canon, float *grad_x, float *grad_w_canon,
                       int B, int G, int Cq, int H, int W, int KH, int KW, unsigned orient, void *workspace,
                       size_t workspace_bytes, finc_stream_t stream)
@@ -237,14 +247,20 @@ int finc_backward_f32(const float *grad_z, const float *x, const float *w_canon,
     if (grad_x == grad_z) return FINC_ERR_BAD_DIMS;
     FincShape s{B, G, Cq, H, W, KH, KW, orient};
     hipStream_t st = (hipStream_t)stream;
+    const size_t pk = align256(finc_conv_packed_bytes(G, Cq, KH, KW));
     // grad_x: the same conv on the H- and W-flipped image with in/out channels transposed (finc_conv.hip)
-    if (grad_x && workspace && finc_conv_supported(Cq, H, W, KH, KW) &&
-        workspace_bytes >= finc_conv_packed_bytes(G, Cq, KH, KW)) {
+    if (grad_x && workspace && finc_conv_supported(Cq, H, W, KH, KW) && pk > 0 && workspace_bytes >= pk) {
         if (int e = finc_conv_pack(w_canon, workspace, G, Cq, KH, KW, true, st)) return e;
         FincShape sb = s;
         sb.orient = orient ^ ((G >= 16) ? 0xFFFFFFFFu : ((1u << (2 * G)) - 1u));
         if (int e = finc_conv_launch(grad_z, workspace, grad_x, sb, st)) return e;
         grad_x = nullptr;
+    }
+    // grad_w: MFMA strip kernel with the pixels on K + reduce (+ corner-tap mask)
+    const size_t gwb = finc_gradw_workspace_bytes(s);
+    if (grad_w_canon && workspace && gwb > 0 && workspace_bytes >= pk + gwb) {
+        if (int e = finc_gradw_launch(grad_z, x, grad_w_canon, (char *)workspace + pk, s, st)) return e;
+        grad_w_canon = nullptr;
     }
     if (!grad_x && !grad_w_canon) return FINC_OK;
     return finc_launch_backward_generic(grad_z, x, w_canon, grad_x, grad_w_canon, s, st);

@@ -119,7 +119,7 @@ def finc_backward(grad_z, x, w_canon, G, orient, need_gx=True, need_gw=True):
         return gx, gw
     L = _lib.lib()
     with torch.cuda.device(grad_z.device):
-        ws = _workspace(grad_z.device, L.finc_workspace_bytes(G, Cq, KH, KW))
+        ws = _workspace(grad_z.device, L.finc_backward_workspace_bytes(B, G, Cq, H, W, KH, KW))
         st = L.finc_backward_f32(grad_z.data_ptr(), x.data_ptr() if x is not None else None,
                                  w_canon.data_ptr(), gx.data_ptr() if gx is not None else None,
                                  gw.data_ptr() if gw is not None else None, B, G, Cq, H, W, KH, KW, orient,

@@ -130,8 +130,11 @@ int finc_forward_packed_f32(const float *x, const void *packed, float *z, int B,
  *   grad_w_canon[o][i][kh][kw] = sum_{b,h,w} grad_z[b,o,h,w] * x[b,i,h-(KH-1-kh),w-(KW-1-kw)]
  * with the corner-tap mask applied in-kernel (masked entries are written as 0).
  * grad_w is OVERWRITTEN (not accumulated).  Either output may be NULL to skip it.
- * `workspace` (finc_workspace_bytes()) lets grad_x run on the MFMA strip kernel; NULL selects the direct kernel.
+ * `workspace` of finc_backward_workspace_bytes() bytes lets both gradients run on the MFMA strip kernels (grad_x: the
+ * forward kernel on the flipped image with transposed fragments; grad_w: pixels on the MFMA K dimension, partial
+ * tiles in the workspace, then a reduce).  NULL or a smaller buffer selects the direct kernels.
  */
+size_t finc_backward_workspace_bytes(int B, int G, int Cq, int H, int W, int KH, int KW);
 int finc_backward_f32(const float *grad_z, const float *x, const float *w_canon, float *grad_x, float *grad_w_canon,
                       int B, int G, int Cq, int H, int W, int KH, int KW, unsigned orient, void *workspace,
                       size_t workspace_bytes, finc_stream_t stream);

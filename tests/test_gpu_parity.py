@@ -292,6 +292,37 @@ def test_ksplit_forward_and_grad_input(shape, dev):
     assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), abs(rhs), 1.0)
 
 
+@pytest.mark.parametrize("shape", [(3, 96, 20, 40, 3), (2, 64, 9, 17, 5), (2, 16, 12, 12, 2), (64, 96, 64, 64, 3)])
+def test_grad_weight_mfma(shape, dev):
+    """grad_w on the MFMA strip kernel (pixels on K) + reduce + corner-tap mask.  Pinned by linearity in the weights:
+    <grad_w, dW> == <gz, forward(x; dW)> for any bank dW whose masked entries are zero, and against the direct
+    kernel (no workspace) on the small shapes."""
+    from fincflow_amd import _lib, ops
+    B, C, H, W, K = shape
+    L = _lib.lib()
+    Cq = C // 4
+    assert L.finc_backward_workspace_bytes(B, 4, Cq, H, W, K, K) > L.finc_workspace_bytes(4, Cq, K, K)  # MFMA grad_w exists
+    torch.manual_seed(sum(shape))
+    wc = canon(oracle.make_stored_weights(4, Cq, K, K), 4, ORIENT_FASTFLOW, dev)
+    x = torch.randn(B, C, H, W, device=dev)
+    gz = torch.randn(B, C, H, W, device=dev)
+    _, gw = ops.finc_backward(gz, x, wc, 4, ORIENT_FASTFLOW, need_gx=False, need_gw=True)
+    mask = torch.ones_like(wc)
+    for c in range(Cq):
+        mask.view(4, Cq, Cq, K, K)[:, c, c:, -1, -1] = 0
+    assert torch.all(gw[mask == 0] == 0)
+    dW = torch.randn_like(wc) * mask
+    lhs = float((gw.double() * dW.double()).sum())
+    rhs = float((gz.double() * ops.finc_forward(x, dW.contiguous()).double()).sum())
+    assert abs(lhs - rhs) <= 2e-5 * max(abs(lhs), abs(rhs), 1.0)
+    if B * C * H * W <= 1 << 20:
+        gw_direct = torch.empty_like(wc)
+        st = L.finc_backward_f32(gz.data_ptr(), x.data_ptr(), wc.data_ptr(), None, gw_direct.data_ptr(), B, 4, Cq, H, W, K, K,
+                                 ORIENT_FASTFLOW, None, 0, torch.cuda.current_stream().cuda_stream)
+        assert st == 0
+        assert rel_err(gw.cpu().numpy(), gw_direct.cpu().numpy()) <= 1e-4
+
+
 def test_empty_batch(dev):
     from fincflow_amd import ops
     wc = canon(oracle.make_stored_weights(4, 2, 3, 3), 4, ORIENT_FASTFLOW, dev)
