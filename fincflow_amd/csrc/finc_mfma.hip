@@ -244,9 +244,7 @@ __global__ __launch_bounds__(64 * NW) void finc_wave_kernel(const float *__restr
     int scol = 4 * (fl4 - 2), srow = p;       // next group to store
     int lslot = SEC ? ((4 * (fl4 - 1)) % 12 + 12) % 12 : ((4 * fl4) % 12 + 12) % 12; // z-ring slot of the next landing
     int sph = fl4 & 1;                        // SEC: parity of the group read next (odd: the pair is complete)
-    unsigned zoff[NKZ], coff[NKD];            // per-lane channel byte offsets inside the slab
-#pragma unroll
-    for (int j = 0; j < NKZ; ++j) zoff[j] = (4 * j + q) < CQ ? (unsigned)(4 * j + q) * HW * 4u : OFF_BAD_CHANNEL;
+    unsigned coff[NKD];                       // per-lane channel byte offsets of the registers this wave stores
 #pragma unroll
     for (int j = 0; j < NKD; ++j) {
         const int c = chan_d(MT, C::PACK, wv * NKD + j, q);
