@@ -108,6 +108,7 @@ def bench_stack(args):
     4x4 + ActNorm + 1x1 + coupling nets).  A step = model.sample(128), replayed from one HIP graph when capture
     succeeds.  The reference's published whole-stack numbers (timing_comparision.py:10-14) are for a different stack
     size and batch 100, so vs_baseline stays null."""
+    os.environ.setdefault("MIOPEN_FIND_MODE", "2")   # coupling-net convs: heuristics, not an exhaustive find per shape
     import numpy as np
     import torch
     from fincflow_amd import FastFlowUnit, glow

@@ -6,8 +6,9 @@ the arithmetic is hand-written CDNA4 HIP behind the C ABI in include/finc.h
 library is missing or a tensor is not on a ROCm device.
 """
 from . import ops  # noqa: F401
-from .layers import FastFlowUnit, FlowLayer, FlowSequential, PaddedConv2d  # noqa: F401
+from .layers import (CINCFlowUnit, FastFlowUnit, FlowLayer, FlowSequential, PaddedConv2d,  # noqa: F401
+                     load_reference_checkpoint)
 from .ops import finc_forward, finc_inverse, inverse  # noqa: F401
 
-__all__ = ["FastFlowUnit", "PaddedConv2d", "FlowLayer", "FlowSequential", "finc_forward", "finc_inverse", "inverse",
+__all__ = ["FastFlowUnit", "CINCFlowUnit", "load_reference_checkpoint", "PaddedConv2d", "FlowLayer", "FlowSequential", "finc_forward", "finc_inverse", "inverse",
            "ops"]

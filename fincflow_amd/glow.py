@@ -151,7 +151,7 @@ class GaussianPrior(nn.Module):
         super().__init__()
         self.size = tuple(size)
         self.dim = int(np.prod(size))
-        self.register_buffer('_anchor', torch.zeros(1))
+        self.register_buffer('_anchor', torch.zeros(1), persistent=False)  # not in reference checkpoints
 
     def log_prob(self, input, context=None, sum=True):
         z = input.reshape(-1, self.dim)

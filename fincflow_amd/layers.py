@@ -162,13 +162,68 @@ class FastFlowUnit(nn.Module):
         return torch.cat(outs, dim=1)
 
 
+class CINCFlowUnit(nn.Module):
+    """The groups=1 (CInC) unit of cinc_flow.py:9-80: ONE top-left PaddedConv2d over all channels
+    (`out_channels` is overridden with `in_channels`, cinc_flow.py:17), state-dict key `conv_tl.conv.weight`."""
+
+    def __init__(self, in_channels, out_channels, kernel_size):
+        super().__init__()
+        if isinstance(kernel_size, int) or len(kernel_size) == 1:
+            kernel_size = (kernel_size, kernel_size) if isinstance(kernel_size, int) else (kernel_size[0],) * 2
+        out_channels = in_channels
+        self.conv_tl = PaddedConv2d(out_channels, out_channels, kernel_size, order='TL')
+
+    def forward(self, x, context=None):
+        out, logdet = self.conv_tl.forward(x)
+        return out, 0.0 + logdet
+
+    def reverse(self, x, context=None):
+        return self.reverse_level1(x)
+
+    def reverse_level1(self, x):
+        return self.conv_tl.reverse(x)[0]
+
+
+def load_reference_checkpoint(model, checkpoint, strict=True, validate=True):
+    """Load a reference training checkpoint (train/experiment.py:400-427: a dict holding 'model_state_dict',
+    written by `torch.save`) or a bare state-dict into `model`.
+
+    The reference stores every PaddedConv2d weight flipped per its `order` (layers/conv.py:72-79) under
+    `<prefix>.conv_{tl,tr,bl,br}.conv.weight`; the modules here keep the same storage and the same keys, so
+    this is `load_state_dict` plus what a checkpoint written by `nn.DataParallel` needs (the 'module.' prefix,
+    fastflow_cifar_multi_gpu.py wraps the model) and what trained weights need: every packed-fragment cache is
+    dropped and, with `validate`, each layer's unit-triangular corner tap is checked once on the device
+    (a violated invariant raises RuntimeError instead of silently solving a different system).
+    Returns the (missing_keys, unexpected_keys) of `load_state_dict`.
+    """
+    if isinstance(checkpoint, (str, bytes)) or hasattr(checkpoint, "__fspath__"):
+        checkpoint = torch.load(checkpoint, map_location="cpu", weights_only=False)
+    state = checkpoint.get("model_state_dict", checkpoint) if isinstance(checkpoint, dict) else checkpoint
+    if state and all(k.startswith("module.") for k in state):
+        state = {k[len("module."):]: v for k, v in state.items()}
+    result = model.load_state_dict(state, strict=strict)
+    for m in model.modules():
+        cache = getattr(m, "_cache", None)
+        if isinstance(cache, ops.PackedWeights):
+            cache.invalidate()
+        if validate and isinstance(m, PaddedConv2d):
+            w = m.conv.weight.detach()
+            if w.is_cuda:
+                ops.check_invariant(ops.canonicalize(w.contiguous(), 1, m._orient), 1)
+            else:  # host-side check of the same rule, for a model validated before .cuda()
+                corner = m._flip(w)[:, :, -1, -1]
+                if not torch.equal(torch.triu(corner), torch.eye(corner.shape[0], dtype=corner.dtype)):
+                    raise RuntimeError("checkpoint violates the unit-triangular corner tap (layers/conv.py:63-70)")
+    return result
+
+
 class StandardNormal(nn.Module):
     """Base density with the runner's interface (train/losses.py:17-45): log_prob(z) -> [B], sample(n)."""
 
     def __init__(self, size):
         super().__init__()
         self.size = tuple(size)
-        self.register_buffer("_anchor", torch.zeros(1))
+        self.register_buffer("_anchor", torch.zeros(1), persistent=False)  # not in reference checkpoints
 
     def log_prob(self, z, context=None):
         return -0.5 * (z ** 2 + torch.log(torch.tensor(2 * torch.pi, device=z.device))).flatten(1).sum(1)

@@ -396,3 +396,46 @@ def test_c5_shape_one_image(dev):
     assert rel_err(xr.cpu().numpy(), x.cpu().numpy()) <= TOL
     xs = ops.finc_inverse(z, wc, algo="strict")
     assert rel_err(xr.cpu().numpy(), xs.cpu().numpy()) <= TOL
+
+
+@pytest.mark.parametrize("C,k", [(8, 3), (6, 3), (16, 2), (24, 3)])
+def test_cincflowunit_groups1(C, k, dev):
+    """the groups=1 unit (cinc_flow.py:9-80) -- one TL conv over all channels -- against the oracle:
+    forward, inverse (cached packed path) and strict-order bit-exactness through the G=1 ABI call."""
+    from fincflow_amd import CINCFlowUnit, ops
+    torch.manual_seed(7)
+    u = CINCFlowUnit(C, C, k).to(dev)
+    ws = u.conv_tl.conv.weight.detach().cpu().numpy()
+    wc = oracle.canonicalize(ws, 1, 0)
+    x = np.random.default_rng(3).standard_normal((3, C, 11, 13)).astype(np.float32)
+    z, ld = u(t(x, dev))                             # autograd path (weights require grad)
+    assert ld == 0.0
+    z_ref = oracle.forward_f32(x, wc, 1, 0)
+    assert rel_err(z.detach().cpu().numpy(), z_ref) <= TOL
+    with torch.no_grad():                            # cached packed path
+        assert rel_err(u(t(x, dev))[0].cpu().numpy(), z_ref) <= TOL
+    xr = u.reverse(t(z_ref, dev))
+    assert rel_err(xr.cpu().numpy(), oracle.inverse_via_f64(z_ref, wc, 1, 0)) <= TOL
+    strict = ops.finc_inverse(t(z_ref, dev), canon(ws, 1, 0, dev), 1, 0, algo="strict").cpu().numpy()
+    assert np.array_equal(strict, oracle.inverse_f32(z_ref, wc, 1, 0))
+
+
+def test_load_reference_checkpoint_on_device(dev, tmp_path):
+    """a reference-format checkpoint (train/experiment.py:400-427) drives the unit; the packed
+    caches are rebuilt and the loaded weights reproduce the reference's recorded outputs."""
+    from fincflow_amd import FastFlowUnit, FlowSequential, load_reference_checkpoint
+    from fincflow_amd.layers import StandardNormal
+    g = golden("unit_B2_C48_32x32_k3")
+    model = FlowSequential(StandardNormal((48, 32, 32)), FastFlowUnit(48, 48, 3)).to(dev)
+    z0 = model.sequence_modules[0].reverse(t(g["z"], dev))        # fills the cache with the random init
+    sd = {f"module.0.conv_{o}.conv.weight": torch.from_numpy(g[f"w_{o}"]) for o in ("tl", "tr", "bl", "br")}
+    path = tmp_path / "ckpt.tar"
+    torch.save({"summary": {}, "model_state_dict": sd, "config": {}}, path)
+    load_reference_checkpoint(model, path)
+    unit = model.sequence_modules[0]
+    assert rel_err(unit.reverse(t(g["z"], dev)).cpu().numpy(), g["x_rev_cython"]) <= TOL
+    assert rel_err(unit(t(g["x"], dev))[0].detach().cpu().numpy(), g["z"]) <= TOL
+    bad = {k: v.clone() for k, v in sd.items()}
+    bad["module.0.conv_bl.conv.weight"][1, 1, 0, -1] = 0.5        # BL stores the corner tap at [.., 0, -1]
+    with pytest.raises(RuntimeError):
+        load_reference_checkpoint(model, bad)

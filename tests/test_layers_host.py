@@ -64,3 +64,38 @@ def test_no_cpu_fallback():
 def test_flowsequential_protocol_shape():
     seq = FlowSequential(StandardNormal((4, 8, 8)), FastFlowUnit(4, 4, 3), FastFlowUnit(4, 4, 3))
     assert len(list(seq)) == 2 and hasattr(seq, "sample") and hasattr(seq, "log_prob")
+
+
+def test_cincflowunit_contract():
+    """cinc_flow.py:9-24: one TL PaddedConv2d over ALL channels (out_channels overridden), no C%4 rule."""
+    from fincflow_amd import CINCFlowUnit
+    u = CINCFlowUnit(6, 999, 3)
+    assert sorted(u.state_dict().keys()) == ["conv_tl.conv.weight"]
+    assert tuple(u.conv_tl.conv.weight.shape) == (6, 6, 3, 3)
+    assert u.conv_tl.order == "TL"
+    with pytest.raises(RuntimeError, match="CUDA tensor"):
+        u(torch.randn(1, 6, 4, 4))
+    with pytest.raises(RuntimeError, match="CUDA tensor"):
+        u.reverse(torch.randn(1, 6, 4, 4))
+
+
+def test_load_reference_checkpoint(tmp_path):
+    """train/experiment.py:400-427: {'model_state_dict': ...} written by torch.save; DataParallel prefix;
+    a checkpoint that breaks the unit-triangular corner tap is refused."""
+    from fincflow_amd import load_reference_checkpoint
+    g = golden("unit_c1_B2_C4_8x8_k3")
+    sd = {f"0.conv_{o}.conv.weight": torch.from_numpy(g[f"w_{o}"]) for o in ("tl", "tr", "bl", "br")}
+    path = tmp_path / "ckpt.tar"
+    torch.save({"summary": {}, "model_state_dict": {"module." + k: v for k, v in sd.items()},
+                "optimizer_state_dict": {}, "scheduler_state_dict": {}, "config": {"name": "x"}}, path)
+    model = FlowSequential(StandardNormal((4, 8, 8)), FastFlowUnit(4, 4, 3))
+    missing, unexpected = load_reference_checkpoint(model, str(path))
+    assert not missing and not unexpected
+    for o in ("tl", "tr", "bl", "br"):
+        assert np.array_equal(getattr(model[0] if hasattr(model, "__getitem__") else list(model)[0],
+                                      f"conv_{o}").conv.weight.detach().numpy(), g[f"w_{o}"])
+    bad = {k: v.clone() for k, v in sd.items()}
+    bad["0.conv_tr.conv.weight"][0, 0, -1, 0] = 2.0   # TR stores the corner tap at [.., -1, 0]
+    with pytest.raises(RuntimeError, match="unit-triangular"):
+        load_reference_checkpoint(model, bad)
+    load_reference_checkpoint(model, bad, validate=False)
