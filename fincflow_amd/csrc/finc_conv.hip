@@ -5,8 +5,9 @@
 //
 //   * lane (q,p): column w0+p, k-slot q.  The 16 lanes of a row q read 16 consecutive floats of one channel row
 //     = one 64-byte sector per load and per store: HBM traffic is coalesced by construction, no LDS at all.
-//   * per step: z[Cq x 16px] = sum_{a,b} W_ab * x[(h-a, w-b)]  as KH*KW*ceil(Cq/4)*ceil(Cq/16)
-//     v_mfma_f32_16x16x4_f32, all independent (two accumulator chains per output tile).
+//   * per step: z[Cq x 16px] = sum_{a,b} W_ab * x[(h-a, w-b)]: per tap and k-step one v_mfma_f32_16x16x4_f32 per full
+//     16-channel tile plus one v_mfma_f32_4x4x1_16B_f32 per remaining 4-channel block (finc_tile.h), all independent
+//     across rows (one accumulator set per unrolled sub-step).
 //   * column shifts b come from DPP row_shr:b, the b columns left of the strip from a tiny masked "halo" load;
 //     row shifts a are the operands of the previous rows, kept in registers (the row slot rotates with the
 //     loop, which is unrolled by KH, so ageing a row costs no instruction).
@@ -17,6 +18,7 @@
 // (DESIGN.md 3.3), so finc_backward_f32 calls this kernel with `transpose` fragments and orient ^ 3 per group.
 // Replaces F.pad + cuDNN conv (layers/conv.py:102-107) x4 + chunk/cat (fastflow.py:31-50).
 #include "finc_common.h"
+#include "finc_tile.h"
 
 #include <type_traits>
 #include <utility>
@@ -49,13 +51,16 @@ __device__ inline float row_shl(float src)
 // tap -- 1/NW of the fragments and of the input rows -- and the partial output tiles are summed through LDS once per
 // row.  That is how a filter bank that does not fit one wave's registers (Cq=48, 5x5: 900 fragments) still runs with
 // every fragment register-resident.
+// Two waves per SIMD (256 registers each) is what hides one wave's loads, stores and VALU behind the other's MFMAs:
+// single-wave workgroups ask for that register budget (the K-split variants keep theirs: their waves are many).
 template <int CQP, int KH, int KW, int NW>
-__global__ __launch_bounds__(64 * NW) void finc_conv_kernel(const float *__restrict__ in,
+__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 1 ? 2 : 1))) void finc_conv_kernel(const float *__restrict__ in,
                                                             const float *__restrict__ packed, float *__restrict__ out,
                                                             int G, int CQ, int H, int W, int NS, unsigned orient)
 {
-    constexpr int MT = (CQP + 15) / 16, NKZT = CQP / 4, NTAP = KH * KW;
-    static_assert(NKZT % NW == 0 && (MT * 4) % NW == 0, "K-split must divide the k-steps and the output registers");
+    constexpr int MTB = CQP / 16, NSM = (CQP % 16) / 4, MT = MTB + NSM, NKZT = CQP / 4, NTAP = KH * KW;
+    static_assert(NW == 1 || (NSM == 0 && NKZT % NW == 0 && (MT * 4) % NW == 0),
+                  "K-split needs full tiles and must divide the k-steps and the output registers");
     constexpr int NKZ = NKZT / NW;                        // k-steps this wave owns
     constexpr int NFRAG = NTAP * NKZ * MT;                // fragments this wave holds
     constexpr int DREG = MT * 4 / NW;                     // output registers this wave finalises and stores
@@ -84,8 +89,11 @@ __global__ __launch_bounds__(64 * NW) void finc_conv_kernel(const float *__restr
             const int mt = f % MT, jl = (f / MT) % NKZ, tap = f / (MT * NKZ);
             af[f] = pk[((tap * NKZT + wv * NKZ + jl) * MT + mt) * 64];
         }
+        // MFMA A operands: keep them out of the VGPRs.  With the 256-register budget the files are split 128 : 128, so
+        // a bank larger than that pins what fits and leaves the rest to the allocator.
+        constexpr int NPIN = (NW == 1 && NFRAG > 124) ? 124 : NFRAG;
 #pragma unroll
-        for (int f = 0; f < NFRAG; ++f) asm volatile("" : "+a"(af[f])); // MFMA A operands: keep them out of the VGPRs
+        for (int f = 0; f < NPIN; ++f) asm volatile("" : "+a"(af[f]));
     }
 
     // Addressing is branch-free and select-free: a buffer offset = (row part, scalar) + (lane part, constant).
@@ -97,22 +105,31 @@ __global__ __launch_bounds__(64 * NW) void finc_conv_kernel(const float *__restr
     const bool hok = p < KW - 1 && hcol >= 0;
     const unsigned coloff = (unsigned)(fw ? W - 1 - col : col) * 4u;
     const unsigned hcoloff = (unsigned)(fw ? W - 1 - hcol : hcol) * 4u;
-    unsigned lin[NKZ], lhal[NKZ], lout[MT][4];
+    // Lane part of an offset: column + k-slot/lane-row channel q; the uniform channel part (4j, 16mt+r, ...) rides in the
+    // instruction's scalar offset.  Channels >= CQ exist only in the LAST group of four, so only the last k-step / the
+    // last output group needs its own (masked) lane part.  (Validity must sit in the VGPR offset: the scalar offset is
+    // not part of the buffer range check.)
+    const unsigned qoff = (unsigned)q * HW * 4u;
+    const bool lastok = 4 * (wv * NKZ + NKZ - 1) + q < CQ;
+    const unsigned lin0 = colok ? coloff + qoff : OFF_BAD_CHANNEL;
+    const unsigned lin1 = (colok && lastok) ? coloff + qoff : OFF_BAD_CHANNEL;
+    const unsigned lhal0 = hok ? hcoloff + qoff : OFF_BAD_CHANNEL;
+    const unsigned lhal1 = (hok && lastok) ? hcoloff + qoff : OFF_BAD_CHANNEL;
+    const unsigned lo_base = colok ? coloff + 4u * qoff : OFF_BAD_CHANNEL;   // 16-row tile: channel 16mt + 4q + r
+    unsigned lo_tail[4];                                  // last 16-row tile when it ends the group (Cq % 16 == 0 shapes)
 #pragma unroll
-    for (int j = 0; j < NKZ; ++j) {
-        const int cin = 4 * (wv * NKZ + j) + q;               // input channel of k-slot q of this wave's k-step j
-        const bool chok = cin < CQ;
-        const unsigned ch = (unsigned)cin * HW * 4u;
-        lin[j] = (colok && chok) ? coloff + ch : OFF_BAD_CHANNEL;
-        lhal[j] = (hok && chok) ? hcoloff + ch : OFF_BAD_CHANNEL;
+    for (int r = 0; r < 4; ++r)
+        lo_tail[r] = (colok && 16 * (MTB - 1) + 4 * q + r < CQ) ? coloff + 4u * qoff : OFF_BAD_CHANNEL;
+    unsigned lout[NW > 1 ? MT : 1][4];                    // K-split store path: per-register lane offsets
+    if constexpr (NW > 1) {
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int c = 16 * mt + 4 * q + r;
+                lout[mt][r] = (colok && c < CQ) ? coloff + (unsigned)c * HW * 4u : OFF_BAD_CHANNEL;
+            }
     }
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int c = 16 * mt + 4 * q + r;
-            lout[mt][r] = (colok && c < CQ) ? coloff + (unsigned)c * HW * 4u : OFF_BAD_CHANNEL;
-        }
     auto rowoff = [&](int h) {                            // scalar
         return (h >= 0 && h < H) ? (unsigned)((fh ? H - 1 - h : h) * W) * 4u : OFF_INVALID;
     };
@@ -127,12 +144,14 @@ __global__ __launch_bounds__(64 * NW) void finc_conv_kernel(const float *__restr
     float nxt[NKZ], nxh[NKZ];                             // the row loaded one step ahead (+ its halo)
     auto issue = [&](int h) {
         const unsigned ro = rowoff(h);
+        const unsigned v0 = ro + lin0, v1 = ro + lin1, h0 = ro + lhal0, h1 = ro + lhal1;
 #pragma unroll
         for (int j = 0; j < NKZ; ++j) {
-            const unsigned u = __builtin_amdgcn_raw_buffer_load_b32(rin, ro + lin[j], 0, 0);
+            const int so = 4 * (wv * NKZ + j) * HW * 4;   // uniform: channel 4j of this wave's k-step j
+            const unsigned u = __builtin_amdgcn_raw_buffer_load_b32(rin, j == NKZ - 1 ? v1 : v0, so, 0);
             nxt[j] = __builtin_bit_cast(float, u);
             if constexpr (KW > 1) {
-                const unsigned uh = __builtin_amdgcn_raw_buffer_load_b32(rin, ro + lhal[j], 0, 0);
+                const unsigned uh = __builtin_amdgcn_raw_buffer_load_b32(rin, j == NKZ - 1 ? h1 : h0, so, 0);
                 nxh[j] = __builtin_bit_cast(float, uh);
             }
         }
@@ -146,20 +165,33 @@ __global__ __launch_bounds__(64 * NW) void finc_conv_kernel(const float *__restr
     int parity = 0;
     auto store_row = [&](const v4f (&ac)[MT], int h) {   // h = the row those accumulators belong to
         const unsigned ro = rowoff(h);
-        float vv[MT * 4];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt) {
-            const float v0 = ac[mt].x, v1 = ac[mt].y, v2 = ac[mt].z, v3 = ac[mt].w;
-            vv[4 * mt + 0] = v0; vv[4 * mt + 1] = v1; vv[4 * mt + 2] = v2; vv[4 * mt + 3] = v3;
-        }
         if constexpr (NW == 1) {
+            const unsigned vb = ro + lo_base;
 #pragma unroll
-            for (int d = 0; d < MT * 4; ++d)
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vv[d]), rout, ro + lout[d / 4][d % 4], 0,
-                                                      0);
+            for (int mt = 0; mt < MTB; ++mt) {
+                const float v[4] = {ac[mt].x, ac[mt].y, ac[mt].z, ac[mt].w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const unsigned vo = (NSM == 0 && mt == MTB - 1) ? ro + lo_tail[r] : vb;
+                    __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[r]), rout, vo, (16 * mt + r) * HW * 4, 0);
+                }
+            }
+            // a reduced 4-row block leaves channel 16*MTB + 4sb + q in lane row q: the lane part of an input k-step
+#pragma unroll
+            for (int sb = 0; sb < NSM; ++sb) {
+                const float v = finc_block_reduce(ac[MTB + sb]);
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rout, ro + (sb == NSM - 1 ? lin1 : lin0),
+                                                      (16 * MTB + 4 * sb) * HW * 4, 0);
+            }
         } else {
             // exchange: register d of the output belongs to wave d / DREG; everybody ships the registers it does not
             // own, one barrier, the owner adds the NW-1 partials it received and stores (double-buffered by parity)
+            float vv[MT * 4];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const float v0 = ac[mt].x, v1 = ac[mt].y, v2 = ac[mt].z, v3 = ac[mt].w;
+                vv[4 * mt + 0] = v0; vv[4 * mt + 1] = v1; vv[4 * mt + 2] = v2; vv[4 * mt + 3] = v3;
+            }
             float *xb = xch + parity * (NW * NW * DREG * 64);
 #pragma unroll
             for (int d = 0; d < MT * 4; ++d) {
@@ -221,8 +253,7 @@ __global__ __launch_bounds__(64 * NW) void finc_conv_kernel(const float *__restr
                 for (int j = 0; j < NKZ; ++j)
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
-                        ac[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[((a * KW + b) * NKZ + j) * MT + mt],
-                                                                      X[(S + KH - a) % KH][b][j], ac[mt], 0, 0, 0);
+                        finc_mma<MTB>(ac[mt], mt, af[((a * KW + b) * NKZ + j) * MT + mt], X[(S + KH - a) % KH][b][j]);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[S][mt] = ac[mt];
     };
@@ -376,9 +407,9 @@ __global__ void gradw_reduce_kernel(const float *__restrict__ part, float *__res
     }
 }
 
-// fragment (tap (a,b), j, mt), lane (q,i): W[row 16mt+i][col 4j+q][KH-1-a][KW-1-b]; `transpose` swaps row/col
+// fragment (tap (a,b), j, mt), lane (q,i): W[row finc_tile_row(mt,i)][col 4j+q][KH-1-a][KW-1-b]; `transpose` swaps row/col
 __global__ void conv_pack_kernel(const float *__restrict__ wc, float *__restrict__ packed, int Cq, int KH, int KW, int MT,
-                                 int NKZ, int transpose, int nfrag)
+                                 int MTB, int NKZ, int transpose, int nfrag)
 {
     const int g = blockIdx.y;
     const float *wg = wc + (size_t)g * Cq * Cq * KH * KW;
@@ -387,7 +418,7 @@ __global__ void conv_pack_kernel(const float *__restrict__ wc, float *__restrict
         const int lane = e & 63, f = e >> 6;
         const int q = lane >> 4, i = lane & 15;
         const int mt = f % MT, j = (f / MT) % NKZ, tap = f / (MT * NKZ);
-        const int row = 16 * mt + i, col = 4 * j + q;
+        const int row = finc_tile_row(MTB, mt, i), col = 4 * j + q;
         const int a = tap / KW, b = tap % KW;
         float v = 0.f;
         if (row < Cq && col < Cq) {
@@ -403,18 +434,20 @@ typedef void (*gradw_fn)(const float *, const float *, float *, int, int, int, i
 struct ConvInst {
     int cqp, kh, kw;
     conv_fn fn;
-    int mt, nkz, nfrag, nw;
+    int mt, mtb, nkz, nfrag, nw; // mt = mtb 16-row tiles + 4-row blocks: fragments per (tap, k-step)
+    int mtg;                     // grad-weight kernel: ceil(Cq/16) tiles in both dimensions
     gradw_fn gw; // MFMA grad-weight kernel (nullptr: NTAP*MT*MT accumulators would not fit)
 };
 template <int CQP, int KH, int KW, int NW = 1>
 constexpr ConvInst make_conv()
 {
-    constexpr int MT = (CQP + 15) / 16;
-    if constexpr (KH * KW * MT * MT * 4 <= 200)
-        return ConvInst{CQP, KH, KW, finc_conv_kernel<CQP, KH, KW, NW>, MT, CQP / 4, KH * KW * (CQP / 4) * MT, NW,
+    constexpr int MTG = (CQP + 15) / 16, MTB = CQP / 16, MT = MTB + (CQP % 16) / 4;
+    if constexpr (KH * KW * MTG * MTG * 4 <= 200)
+        return ConvInst{CQP, KH, KW, finc_conv_kernel<CQP, KH, KW, NW>, MT, MTB, CQP / 4, KH * KW * (CQP / 4) * MT, NW, MTG,
                         finc_gradw_kernel<CQP, KH, KW>};
     else
-        return ConvInst{CQP, KH, KW, finc_conv_kernel<CQP, KH, KW, NW>, MT, CQP / 4, KH * KW * (CQP / 4) * MT, NW, nullptr};
+        return ConvInst{CQP, KH, KW, finc_conv_kernel<CQP, KH, KW, NW>, MT, MTB, CQP / 4, KH * KW * (CQP / 4) * MT, NW, MTG,
+                        nullptr};
 }
 const ConvInst g_conv[] = {
     make_conv<4, 3, 3>(),  make_conv<8, 3, 3>(),  make_conv<12, 3, 3>(), make_conv<16, 3, 3>(), make_conv<24, 3, 3>(),
@@ -452,7 +485,7 @@ int finc_conv_pack(const float *wc, void *packed, int G, int Cq, int KH, int KW,
     int blocks = (total + 255) / 256;
     if (blocks > 64) blocks = 64;
     hipLaunchKernelGGL(conv_pack_kernel, dim3(blocks, G), dim3(256), 0, st, wc, (float *)packed, Cq, KH, KW, i->mt,
-                       i->nkz, transpose ? 1 : 0, i->nfrag);
+                       i->mtb, i->nkz, transpose ? 1 : 0, i->nfrag);
     FINC_CHECK_LAUNCH();
     return FINC_OK;
 }
@@ -467,7 +500,7 @@ size_t finc_gradw_workspace_bytes(const FincShape &s)
 {
     const ConvInst *i = find_conv(s.Cq, s.KH, s.KW);
     if (!i || !i->gw || !finc_conv_supported(s.Cq, s.H, s.W, s.KH, s.KW)) return 0;
-    return (size_t)s.G * gradw_wpg(s) * s.KH * s.KW * i->mt * i->mt * 256 * sizeof(float);
+    return (size_t)s.G * gradw_wpg(s) * s.KH * s.KW * i->mtg * i->mtg * 256 * sizeof(float);
 }
 
 int finc_gradw_launch(const float *gz, const float *x, float *gw, void *workspace, const FincShape &s, hipStream_t st)
@@ -478,10 +511,10 @@ int finc_gradw_launch(const float *gz, const float *x, float *gw, void *workspac
     hipLaunchKernelGGL(i->gw, dim3(s.G * WPG), dim3(64), 0, st, gz, x, (float *)workspace, s.G, s.Cq, s.H, s.W, NS, s.B,
                        WPG, s.orient);
     FINC_CHECK_LAUNCH();
-    const int per = s.KH * s.KW * i->mt * i->mt * 256;
+    const int per = s.KH * s.KW * i->mtg * i->mtg * 256;
     int blocks = (per + 255) / 256;
     hipLaunchKernelGGL(gradw_reduce_kernel, dim3(blocks, s.G), dim3(256), 0, st, (const float *)workspace, gw, s.Cq, s.KH,
-                       s.KW, i->mt, WPG);
+                       s.KW, i->mtg, WPG);
     FINC_CHECK_LAUNCH();
     return FINC_OK;
 }

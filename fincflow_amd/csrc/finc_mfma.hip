@@ -34,6 +34,7 @@
 //
 // The forward has no recurrence and uses a different, simpler mapping: finc_conv.hip.
 #include "finc_common.h"
+#include "finc_tile.h"
 
 #include <type_traits>
 #include <utility>
@@ -47,15 +48,19 @@ typedef unsigned v4u __attribute__((ext_vector_type(4)));
 template <int CQP_, int KH_, int KW_, int NW_ = 1>
 struct Cfg {
     static constexpr int CQP = CQP_, KH = KH_, KW = KW_, NW = NW_;
-    static constexpr int MT = (CQP + 15) / 16;            // 16-row output-channel tiles
+    // Output channels: MTB full 16-row tiles (v_mfma_f32_16x16x4_f32) + NSM 4-row blocks for the rest
+    // (v_mfma_f32_4x4x1_16B_f32: 16 independent 4x4 outer products = 4 k-slots x 4 pixel quads of ONE 4-channel block;
+    // its B operand is the very same register, and 2 passes instead of 8 -- so Cq = 24 costs 1 + 2*1/4 tiles of MFMA
+    // time instead of 2, and neither M nor K carries padding).
+    static constexpr int MTB = CQP / 16;
+    static constexpr int NSM = (CQP % 16) / 4;
+    static constexpr int MT = MTB + NSM;                  // accumulators / fragments per (tap, k-step)
     static constexpr int NKZT = CQP / 4;                  // k-steps of a streamed operand (k-slot q <-> channel 4j+q)
-    static constexpr int LASTV = (CQP - 16 * (MT - 1)) / 4; // k-slots of the last D tile that hold real channels
-    static constexpr bool PACK = LASTV <= 2;              // fold the last tile's 4 half-empty regs into 2
-    static constexpr int NKDT = PACK ? 4 * (MT - 1) + 2 : 4 * MT; // regs of a D-layout result as operand / for store
+    static constexpr int NKDT = CQP / 4;                  // regs of a solved pixel as operand / for store
     // NW > 1 ("K-split"): wave w of the workgroup owns k-steps [w*NKZ, (w+1)*NKZ) of the z-term and
     // [w*NKD, (w+1)*NKD) of every tap, i.e. 1/NW of the fragments; the output registers it finalises after the
     // per-step exchange are exactly the D registers that are its own operands.
-    static_assert(NW == 1 || (!PACK && NKZT % NW == 0 && NKDT % NW == 0), "K-split needs full tiles and divisibility");
+    static_assert(NW == 1 || (NSM == 0 && NKZT % NW == 0 && NKDT % NW == 0), "K-split needs full tiles and divisibility");
     static constexpr int NKZ = NKZT / NW;                 // per wave
     static constexpr int NKD = NKDT / NW;
     static constexpr int NK = NKD;                        // k-steps per neighbour tap (per wave)
@@ -68,13 +73,13 @@ struct Cfg {
     static constexpr int XCH = NW > 1 ? NW * NW * NKD * 64 : 0;   // exchange buffer [dst][src][reg][lane]
 };
 
-// channel held by k-slot q of k-step j of a D-layout-derived operand
-__host__ __device__ inline int chan_d(int MT, bool PACK, int j, int q)
+// channel held by k-slot q of k-step j of an operand made from solved pixels: registers of the 16-row tiles first
+// (D layout: reg r of tile mt, lane row q = channel 16mt + 4q + r), then one register per 4-row block (channel
+// 16*MTB + 4sb + q after the reduce-transpose of pack_d)
+__host__ __device__ inline int chan_d(int MTB, int j, int q)
 {
-    const int full = PACK ? 4 * (MT - 1) : 4 * MT;
-    if (j < full) return 16 * (j >> 2) + 4 * q + (j & 3);
-    const int jj = j - full;
-    return 16 * (MT - 1) + (q < 2 ? 4 * q + 2 * jj : 4 * (q - 2) + 2 * jj + 1);
+    if (j < 4 * MTB) return 16 * (j >> 2) + 4 * q + (j & 3);
+    return 16 * MTB + 4 * (j - 4 * MTB) + q;
 }
 
 template <int N>
@@ -96,31 +101,22 @@ struct ShiftOp {
     }
 };
 
-// D-layout accumulators -> operand/store registers (identity or pair-packing of the last tile)
+// accumulators -> operand/store registers.  A 16-row tile's 4 registers are operands as they are.  A 4-row block's
+// register i holds, in lane row q', the k-slot-q' PARTIAL sum of channel base+i: sum over the 4 lane rows and leave
+// channel base+q in lane row q (a 4x4 transpose-reduce: rows two apart by v_permlane32_swap + add, rows one apart by
+// v_permlane16_swap + add).
 template <class C>
 __device__ inline void pack_d(const v4f (&acc)[C::MT], float (&xpk)[C::NKDT])
 {
-    constexpr int full = C::PACK ? C::MT - 1 : C::MT;
 #pragma unroll
-    for (int mt = 0; mt < full; ++mt) {
+    for (int mt = 0; mt < C::MTB; ++mt) {
         xpk[4 * mt + 0] = acc[mt].x;
         xpk[4 * mt + 1] = acc[mt].y;
         xpk[4 * mt + 2] = acc[mt].z;
         xpk[4 * mt + 3] = acc[mt].w;
     }
-    if constexpr (C::PACK) {
-        // NB: __builtin_bit_cast applied directly to an ext-vector ELEMENT (a.y, s0.x ...) silently reads
-        // element 0 with this compiler; always go through scalar temporaries.
-        const float ax = acc[C::MT - 1].x, ay = acc[C::MT - 1].y, az = acc[C::MT - 1].z, aw = acc[C::MT - 1].w;
-        // v_permlane32_swap: new vdst = [vdst.lo32lanes, src.lo32lanes]
-        const v2u s0 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, ax), __builtin_bit_cast(unsigned, ay),
-                                                        false, false);
-        const v2u s1 = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, az), __builtin_bit_cast(unsigned, aw),
-                                                        false, false);
-        const unsigned u0 = s0.x, u1 = s1.x;
-        xpk[4 * (C::MT - 1) + 0] = __builtin_bit_cast(float, u0);
-        xpk[4 * (C::MT - 1) + 1] = __builtin_bit_cast(float, u1);
-    }
+#pragma unroll
+    for (int sb = 0; sb < C::NSM; ++sb) xpk[4 * C::MTB + sb] = finc_block_reduce(acc[C::MTB + sb]);
 }
 
 // taps of the inverse's phase B (a+b >= 2), row-major
@@ -158,8 +154,29 @@ struct BTaps {
 #ifndef FINC_ABLATE
 #define FINC_ABLATE 0
 #endif
+#ifndef FINC_ABLATE_IO   // timing-only bit mask: 1 no loads, 2 no stores, 4 no landing, 8 no x-ring read
+#define FINC_ABLATE_IO 0
+#endif
 template <int I>
 using IC = std::integral_constant<int, I>;
+
+// Diagnostic build only (-DFINC_STAMP, scripts/stamp.sh): s_memtime stamps at the region boundaries of a step,
+// accumulated per (step & 3, segment) for ONE wave over the steady-state steps and left in a buffer of their own.
+// The stamp's lgkmcnt(0) drains the LDS queue, so read the SHARES of such a build, never its run time.
+#ifdef FINC_STAMP
+__device__ unsigned long long finc_stamp_buf[64];
+#define FINC_STAMP_AT(k)                                                                                              \
+    do {                                                                                                              \
+        FINC_SB();                                                                                                    \
+        unsigned long long t_;                                                                                        \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                                     \
+        if (stamp_on) stamp_acc[PH * 10 + (k)] += (unsigned)(t_ - stamp_prev);                                         \
+        stamp_prev = t_;                                                                                              \
+        FINC_SB();                                                                                                    \
+    } while (0)
+#else
+#define FINC_STAMP_AT(k) do { } while (0)
+#endif
 
 constexpr unsigned OFF_INVALID = 0x80000000u;    // voffset beyond any slab: buffer loads return 0, stores are dropped
 constexpr unsigned OFF_BAD_CHANNEL = 0x40000000u; // added to a valid offset it still lands beyond the slab (< 1 GiB)
@@ -247,7 +264,7 @@ __global__ __launch_bounds__(64 * NW) void finc_wave_kernel(const float *__restr
     unsigned coff[NKD];                       // per-lane channel byte offsets of the registers this wave stores
 #pragma unroll
     for (int j = 0; j < NKD; ++j) {
-        const int c = chan_d(MT, C::PACK, wv * NKD + j, q);
+        const int c = chan_d(C::MTB, wv * NKD + j, q);
         coff[j] = c < CQ ? (unsigned)c * HW * 4u : OFF_BAD_CHANNEL;
     }
     v4u zb[NKZ][NPC];                         // in flight HBM -> z ring (raw: nothing may touch it until it lands)
@@ -277,29 +294,38 @@ __global__ __launch_bounds__(64 * NW) void finc_wave_kernel(const float *__restr
     const int lwrap = (fh ? -P : P) * W * 4 - (fw ? -1 : 1) * W * 4;         // extra bytes when the chunk wraps to row+P
     int loff = ((fh ? H - 1 - lrow : lrow) * W + (fw ? W - (SEC ? 8 : 4) - lcol : lcol)) * 4 + (4 * wv * NKZ + q) * HW * 4;
     const unsigned zlast = (4 * (wv * NKZ + NKZ - 1) + q) < CQ ? 0u : OFF_BAD_CHANNEL;  // only the last k-step can hold a padded channel
-    auto io_issue = [&]() {
+    // Memory instructions are spread over the window, a few per step: 12 strided stores (or loads) issued back to back
+    // overrun the CU's memory queues and the wave stalls for most of a microsecond (scripts/micro/vmem_issue.hip).
+    auto io_issue = [&](int j0, int j1, bool advance) {
         const bool ok = lcol >= 0 && lrow < H && p < P;
         const unsigned vb = ok ? (unsigned)loff : OFF_INVALID;
         if constexpr (SEC) {
             if (lph == 0) {                   // one parity class per window (divergent: other lanes keep their data)
 #pragma unroll
                 for (int j = 0; j < NKZ; ++j) {
+                    if (j < j0 || j >= j1) continue;
                     const unsigned vo = j == NKZ - 1 ? vb + zlast : vb;
                     zb[j][0] = __builtin_amdgcn_raw_buffer_load_b128(rin, vo, j * 16 * HW, 0);
                     zb[j][1] = __builtin_amdgcn_raw_buffer_load_b128(rin, vo + 16u, j * 16 * HW, 0);
                 }
-                lcol += 8;
+                if (advance) {
+                    lcol += 8;
+                    loff += lstep;
+                    if (lcol == W) { lcol = 0; lrow += P; loff += lwrap; }
+                }
+            }
+            if (advance) lph ^= 1;
+        } else {
+#pragma unroll
+            for (int j = 0; j < NKZ; ++j) {
+                if (j < j0 || j >= j1) continue;
+                zb[j][0] = __builtin_amdgcn_raw_buffer_load_b128(rin, j == NKZ - 1 ? vb + zlast : vb, j * 16 * HW, 0);
+            }
+            if (advance) {
+                lcol += 4;
                 loff += lstep;
                 if (lcol == W) { lcol = 0; lrow += P; loff += lwrap; }
             }
-            lph ^= 1;
-        } else {
-#pragma unroll
-            for (int j = 0; j < NKZ; ++j)
-                zb[j][0] = __builtin_amdgcn_raw_buffer_load_b128(rin, j == NKZ - 1 ? vb + zlast : vb, j * 16 * HW, 0);
-            lcol += 4;
-            loff += lstep;
-            if (lcol == W) { lcol = 0; lrow += P; loff += lwrap; }
         }
     };
     auto io_land = [&]() {
@@ -347,12 +373,13 @@ __global__ __launch_bounds__(64 * NW) void finc_wave_kernel(const float *__restr
         scol += 4;
         if (scol == W) { scol = 0; srow += P; }
     };
-    auto io_swrite = [&]() {
+    auto io_swrite = [&](int j0, int j1) {
         // every lane issues; lanes whose pair is not complete (or that are off the image) drop by offset
         const unsigned base = st_fire ? st_off : OFF_INVALID;
         const unsigned o_even = fw ? 16u : 0u, o_odd = fw ? 0u : 16u; // held (even) group / fresh (odd) group
 #pragma unroll
         for (int j = 0; j < NKD; ++j) {
+            if (j < j0 || j >= j1) continue;
             const unsigned vo = base == OFF_INVALID ? OFF_INVALID : base + coff[j];
             v4u v;
             v.x = __builtin_bit_cast(unsigned, sv[j][0]);
@@ -374,14 +401,27 @@ __global__ __launch_bounds__(64 * NW) void finc_wave_kernel(const float *__restr
             }
         }
     };
-    auto io_phase = [&](auto ph_c) {           // one quarter of the window's HBM work per step
+    // the window's HBM work, spread over its 4 steps: step 0 reads the x ring; steps 1-3 store a third of the registers
+    // each; step 2 lands the loads of the previous window and re-issues the first half, step 3 the second half
+    constexpr int S1 = (NKD + 2) / 3, S2 = (2 * NKD + 2) / 3, L1 = (NKZ + 1) / 2;
+    auto io_phase = [&](auto ph_c) {
         constexpr int PH = decltype(ph_c)::value;
         if constexpr (FINC_ABLATE >= 1) return;
-        if constexpr (PH == 0) io_sread();
-        if constexpr (PH == 1) io_swrite();
-        if constexpr (PH == 2) io_land();
-        if constexpr (PH == 3) io_issue();
+        constexpr int AB = FINC_ABLATE_IO;
+        if constexpr (PH == 0 && !(AB & 8)) io_sread();
+        if constexpr (PH == 1 && !(AB & 2)) io_swrite(0, S1);
+        if constexpr (PH == 2) {
+            if constexpr (!(AB & 2)) io_swrite(S1, S2);
+            if constexpr (!(AB & 4)) io_land();
+            if constexpr (!(AB & 1)) io_issue(0, L1, false);
+        }
+        if constexpr (PH == 3) {
+            if constexpr (!(AB & 2)) io_swrite(S2, NKD);
+            if constexpr (!(AB & 1)) io_issue(L1, NKZ, true);
+        }
     };
+    auto io_swrite_all = [&]() { io_swrite(0, NKD); };
+    auto io_issue_all = [&]() { io_issue(0, NKZ, true); };
 
     // ---- neighbour operands --------------------------------------------------------------------
     // S_a(tau) = row_shr:a of the pixels solved at step tau (S_0 = the pixels themselves).  Tap (a,b) of step t reads
@@ -495,13 +535,13 @@ __global__ __launch_bounds__(64 * NW) void finc_wave_kernel(const float *__restr
     // pre-loop = the HBM side of the two windows before the first computed one
     if constexpr (SEC) {
         io_land();   // window -3 (lands only zeros)
-        io_issue();
+        io_issue_all();
         io_land();   // window -2: the first group lands
-        io_issue();
+        io_issue_all();
     } else {
-        io_issue();
+        io_issue_all();
         io_land();
-        io_issue();  // left in flight, lands in window -1
+        io_issue_all();  // left in flight, lands in window -1
     }
 
     int nslot = ((-3 - p) % 12 + 12) % 12;    // z-ring slot of the position of step t+1 ...
@@ -527,18 +567,24 @@ __global__ __launch_bounds__(64 * NW) void finc_wave_kernel(const float *__restr
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     if constexpr (KW > 1)
-                        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[FT + ((0 * KW + 1 - 1) * NK + j) * MT + mt],
-                                                                       ROT ? Q[0][(PHA + 3) & 3][j] : R[0][1][j], acc[mt],
-                                                                       0, 0, 0);
+                        finc_mma<C::MTB>(acc[mt], mt, af[FT + ((0 * KW + 1 - 1) * NK + j) * MT + mt],
+                                    ROT ? Q[0][(PHA + 3) & 3][j] : R[0][1][j]);
                     if constexpr (KH > 1)
-                        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[FT + ((1 * KW + 0 - 1) * NK + j) * MT + mt],
-                                                                       ROT ? Q[1][(PHA + 3) & 3][j] : R[1][0][j], acc[mt],
-                                                                       0, 0, 0);
+                        finc_mma<C::MTB>(acc[mt], mt, af[FT + ((1 * KW + 0 - 1) * NK + j) * MT + mt],
+                                    ROT ? Q[1][(PHA + 3) & 3][j] : R[1][0][j]);
                 }
         };
 
+#ifdef FINC_STAMP
+        unsigned stamp_acc[40];
+#pragma unroll
+        for (int i = 0; i < 40; ++i) stamp_acc[i] = 0u;
+        unsigned long long stamp_prev = 0;
+        bool stamp_on = false;
+#endif
         auto step = [&](auto ph_c) {
             constexpr int PH = decltype(ph_c)::value;   // == t & 3
+            FINC_STAMP_AT(9);                           // segment 9: loop latch (between two steps)
             // the masks cost VALU issue that f32 MFMAs do not hide: apply them only on the steps where a lane
             // wraps (P of every W steps) / has not started yet (the first P steps); both tests are scalar
             const bool any_wrap = tm >= 0 && tm < P;
@@ -591,6 +637,7 @@ __global__ __launch_bounds__(64 * NW) void finc_wave_kernel(const float *__restr
                 for (int j = 0; j < NKZ; ++j) zv[j] = started ? zv[j] : 0.f;
             }
             phase_a(ph_c, NK / 2, NK);
+            FINC_STAMP_AT(0);                           // segment 0: phase A (+ z read, idle mask)
             if constexpr (ROT) {
                 // the operands phase A just read unmasked (b = 0 / 1 of this step) become b >= 1 taps of a step that
                 // starts a row: zero them, for the wrapping lanes only, after phase A has issued and before phase B
@@ -617,7 +664,8 @@ __global__ __launch_bounds__(64 * NW) void finc_wave_kernel(const float *__restr
             for (int j = 0; j < NKZ; ++j)
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
-                    accn[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[FZ + j * MT + mt], zv[j], accn[mt], 0, 0, 0);
+                    finc_mma<C::MTB>(accn[mt], mt, af[FZ + j * MT + mt], zv[j]);
+            FINC_STAMP_AT(1);                           // segment 1: z-term
             if constexpr (NW > 1) {
                 // K-split exchange: acc holds this wave's share of ALL output registers.  Ship the registers other waves
                 // own, keep ours; after the barrier post1 adds the NW-1 shares it received.
@@ -685,13 +733,13 @@ __global__ __launch_bounds__(64 * NW) void finc_wave_kernel(const float *__restr
                 for (int j = 0; j < NK; ++j)
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
-                        accn[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[FT + ((a * KW + b - 1) * NK + j) * MT + mt],
-                                                                        ROT ? Q[a][(PH + 9 - a - b) & 3][j] : R[a][b][j],
-                                                                        accn[mt], 0, 0, 0);
+                        finc_mma<C::MTB>(accn[mt], mt, af[FT + ((a * KW + b - 1) * NK + j) * MT + mt],
+                                    ROT ? Q[a][(PH + 9 - a - b) & 3][j] : R[a][b][j]);
                 if constexpr (CI == 0) post1();
                 if constexpr (CI == (NCH > 1 ? 1 : 0)) io_phase(ph_c);
                 if constexpr (CI == (NCH > 2 ? 2 : NCH - 1)) post2();
                 FINC_SB();
+                if constexpr (CI < 6) FINC_STAMP_AT(2 + CI); // segments 2.. : phase-B chunks (0: post1, 1: HBM I/O, 2: post2)
             };
             if constexpr (NCH == 0) {
                 post1();
@@ -712,14 +760,15 @@ __global__ __launch_bounds__(64 * NW) void finc_wave_kernel(const float *__restr
             if (nslot == 12) { nslot = 0; zrd -= 12 * 64; }
             if constexpr (PH == 3) xwin ^= 256;
             fifo_advance();
+            FINC_STAMP_AT(8);                           // segment 8: advance
         };
 
         // Window -4 (steps -4..-1) solves nothing: every lane is still before its first pixel.  Only its HBM side
         // and the z-term of lane 0's first pixel (phase B of step -1) matter, so it runs without the other 3.9 steps.
         io_sread();
-        io_swrite();
+        io_swrite_all();
         io_land();
-        io_issue();
+        io_issue_all();
 #pragma unroll
         for (int k = 0; k < 3; ++k) {                  // steps -4, -3, -2: bookkeeping only (the FIFO ring is zero)
             ++tp1; ++tm;
@@ -735,7 +784,7 @@ __global__ __launch_bounds__(64 * NW) void finc_wave_kernel(const float *__restr
                 const float zvj = started ? v : 0.f;
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt)
-                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[FZ + j * MT + mt], zvj, acc[mt], 0, 0, 0);
+                    finc_mma<C::MTB>(acc[mt], mt, af[FZ + j * MT + mt], zvj);
             }
             ++tp1; ++tm;
             ++nslot; zrd += 64;
@@ -744,24 +793,35 @@ __global__ __launch_bounds__(64 * NW) void finc_wave_kernel(const float *__restr
             fifo_advance();
         }
         for (int t0 = 0; t0 < Tend; t0 += 4) {
+#ifdef FINC_STAMP
+            stamp_on = t0 >= 64 && t0 < 192;
+#endif
             step(IC<0>{});
             step(IC<1>{});
             step(IC<2>{});
             step(IC<3>{});
         }
         io_sread();
-        io_swrite();
+        io_swrite_all();
+#ifdef FINC_STAMP
+        if (blockIdx.x == 517 && threadIdx.x == 0) {
+#pragma unroll
+            for (int i = 0; i < 40; ++i) finc_stamp_buf[i] = stamp_acc[i];
+        }
+#endif
     }
 }
 
 // -----------------------------------------------------------------------------------------------
 // Fragment packing (fp64 math, one workgroup per group): Linv = L^-1 by forward substitution;
 // z-term fragment = Linv; tap (a,b) fragment = -(Linv * Wc[:,:,KH-1-a,KW-1-b]).
-// Lane (q,i) of fragment (tap, j, mt) holds row 16mt+i, column = channel of k-slot q of k-step j
-// (z-term: 4j+q; taps: chan_d, the order in which the solved pixels leave the accumulators).
+// Lane (q,i) of fragment (tap, j, mt) holds row 16mt+i for a 16-row tile (mt < MTB), row 16*MTB + 4(mt-MTB) + (i&3)
+// for a 4-row block (the 4x4x1 A operand: lane 4*blk+i' = row i' of block blk, the same for all 4 pixel quads);
+// column = channel of k-slot q of k-step j (z-term: 4j+q; taps: chan_d, the order in which the solved pixels leave
+// the accumulators).
 // -----------------------------------------------------------------------------------------------
 __global__ void pack_kernel(const float *__restrict__ wc, float *__restrict__ packed, int Cq, int KH, int KW, int MT,
-                            int NKZ, int NKD, int pack_last, int unused, int nfrag)
+                            int NKZ, int NKD, int MTB, int unused, int nfrag)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[]; // Linv [Cq][Cq]
     const int g = blockIdx.x;
@@ -789,8 +849,8 @@ __global__ void pack_kernel(const float *__restrict__ wc, float *__restrict__ pa
             const int ff = f - NKZ * MT;
             mt = ff % MT; j = (ff / MT) % NKD; tap = 1 + ff / (MT * NKD);
         }
-        const int row = 16 * mt + i;
-        const int col = zterm ? 4 * j + q : chan_d(MT, pack_last != 0, j, q);
+        const int row = finc_tile_row(MTB, mt, i);
+        const int col = zterm ? 4 * j + q : chan_d(MTB, j, q);
         double v = 0.0;
         if (row < Cq && col < Cq) {
             if (zterm) {
@@ -816,7 +876,7 @@ struct Inst {
     int cqp, kh, kw;
     wave_fn fn;      // 16-byte-group I/O (any W % 4 == 0)
     wave_fn fn_sec;  // 32-byte-piece I/O (W % 8 == 0)
-    int nkz, nkd, nk, mt, nfrag, pack; // nkz/nkd/nfrag: per GROUP (packing); nk: per wave
+    int nkz, nkd, nk, mt, nfrag, mtb;  // nkz/nkd/nfrag: per GROUP (packing); nk: per wave; mt = mtb tiles + 4-row blocks
     int nw, wnkz, wnkd;                // K-split: waves per workgroup, per-wave k-steps
 };
 
@@ -825,7 +885,7 @@ constexpr Inst make_inst()
 {
     using C = Cfg<CQP, KH, KW, NW>;
     return Inst{CQP, KH, KW, finc_wave_kernel<CQP, KH, KW, false, NW>, finc_wave_kernel<CQP, KH, KW, true, NW>, C::NKZT, C::NKDT,
-                C::NK, C::MT, C::NFRAGT, C::PACK ? 1 : 0, NW, C::NKZ, C::NKD};
+                C::NK, C::MT, C::NFRAGT, C::MTB, NW, C::NKZ, C::NKD};
 }
 
 #define FINC_BOTH(cqp, kh, kw) make_inst<cqp, kh, kw>()
@@ -858,6 +918,13 @@ size_t lds_bytes(const Inst &i, int W, int P)
 
 } // namespace
 
+#ifdef FINC_STAMP
+extern "C" int finc_debug_stamps(unsigned long long *host_out, int n)
+{
+    return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(finc_stamp_buf), sizeof(unsigned long long) * (size_t)n);
+}
+#endif
+
 bool finc_mfma_supported(int Cq, int H, int W, int KH, int KW)
 {
     const Inst *i = find_inst(Cq, KH, KW);
@@ -881,7 +948,7 @@ int finc_mfma_pack(const float *wc, void *packed, int G, int Cq, int KH, int KW,
     const Inst *i = find_inst(Cq, KH, KW);
     if (!i) return FINC_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(pack_kernel, dim3(G), dim3(256), sizeof(double) * Cq * Cq, st, wc, (float *)packed, Cq, KH, KW,
-                       i->mt, i->nkz, i->nkd, i->pack, 0, i->nfrag);
+                       i->mt, i->nkz, i->nkd, i->mtb, 0, i->nfrag);
     FINC_CHECK_LAUNCH();
     return FINC_OK;
 }

@@ -1,0 +1,49 @@
+// Output-channel tiling shared by the MFMA kernels (gfx950 only; device code).
+//
+// The Cq output channels of a group are covered by MTB = Cq/16 full 16-row tiles (v_mfma_f32_16x16x4_f32, 8 passes)
+// plus NSM = (Cq%16)/4 four-row blocks (v_mfma_f32_4x4x1_16B_f32, 2 passes): 16 independent 4x4 outer products, used
+// as 4 k-slots x 4 pixel quads of ONE 4-channel block.  Both take the SAME B operand (lane (q,p) = channel 4j+q of
+// pixel p), so the rest of a group (Cq = 24: 8 channels) costs 2 x 2 passes per k-step instead of 8 for a second,
+// half-empty 16-row tile; neither M nor K carries padding.  Layouts pinned on hardware by scripts/micro/mfma4x4.hip.
+#pragma once
+
+typedef float finc_v4f __attribute__((ext_vector_type(4)));
+typedef unsigned finc_v2u __attribute__((ext_vector_type(2)));
+
+// one accumulator update: tile index mt < MTB is a 16-row tile, otherwise a 4-row block; `a` = the matching fragment
+// (16-row tile: lane (q,i) = W[16mt+i][k-slot q]; 4-row block: lane (q,i) = W[16*MTB + 4sb + (i&3)][k-slot q])
+template <int MTB>
+__device__ inline void finc_mma(finc_v4f &acc, int mt, float a, float b)
+{
+    if (mt < MTB) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, acc, 0, 0, 0);
+    else acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, acc, 0, 0, 0);
+}
+
+// A 4-row block's register i holds, in lane row q', the k-slot-q' PARTIAL sum of channel base+i.  Sum over the 4 lane
+// rows and leave channel base+q in lane row q: a 4x4 transpose-reduce (rows two apart by v_permlane32_swap + add,
+// rows one apart by v_permlane16_swap + add; 6 VALU).
+__device__ inline float finc_block_reduce(const finc_v4f &acc)
+{
+    // NB: __builtin_bit_cast applied directly to an ext-vector ELEMENT silently reads element 0 with this compiler;
+    // always go through scalar temporaries.
+    const float r0 = acc.x, r1 = acc.y, r2 = acc.z, r3 = acc.w;
+    // v_permlane32_swap(v, s): new v = [v.lanes 0-31, s.lanes 0-31], new s = [v.lanes 32-63, s.lanes 32-63]
+    const finc_v2u a = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, r0), __builtin_bit_cast(unsigned, r2),
+                                                        false, false);
+    const finc_v2u b = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, r1), __builtin_bit_cast(unsigned, r3),
+                                                        false, false);
+    const unsigned a0 = a.x, a1 = a.y, b0 = b.x, b1 = b.y;
+    const float s02 = __builtin_bit_cast(float, a0) + __builtin_bit_cast(float, a1); // rows 0,1: r0 ; rows 2,3: r2
+    const float s13 = __builtin_bit_cast(float, b0) + __builtin_bit_cast(float, b1); // rows 0,1: r1 ; rows 2,3: r3
+    // v_permlane16_swap(v, s): new v = [v.row0, s.row0, v.row2, s.row2], new s = [v.row1, s.row1, v.row3, s.row3]
+    const finc_v2u c = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, s02), __builtin_bit_cast(unsigned, s13),
+                                                        false, false);
+    const unsigned c0 = c.x, c1 = c.y;
+    return __builtin_bit_cast(float, c0) + __builtin_bit_cast(float, c1);
+}
+
+// row of the weight matrix held by lane i (0..15) of fragment tile mt
+__host__ __device__ inline int finc_tile_row(int MTB, int mt, int i)
+{
+    return mt < MTB ? 16 * mt + i : 16 * MTB + 4 * (mt - MTB) + (i & 3);
+}

@@ -4,7 +4,7 @@ set -e
 cd "$(dirname "$0")/../fincflow_amd/csrc"
 mkdir -p ../../ablate_build
 for v in 0 1 2 3; do
-  hipcc -O3 -fPIC --offload-arch=gfx950 -std=c++20 -DFINC_ABLATE=$v -c finc_mfma.hip -o ../../ablate_build/mfma_$v.o &
+  hipcc -O3 -fPIC --offload-arch=gfx950 -std=c++20 -mllvm -amdgpu-mfma-vgpr-form -DFINC_ABLATE=$v -c finc_mfma.hip -o ../../ablate_build/mfma_$v.o &
 done
 wait
 for v in 0 1 2 3; do

@@ -3,7 +3,8 @@
 It re-enacts, step by step and lane by lane, the schedule of `finc_wave_kernel`
 for ONE (image, group) problem in canonical orientation: the skewed row-per-lane
 wavefront, the z / x LDS rings with their 4-step I/O cadence, the DPP row_shr
-neighbour exchange, the band hand-over FIFO, the D-layout -> operand packing and
+neighbour exchange, the band hand-over FIFO, the accumulator -> operand packing (16-row
+tiles as they are, 4-row blocks through the permlane transpose-reduce) and
 the fragment layout produced by `pack_kernel`.  The MFMA itself is modelled as
 an exact fp64 matrix product, so any disagreement with the oracle is a schedule
 or indexing bug, not rounding.  It exists so that the kernel's bookkeeping can
@@ -15,28 +16,25 @@ LANES = 64
 
 
 def cfg(CQP, KH, KW, fwd):
-    MT = (CQP + 15) // 16
+    MTB, NSM = CQP // 16, (CQP % 16) // 4   # 16-row tiles (16x16x4) + 4-row blocks (4x4x1, 16 blocks)
+    MT = MTB + NSM
     NKZ = CQP // 4
-    LASTV = (CQP - 16 * (MT - 1)) // 4
-    PACK = LASTV <= 2
-    NKD = 4 * (MT - 1) + 2 if PACK else 4 * MT
+    NKD = CQP // 4
     NK = NKZ if fwd else NKD
-    return dict(MT=MT, NKZ=NKZ, PACK=PACK, NKD=NKD, NK=NK)
+    return dict(MT=MT, MTB=MTB, NSM=NSM, NKZ=NKZ, NKD=NKD, NK=NK)
 
 
-def chan_d(MT, PACK, j, q):
-    full = 4 * (MT - 1) if PACK else 4 * MT
-    if j < full:
+def chan_d(MTB, j, q):
+    if j < 4 * MTB:
         return 16 * (j >> 2) + 4 * q + (j & 3)
-    jj = j - full
-    return 16 * (MT - 1) + (4 * q + 2 * jj if q < 2 else 4 * (q - 2) + 2 * jj + 1)
+    return 16 * MTB + 4 * (j - 4 * MTB) + q
 
 
 def pack_fragments(wc, CQP, fwd):
     """pack_kernel: returns {('z', j, mt) | ((a,b), j, mt): array[64]} in fp64."""
     Cq, _, KH, KW = wc.shape
     c = cfg(CQP, KH, KW, fwd)
-    MT, NKZ, NK = c["MT"], c["NKZ"], c["NK"]
+    MT, MTB, NKZ, NK = c["MT"], c["MTB"], c["NKZ"], c["NK"]
     w = wc.astype(np.float64)
     L = w[:, :, KH - 1, KW - 1]
     Linv = np.linalg.inv(L) if not fwd else None
@@ -48,7 +46,8 @@ def pack_fragments(wc, CQP, fwd):
                 v = np.zeros(LANES)
                 for lane in range(LANES):
                     q, i = lane >> 4, lane & 15
-                    row, col = 16 * mt + i, colfn(j, q)
+                    row = 16 * mt + i if mt < MTB else 16 * MTB + 4 * (mt - MTB) + (i & 3)
+                    col = colfn(j, q)
                     if row < Cq and col < Cq:
                         v[lane] = mat[row, col]
                 frags[(key, j, mt)] = v
@@ -62,7 +61,7 @@ def pack_fragments(wc, CQP, fwd):
         for a in range(KH):
             for b in range(KW):
                 if (a, b) != (0, 0):
-                    frag(-(Linv @ w[:, :, KH - 1 - a, KW - 1 - b]), lambda j, q: chan_d(MT, c["PACK"], j, q), NK, (a, b))
+                    frag(-(Linv @ w[:, :, KH - 1 - a, KW - 1 - b]), lambda j, q: chan_d(MTB, j, q), NK, (a, b))
     return frags
 
 
@@ -89,22 +88,42 @@ def row_shr(n, old, src):
     return out
 
 
-def permlane32_swap_lo(vdst, src):
-    """new vdst of v_permlane32_swap: [vdst lanes 0-31, src lanes 0-31]."""
-    return np.concatenate([vdst[:32], src[:32]])
+def mfma4(a, b, c):
+    """v_mfma_f32_4x4x1_16B_f32: block = lane // 4; D reg i of lane 4*blk + j += A[4*blk + i] * B[4*blk + j]
+    (layout pinned on the hardware by scripts/micro/mfma4x4.hip)."""
+    out = c.copy()
+    for lane in range(LANES):
+        blk = lane // 4
+        for i in range(4):
+            out[lane, i] += a[4 * blk + i] * b[lane]
+    return out
+
+
+def permlane32_swap(vdst, src):
+    """v_permlane32_swap: new vdst = [vdst lanes 0-31, src lanes 0-31], new src = [vdst lanes 32-63, src lanes 32-63]."""
+    return np.concatenate([vdst[:32], src[:32]]), np.concatenate([vdst[32:], src[32:]])
+
+
+def permlane16_swap(vdst, src):
+    """v_permlane16_swap: odd rows of vdst <-> even rows of src (rows of 16 lanes)."""
+    v, s_ = vdst.reshape(4, 16), src.reshape(4, 16)
+    nv = np.stack([v[0], s_[0], v[2], s_[2]]).reshape(64)
+    ns = np.stack([v[1], s_[1], v[3], s_[3]]).reshape(64)
+    return nv, ns
 
 
 def pack_d(acc, c):
-    MT, PACK, NKD = c["MT"], c["PACK"], c["NKD"]
+    MTB, NSM, NKD = c["MTB"], c["NSM"], c["NKD"]
     xpk = np.zeros((NKD, LANES))
-    full = MT - 1 if PACK else MT
-    for mt in range(full):
+    for mt in range(MTB):
         for r in range(4):
             xpk[4 * mt + r] = acc[mt][:, r]
-    if PACK:
-        a = acc[MT - 1]
-        xpk[4 * (MT - 1) + 0] = permlane32_swap_lo(a[:, 0], a[:, 1])
-        xpk[4 * (MT - 1) + 1] = permlane32_swap_lo(a[:, 2], a[:, 3])
+    for sb in range(NSM):
+        a = acc[MTB + sb]
+        a0, a1 = permlane32_swap(a[:, 0], a[:, 2])
+        b0, b1 = permlane32_swap(a[:, 1], a[:, 3])
+        c0, c1 = permlane16_swap(a0 + a1, b0 + b1)
+        xpk[4 * MTB + sb] = c0 + c1
     return xpk
 
 
@@ -114,7 +133,7 @@ def run(inp, wc, fwd=False):
     KH, KW = wc.shape[2:]
     CQP = (CQ + 3) // 4 * 4
     c = cfg(CQP, KH, KW, fwd)
-    MT, NKZ, NKD, NK = c["MT"], c["NKZ"], c["NKD"], c["NK"]
+    MT, MTB, NKZ, NKD, NK = c["MT"], c["MTB"], c["NKZ"], c["NKD"], c["NK"]
     assert W % 4 == 0
     P = min(16, W)
     assert P >= KH - 1
@@ -205,7 +224,7 @@ def run(inp, wc, fwd=False):
             if st["fire"][lane]:
                 if st["ok"][lane]:
                     for j in range(NKD):
-                        ch = chan_d(MT, c["PACK"], j, q[lane])
+                        ch = chan_d(MTB, j, q[lane])
                         if ch < CQ:
                             for k in range(4):
                                 if SEC:
@@ -257,7 +276,7 @@ def run(inp, wc, fwd=False):
                 DL[a, 0] = sn
 
     def mm(key, j, mt, b, acc):
-        return mfma(fr[(key, j, mt)], b, acc)
+        return (mfma if mt < MTB else mfma4)(fr[(key, j, mt)], b, acc)
 
     if SEC:
         io_land(); io_issue(); io_land(); io_issue()
