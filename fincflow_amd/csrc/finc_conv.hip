@@ -15,7 +15,7 @@
 //     (tap, j, mt), lane (q,i) = W[16mt+i][4j+q]).
 //
 // grad_input of this conv is the same operator on the H- and W-flipped image with in/out channels transposed
-// (DESIGN.md 3.3), so finc_backward_f32 calls this kernel with `transpose` fragments and orient ^ 3 per group.
+// (DESIGN.md 3.2), so finc_backward_f32 calls this kernel with `transpose` fragments and orient ^ 3 per group.
 // Replaces F.pad + cuDNN conv (layers/conv.py:102-107) x4 + chunk/cat (fastflow.py:31-50).
 #include "finc_common.h"
 #include "finc_tile.h"

@@ -12,13 +12,14 @@
 //     visitation order (cinc_cuda_kernel_level2.cu:49-56) restricted to a band
 //     of P rows, with the bands chained back to back so the pipeline never
 //     drains.
-//   * per step the wave evaluates, with v_mfma_f32_16x16x4_f32,
+//   * per step the wave evaluates, with v_mfma_f32_16x16x4_f32 for every full 16-channel tile of the output and
+//     v_mfma_f32_4x4x1_16B_f32 for every remaining 4-channel block (finc_tile.h),
 //         x_new[Cq x 16px] = Linv * z  -  sum_{(a,b)!=(0,0)} (Linv * W_ab) * x[(h-a, w-b)]
 //     where L = W_00 is the unit-lower-triangular corner tap.  Folding Linv
 //     into the filter bank (finc_mfma_pack, fp64) removes the sequential
 //     in-pixel channel substitution of the reference (the `kc < c` terms of
 //     cinc_cuda_kernel_level2.cu:64-69) from the critical path.
-//   * ALL filter fragments live in VGPRs for the whole kernel (108 registers
+//   * ALL filter fragments live in AGPRs for the whole kernel (162 registers
 //     at Cq=24, 3x3).  The MFMA D layout (lane (q,p), reg r -> channel 4q+r,
 //     pixel p) is directly a B operand of the next step once the K order is
 //     permuted to match, so solved pixels never leave registers on the
