@@ -233,6 +233,7 @@ __global__ __launch_bounds__(64 * NW) void finc_wave_kernel(const float *__restr
 #pragma unroll
         for (int f = 0; f < NFRAG; ++f) {
             int gi;
+            if (NW == 1 && f < NKZ * MT && finc_zterm_is_zero(C::MTB, f / MT, f % MT)) { af[f] = 0.f; continue; }
             if (f < NKZ * MT) {
                 gi = (wv * NKZ + f / MT) * MT + f % MT;
             } else {
@@ -245,7 +246,10 @@ __global__ __launch_bounds__(64 * NW) void finc_wave_kernel(const float *__restr
         // VGPR and there are only 256 of each.  Pin the fragments to AGPRs so the allocator does not shuffle
         // operands between the two files (v_accvgpr_* moves are VALU issue that f32 MFMAs do not hide).
 #pragma unroll
-        for (int f = 0; f < NFRAG; ++f) asm volatile("" : "+a"(af[f]));
+        for (int f = 0; f < NFRAG; ++f) {
+            if (NW == 1 && f < NKZ * MT && finc_zterm_is_zero(C::MTB, f / MT, f % MT)) continue;   // never read
+            asm volatile("" : "+a"(af[f]));
+        }
     }
     for (int i = lane; i < fifo_n + SS + 64; i += 64) fifo[i] = 0.f;
 
@@ -664,8 +668,10 @@ __global__ __launch_bounds__(64 * NW) void finc_wave_kernel(const float *__restr
 #pragma unroll
             for (int j = 0; j < NKZ; ++j)
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
+                for (int mt = 0; mt < MT; ++mt) {
+                    if (NW == 1 && finc_zterm_is_zero(C::MTB, j, mt)) continue;   // Linv is lower triangular
                     finc_mma<C::MTB>(accn[mt], mt, af[FZ + j * MT + mt], zv[j]);
+                }
             FINC_STAMP_AT(1);                           // segment 1: z-term
             if constexpr (NW > 1) {
                 // K-split exchange: acc holds this wave's share of ALL output registers.  Ship the registers other waves
@@ -784,8 +790,10 @@ __global__ __launch_bounds__(64 * NW) void finc_wave_kernel(const float *__restr
                 const float v = zrd[j * C::ZSLOTS * 64];
                 const float zvj = started ? v : 0.f;
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
+                for (int mt = 0; mt < MT; ++mt) {
+                    if (NW == 1 && finc_zterm_is_zero(C::MTB, j, mt)) continue;
                     finc_mma<C::MTB>(acc[mt], mt, af[FZ + j * MT + mt], zvj);
+                }
             }
             ++tp1; ++tm;
             ++nslot; zrd += 64;

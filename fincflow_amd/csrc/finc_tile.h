@@ -42,6 +42,13 @@ __device__ inline float finc_block_reduce(const finc_v4f &acc)
     return __builtin_bit_cast(float, c0) + __builtin_bit_cast(float, c1);
 }
 
+// Linv (the z-term) is lower triangular: its fragment (k-step j, tile mt) is all zero when every column 4j..4j+3 lies
+// right of every row of the tile, and the MFMA can be skipped
+__host__ __device__ constexpr bool finc_zterm_is_zero(int MTB, int j, int mt)
+{
+    return mt < MTB ? 4 * j > 16 * mt + 15 : 4 * j > 16 * MTB + 4 * (mt - MTB) + 3;
+}
+
 // row of the weight matrix held by lane i (0..15) of fragment tile mt
 __host__ __device__ inline int finc_tile_row(int MTB, int mt, int i)
 {

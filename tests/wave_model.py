@@ -30,6 +30,11 @@ def chan_d(MTB, j, q):
     return 16 * MTB + 4 * (j - 4 * MTB) + q
 
 
+def zterm_is_zero(MTB, j, mt):
+    """finc_tile.h finc_zterm_is_zero: every column 4j..4j+3 lies right of every row of tile mt."""
+    return 4 * j > 16 * mt + 15 if mt < MTB else 4 * j > 16 * MTB + 4 * (mt - MTB) + 3
+
+
 def pack_fragments(wc, CQP, fwd):
     """pack_kernel: returns {('z', j, mt) | ((a,b), j, mt): array[64]} in fp64."""
     Cq, _, KH, KW = wc.shape
@@ -306,6 +311,9 @@ def run(inp, wc, fwd=False):
             accn = [np.zeros((LANES, 4)) for _ in range(MT)]
             for j in range(NKZ):
                 for mt in range(MT):
+                    if zterm_is_zero(MTB, j, mt):      # Linv is lower triangular: the kernel skips these MFMAs
+                        assert not fr[("z", j, mt)].any()
+                        continue
                     accn[mt] = mm("z", j, mt, zv[j], accn[mt])
             for a in range(KH):
                 for b in range(KW):
