@@ -256,15 +256,20 @@ __global__ __launch_bounds__(64 * NW) void finc_wave_kernel(const float *__restr
     // ---- per-lane HBM stream state -------------------------------------------------------------
     const int fl4 = -((p + 3) >> 2);          // floor(-p/4): first 4-column group this lane ever needs
     // SEC (W % 8 == 0): HBM is touched in aligned 32-byte pieces (two 4-column groups), the write atom of the
-    // fabric: a lane loads 32 bytes every other window and lands one half per window; it holds an even group
-    // one window and stores it together with the odd one.  (16-byte pieces cost 4 fetches per 64-byte sector
-    // and a 32-byte partial write per store: FETCH_SIZE 4x, WRITE_SIZE 2x, and the fabric saturates at B=256.)
+    // fabric.  (16-byte pieces cost 4 fetches per 64-byte sector and a 32-byte partial write per store: FETCH_SIZE
+    // 4x, WRITE_SIZE 2x, and the fabric saturates at B=256.)  Loads: every other window ("event", step 3 of the
+    // window, one parity class of lanes per window) a lane lands BOTH groups of the piece it issued two windows ago
+    // and issues the next one at once: that is the one step at which the ring slots of both groups are free (the
+    // first group's until step +4, the second's from step -1), and it gives every load 8 steps (~15 us) to come back.
+    // Stores: a lane holds the even group one window and stores it together with the odd one.
     constexpr int NPC = SEC ? 2 : 1;          // 16-byte pieces held per channel
     // first chunk this lane loads: window -3 if fl4 is even, else -2; chunk index floor(fl4/2) rounded up for odd
     int lcol = SEC ? 8 * ((fl4 - (fl4 & 1)) / 2 + (fl4 & 1)) : 4 * fl4, lrow = p;
     int lph = fl4 & 1;                        // SEC: window parity; this lane loads when it is 0
     int scol = 4 * (fl4 - 2), srow = p;       // next group to store
-    int lslot = SEC ? ((4 * (fl4 - 1)) % 12 + 12) % 12 : ((4 * fl4) % 12 + 12) % 12; // z-ring slot of the next landing
+    // z-ring slot of the next landing.  SEC: the first event (window -4 for an even fl4, -3 for an odd one) "lands" the
+    // never-loaded piece before the first real one, groups (e + 2 + fl4, +1) of event window e
+    int lslot = SEC ? ((4 * (fl4 - 2 + (fl4 & 1))) % 12 + 12) % 12 : ((4 * fl4) % 12 + 12) % 12;
     int sph = fl4 & 1;                        // SEC: parity of the group read next (odd: the pair is complete)
     unsigned coff[NKD];                       // per-lane channel byte offsets of the registers this wave stores
 #pragma unroll
@@ -299,61 +304,69 @@ __global__ __launch_bounds__(64 * NW) void finc_wave_kernel(const float *__restr
     const int lwrap = (fh ? -P : P) * W * 4 - (fw ? -1 : 1) * W * 4;         // extra bytes when the chunk wraps to row+P
     int loff = ((fh ? H - 1 - lrow : lrow) * W + (fw ? W - (SEC ? 8 : 4) - lcol : lcol)) * 4 + (4 * wv * NKZ + q) * HW * 4;
     const unsigned zlast = (4 * (wv * NKZ + NKZ - 1) + q) < CQ ? 0u : OFF_BAD_CHANNEL;  // only the last k-step can hold a padded channel
-    // Memory instructions are spread over the window, a few per step: 12 strided stores (or loads) issued back to back
-    // overrun the CU's memory queues and the wave stalls for most of a microsecond (scripts/micro/vmem_issue.hip).
-    auto io_issue = [&](int j0, int j1, bool advance) {
+    auto io_issue = [&](int j0, int j1, bool advance) {     // 16-byte pieces (W % 8 != 0): one group per window
         const bool ok = lcol >= 0 && lrow < H && p < P;
         const unsigned vb = ok ? (unsigned)loff : OFF_INVALID;
-        if constexpr (SEC) {
-            if (lph == 0) {                   // one parity class per window (divergent: other lanes keep their data)
-#pragma unroll
-                for (int j = 0; j < NKZ; ++j) {
-                    if (j < j0 || j >= j1) continue;
-                    const unsigned vo = j == NKZ - 1 ? vb + zlast : vb;
-                    zb[j][0] = __builtin_amdgcn_raw_buffer_load_b128(rin, vo, j * 16 * HW, 0);
-                    zb[j][1] = __builtin_amdgcn_raw_buffer_load_b128(rin, vo + 16u, j * 16 * HW, 0);
-                }
-                if (advance) {
-                    lcol += 8;
-                    loff += lstep;
-                    if (lcol == W) { lcol = 0; lrow += P; loff += lwrap; }
-                }
-            }
-            if (advance) lph ^= 1;
-        } else {
-#pragma unroll
-            for (int j = 0; j < NKZ; ++j) {
-                if (j < j0 || j >= j1) continue;
-                zb[j][0] = __builtin_amdgcn_raw_buffer_load_b128(rin, j == NKZ - 1 ? vb + zlast : vb, j * 16 * HW, 0);
-            }
-            if (advance) {
-                lcol += 4;
-                loff += lstep;
-                if (lcol == W) { lcol = 0; lrow += P; loff += lwrap; }
-            }
-        }
-    };
-    auto io_land = [&]() {
-        float *b0 = zring + (lslot + k0) * 64 + lane, *b1 = zring + (lslot + k1) * 64 + lane;
-        float *b2 = zring + (lslot + k2) * 64 + lane, *b3 = zring + (lslot + k3) * 64 + lane;
-        // SEC: the group due now is canonical group (lph ^ 1) of the pair held = memory piece (fw ? lph : lph ^ 1)
-        const bool hi = SEC && ((fw ? lph : (lph ^ 1)) != 0);
 #pragma unroll
         for (int j = 0; j < NKZ; ++j) {
-            unsigned v0, v1, v2, v3;
-            if constexpr (SEC) {
-                const unsigned a0 = zb[j][0].x, a1 = zb[j][0].y, a2 = zb[j][0].z, a3 = zb[j][0].w;
-                const unsigned c0 = zb[j][1].x, c1 = zb[j][1].y, c2 = zb[j][1].z, c3 = zb[j][1].w;
-                v0 = hi ? c0 : a0; v1 = hi ? c1 : a1; v2 = hi ? c2 : a2; v3 = hi ? c3 : a3;
-            } else {
-                v0 = zb[j][0].x; v1 = zb[j][0].y; v2 = zb[j][0].z; v3 = zb[j][0].w;
-            }
+            if (j < j0 || j >= j1) continue;
+            zb[j][0] = __builtin_amdgcn_raw_buffer_load_b128(rin, j == NKZ - 1 ? vb + zlast : vb, j * 16 * HW, 0);
+        }
+        if (advance) {
+            lcol += 4;
+            loff += lstep;
+            if (lcol == W) { lcol = 0; lrow += P; loff += lwrap; }
+        }
+    };
+    auto io_land = [&]() {                                   // 16-byte pieces
+        float *b0 = zring + (lslot + k0) * 64 + lane, *b1 = zring + (lslot + k1) * 64 + lane;
+        float *b2 = zring + (lslot + k2) * 64 + lane, *b3 = zring + (lslot + k3) * 64 + lane;
+#pragma unroll
+        for (int j = 0; j < NKZ; ++j) {
+            const unsigned v0 = zb[j][0].x, v1 = zb[j][0].y, v2 = zb[j][0].z, v3 = zb[j][0].w;
             b0[j * C::ZSLOTS * 64] = __builtin_bit_cast(float, v0);
             b1[j * C::ZSLOTS * 64] = __builtin_bit_cast(float, v1);
             b2[j * C::ZSLOTS * 64] = __builtin_bit_cast(float, v2);
             b3[j * C::ZSLOTS * 64] = __builtin_bit_cast(float, v3);
         }
         lslot = lslot == 8 ? 0 : lslot + 4;
+    };
+    auto io_event = [&]() {                   // SEC only
+        if constexpr (!SEC) return;
+        constexpr int HI = NPC - 1;           // (== 1; spelled so that the 16-byte instantiations still compile)
+        if (lph == 0) {                       // this window's parity class (divergent: the other lanes' loads stay in flight)
+            // memory piece 0 / 1 of the pair = canonical group first / second, or second / first when W-flipped
+            float *ga = zring + lslot * 64 + lane;
+            float *gb = zring + (lslot == 8 ? 0 : lslot + 4) * 64 + lane;
+            float *p0 = fw ? gb : ga, *p1 = fw ? ga : gb;
+#pragma unroll
+            for (int j = 0; j < NKZ; ++j) {
+                const unsigned a0 = zb[j][0].x, a1 = zb[j][0].y, a2 = zb[j][0].z, a3 = zb[j][0].w;
+                const unsigned c0 = zb[j][HI].x, c1 = zb[j][HI].y, c2 = zb[j][HI].z, c3 = zb[j][HI].w;
+                float *q0 = p0 + j * C::ZSLOTS * 64, *q1 = p1 + j * C::ZSLOTS * 64;
+                q0[k0 * 64] = __builtin_bit_cast(float, a0);
+                q0[k1 * 64] = __builtin_bit_cast(float, a1);
+                q0[k2 * 64] = __builtin_bit_cast(float, a2);
+                q0[k3 * 64] = __builtin_bit_cast(float, a3);
+                q1[k0 * 64] = __builtin_bit_cast(float, c0);
+                q1[k1 * 64] = __builtin_bit_cast(float, c1);
+                q1[k2 * 64] = __builtin_bit_cast(float, c2);
+                q1[k3 * 64] = __builtin_bit_cast(float, c3);
+            }
+            lslot = lslot >= 4 ? lslot - 4 : lslot + 8;   // + 8 mod 12
+            const bool ok = lcol >= 0 && lrow < H && p < P;
+            const unsigned vb = ok ? (unsigned)loff : OFF_INVALID;
+#pragma unroll
+            for (int j = 0; j < NKZ; ++j) {
+                const unsigned vo = j == NKZ - 1 ? vb + zlast : vb;
+                zb[j][0] = __builtin_amdgcn_raw_buffer_load_b128(rin, vo, j * 16 * HW, 0);
+                zb[j][HI] = __builtin_amdgcn_raw_buffer_load_b128(rin, vo + 16u, j * 16 * HW, 0);
+            }
+            lcol += 8;
+            loff += lstep;
+            if (lcol == W) { lcol = 0; lrow += P; loff += lwrap; }
+        }
+        lph ^= 1;
     };
     auto io_sread = [&]() {
         const bool ok = scol >= 0 && srow < H && p < P;
@@ -417,12 +430,13 @@ __global__ __launch_bounds__(64 * NW) void finc_wave_kernel(const float *__restr
         if constexpr (PH == 1 && !(AB & 2)) io_swrite(0, S1);
         if constexpr (PH == 2) {
             if constexpr (!(AB & 2)) io_swrite(S1, S2);
-            if constexpr (!(AB & 4)) io_land();
-            if constexpr (!(AB & 1)) io_issue(0, L1, false);
+            if constexpr (!SEC && !(AB & 4)) io_land();
+            if constexpr (!SEC && !(AB & 1)) io_issue(0, L1, false);
         }
         if constexpr (PH == 3) {
             if constexpr (!(AB & 2)) io_swrite(S2, NKD);
-            if constexpr (!(AB & 1)) io_issue(L1, NKZ, true);
+            if constexpr (!SEC && !(AB & 1)) io_issue(L1, NKZ, true);
+            if constexpr (SEC && !(AB & 5)) io_event();
         }
     };
     auto io_swrite_all = [&]() { io_swrite(0, NKD); };
@@ -539,10 +553,9 @@ __global__ __launch_bounds__(64 * NW) void finc_wave_kernel(const float *__restr
 
     // pre-loop = the HBM side of the two windows before the first computed one
     if constexpr (SEC) {
-        io_land();   // window -3 (lands only zeros)
-        io_issue_all();
-        io_land();   // window -2: the first group lands
-        io_issue_all();
+        io_event();  // window -4: even-fl4 lanes issue their first piece
+        io_event();  // window -3: odd-fl4 lanes
+        io_event();  // window -2: the first pieces land, the second ones leave
     } else {
         io_issue_all();
         io_land();
@@ -774,8 +787,12 @@ __global__ __launch_bounds__(64 * NW) void finc_wave_kernel(const float *__restr
         // and the z-term of lane 0's first pixel (phase B of step -1) matter, so it runs without the other 3.9 steps.
         io_sread();
         io_swrite_all();
-        io_land();
-        io_issue_all();
+        if constexpr (SEC) {
+            io_event();
+        } else {
+            io_land();
+            io_issue_all();
+        }
 #pragma unroll
         for (int k = 0; k < 3; ++k) {                  // steps -4, -3, -2: bookkeeping only (the FIFO ring is zero)
             ++tp1; ++tm;

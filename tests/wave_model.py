@@ -160,41 +160,22 @@ def run(inp, wc, fwd=False):
     lrow = p.copy()
     lph = fl4 & 1
     scol, srow = 4 * (fl4 - 2), p.copy()
-    lslot = ((4 * (fl4 - 1)) % 12 + 12) % 12 if SEC else ((4 * fl4) % 12 + 12) % 12
+    lslot = ((4 * (fl4 - 2 + (fl4 & 1))) % 12 + 12) % 12 if SEC else ((4 * fl4) % 12 + 12) % 12
     sslot = (4 * (fl4 - 2)) & 7
     zin = np.zeros((NKZ, 4, LANES))
     zb = np.zeros((NKZ, 2, 4, LANES))     # SEC: [j][piece][element][lane]
     sv = np.zeros((NKD, 4, LANES))
     st = dict(ok=np.zeros(LANES, bool), row=p.copy(), col=p.copy(), fire=np.zeros(LANES, bool))
 
-    def io_land():
+    def io_land():                        # 16-byte pieces (W % 8 != 0)
         nonlocal lslot
-        sg = lph ^ 1
         for j in range(NKZ):
             for k in range(4):
-                val = zb[j, sg, k, lanes] if SEC else zin[j, k]
-                zring[j, lslot + k, lanes] = val
+                zring[j, lslot + k, lanes] = zin[j, k]
         lslot = np.where(lslot == 8, 0, lslot + 4)
 
-    def io_issue():
-        nonlocal lcol, lrow, lph
-        if SEC:
-            for lane in range(LANES):
-                if lph[lane] != 0:
-                    continue
-                ok = lcol[lane] >= 0 and lrow[lane] < H and p[lane] < P
-                for j in range(NKZ):
-                    ch = 4 * j + q[lane]
-                    for m in range(2):
-                        for k in range(4):
-                            zb[j, m, k, lane] = inp[ch, lrow[lane], lcol[lane] + 4 * m + k] if (ok and ch < CQ) else 0.0
-            load = lph == 0
-            lcol = np.where(load, lcol + 8, lcol)
-            wrap = load & (lcol == W)
-            lcol = np.where(wrap, 0, lcol)
-            lrow = np.where(wrap, lrow + P, lrow)
-            lph = lph ^ 1
-            return
+    def io_issue():                       # 16-byte pieces
+        nonlocal lcol, lrow
         for lane in range(LANES):
             ok = lcol[lane] >= 0 and lrow[lane] < H and p[lane] < P
             for j in range(NKZ):
@@ -205,6 +186,31 @@ def run(inp, wc, fwd=False):
         wrap = lcol == W
         lcol = np.where(wrap, 0, lcol)
         lrow = np.where(wrap, lrow + P, lrow)
+
+    def io_event():
+        """SEC: one parity class per window lands BOTH groups of the piece issued two windows ago, then issues the next."""
+        nonlocal lcol, lrow, lph, lslot
+        for lane in range(LANES):
+            if lph[lane] != 0:
+                continue
+            sa = lslot[lane]
+            sb_ = 0 if sa == 8 else sa + 4
+            for j in range(NKZ):
+                for k in range(4):
+                    zring[j, sa + k, lane] = zb[j, 0, k, lane]
+                    zring[j, sb_ + k, lane] = zb[j, 1, k, lane]
+            lslot[lane] = sa - 4 if sa >= 4 else sa + 8
+            ok = lcol[lane] >= 0 and lrow[lane] < H and p[lane] < P
+            for j in range(NKZ):
+                ch = 4 * j + q[lane]
+                for m in range(2):
+                    for k in range(4):
+                        zb[j, m, k, lane] = inp[ch, lrow[lane], lcol[lane] + 4 * m + k] if (ok and ch < CQ) else 0.0
+            lcol[lane] += 8
+            if lcol[lane] == W:
+                lcol[lane] = 0
+                lrow[lane] += P
+        lph = lph ^ 1
 
     sh = np.zeros((NKD, 4, LANES))        # SEC: the even group, held one window
     sph = fl4 & 1
@@ -241,7 +247,10 @@ def run(inp, wc, fwd=False):
                 sh[:, :, lane] = sv[:, :, lane]
 
     def io_phase(ph):
-        [io_sread, io_swrite, io_land, io_issue][ph]()
+        if SEC:
+            [io_sread, io_swrite, lambda: None, io_event][ph]()
+        else:
+            [io_sread, io_swrite, io_land, io_issue][ph]()
 
     R = np.zeros((KH, KW, NK, LANES))
     DL = np.zeros((KH, KH, NK, LANES))
@@ -284,7 +293,7 @@ def run(inp, wc, fwd=False):
         return (mfma if mt < MTB else mfma4)(fr[(key, j, mt)], b, acc)
 
     if SEC:
-        io_land(); io_issue(); io_land(); io_issue()
+        io_event(); io_event(); io_event()       # windows -4, -3, -2
     else:
         io_issue(); io_land(); io_issue()
     xs = (-4 - p) & 7
