@@ -18,6 +18,7 @@ SYMBOLS = [
     "finc_check_invariant_f32", "finc_workspace_bytes", "finc_inverse_algo_for", "finc_forward_algo_for",
     "finc_inverse_f32", "finc_forward_f32", "finc_pack_inverse_weights_f32", "finc_pack_forward_weights_f32",
     "finc_inverse_packed_f32", "finc_forward_packed_f32", "finc_backward_f32", "finc_backward_workspace_bytes",
+    "finc_inverse_workspace_bytes",
 ]
 
 _lib = None
@@ -56,6 +57,8 @@ def lib():
     L.finc_inverse_packed_f32.argtypes = runp
     L.finc_forward_packed_f32.argtypes = runp
     L.finc_backward_workspace_bytes.restype = sz
+    L.finc_inverse_workspace_bytes.restype = sz
+    L.finc_inverse_workspace_bytes.argtypes = [i, i, i, i, i, i, i]
     L.finc_backward_workspace_bytes.argtypes = [i, i, i, i, i, i, i]
     L.finc_backward_f32.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, i, i, u, vp, sz, vp]
     for name in SYMBOLS:

@@ -45,6 +45,9 @@ int finc_launch_backward_generic(const float *gz, const float *x, const float *w
                                  const FincShape &s, hipStream_t st);
 
 // ---- inverse, MFMA wavefront kernel: finc_mfma.hip ----
+// rows x Win floats -> rows x Wout floats (Wout > Win: zero fill on the right; Wout < Win: crop)
+int finc_launch_repitch(const float *in, float *out, long long rows, int Win, int Wout, hipStream_t st);
+
 bool finc_mfma_supported(int Cq, int H, int W, int KH, int KW);
 size_t finc_mfma_packed_bytes(int G, int Cq, int KH, int KW);
 int finc_mfma_pack(const float *wc, void *packed, int G, int Cq, int KH, int KW, hipStream_t st);

@@ -225,3 +225,32 @@ int finc_launch_backward_generic(const float *gz, const float *x, const float *w
     }
     return FINC_OK;
 }
+
+// -----------------------------------------------------------------------------------------------
+// Width padding for the MFMA inverse (finc_abi.hip, FINC_ALGO_AUTO with W % 4 != 0): rows are copied into a buffer
+// whose width is a multiple of 8, zero-filled on the right, and the solved rows are copied back.  Exact: a zero z on
+// ghost columns right of the image never feeds a real pixel of an un-flipped group, and stays an exact zero on the
+// canonical LEFT of a W-flipped group, where it stands for the out-of-image taps the unpadded problem masks.
+// -----------------------------------------------------------------------------------------------
+namespace {
+__global__ void repitch_kernel(const float *__restrict__ in, float *__restrict__ out, long long rows, int Win, int Wout)
+{
+    const long long n = rows * Wout;
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (long long)gridDim.x * blockDim.x) {
+        const long long r = e / Wout;
+        const int w = (int)(e - r * Wout);
+        out[e] = w < Win ? in[r * Win + w] : 0.f;
+    }
+}
+} // namespace
+
+int finc_launch_repitch(const float *in, float *out, long long rows, int Win, int Wout, hipStream_t st)
+{
+    const long long n = rows * Wout;
+    if (n == 0) return FINC_OK;
+    long long blocks = (n + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(repitch_kernel, dim3((unsigned)blocks), dim3(256), 0, st, in, out, rows, Win, Wout);
+    FINC_CHECK_LAUNCH();
+    return FINC_OK;
+}

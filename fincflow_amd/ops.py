@@ -89,7 +89,10 @@ def _run(fn_name, act, w_canon, G, orient, algo, out):
     if act.numel() == 0:
         return out
     L = _lib.lib()
-    nbytes = L.finc_workspace_bytes(G, Cq, KH, KW)
+    if fn_name == "finc_inverse_f32":      # room for the zero-padded copy an odd width is solved on
+        nbytes = L.finc_inverse_workspace_bytes(B, G, Cq, H, W, KH, KW)
+    else:
+        nbytes = L.finc_workspace_bytes(G, Cq, KH, KW)
     with torch.cuda.device(act.device):
         ws = _workspace(act.device, nbytes)
         st = getattr(L, fn_name)(act.data_ptr(), w_canon.data_ptr(), out.data_ptr(), B, G, Cq, H, W, KH, KW, orient,

@@ -82,6 +82,15 @@ int finc_check_invariant_f32(const float *w_canon, int G, int Cq, int KH, int KW
 /* Scratch the AUTO/MFMA algos need (packed filter fragments); 0 is never returned. */
 size_t finc_workspace_bytes(int G, int Cq, int KH, int KW);
 
+/*
+ * Workspace finc_inverse_f32 can use for this problem: finc_workspace_bytes(), plus -- when W is not a multiple
+ * of 4, which the MFMA inverse cannot stream -- room for a zero-padded copy of z and of x (row pitch rounded up to
+ * 8 floats).  With at least this much workspace FINC_ALGO_AUTO solves the padded copy (exact, two extra copies);
+ * with less it falls back to FINC_ALGO_STRICT for such widths.  The reference has no counterpart: its kernel
+ * takes any width (cinc_cuda_kernel_level2.cu:49-56).
+ */
+size_t finc_inverse_workspace_bytes(int B, int G, int Cq, int H, int W, int KH, int KW);
+
 /* Which algo FINC_ALGO_AUTO resolves to for this shape (FINC_ALGO_STRICT or FINC_ALGO_MFMA). */
 int finc_inverse_algo_for(int Cq, int H, int W, int KH, int KW);
 int finc_forward_algo_for(int Cq, int H, int W, int KH, int KW);

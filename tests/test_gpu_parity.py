@@ -439,3 +439,44 @@ def test_load_reference_checkpoint_on_device(dev, tmp_path):
     bad["module.0.conv_bl.conv.weight"][1, 1, 0, -1] = 0.5        # BL stores the corner tap at [.., 0, -1]
     with pytest.raises(RuntimeError):
         load_reference_checkpoint(model, bad)
+
+
+@pytest.mark.parametrize("shape", [(3, 16, 14, 14, 3), (2, 48, 9, 30, 3), (2, 96, 20, 27, 3), (1, 16, 7, 7, 3), (2, 16, 6, 5, 5),
+                                   (2, 64, 5, 13, 2), (1, 8, 3, 3, 3)])
+def test_odd_widths_run_on_the_padded_mfma_path(shape, dev):
+    """W % 4 != 0 (MNIST 14x14 / 7x7, crops): FINC_ALGO_AUTO solves a zero-padded copy on the MFMA kernel when the
+    workspace has room (finc_inverse_workspace_bytes) and the strict kernel otherwise; both match the oracle, in every
+    orientation (the W-flipped groups see the padding on their canonical LEFT)."""
+    import ctypes
+    from fincflow_amd import FastFlowUnit, _lib, ops
+    B, C, H, W, K = shape
+    L = _lib.lib()
+    Cq = C // 4
+    base = L.finc_workspace_bytes(4, Cq, K, K)
+    need = L.finc_inverse_workspace_bytes(B, 4, Cq, H, W, K, K)
+    assert L.finc_inverse_algo_for(Cq, H, W, K, K) == _lib.ALGO["strict"]
+    assert need >= base + 2 * B * C * H * ((W + 7) // 8 * 8) * 4, "this shape should have a padded MFMA path"
+    rng = np.random.default_rng(sum(shape))
+    ws = oracle.make_stored_weights(4, Cq, K, K, seed=sum(shape), std=0.05 if K < 5 else 0.02)
+    wco = oracle.canonicalize(ws, 4, ORIENT_FASTFLOW)
+    x = rng.standard_normal((B, C, H, W)).astype(np.float32)
+    z = oracle.forward_f32(x, wco)
+    ref = oracle.inverse_via_f64(z, wco)
+    wc = canon(ws, 4, ORIENT_FASTFLOW, dev)
+    zt = t(z, dev)
+    auto = ops.finc_inverse(zt, wc, algo="auto")
+    assert rel_err(auto.cpu().numpy(), ref) <= TOL
+    # the same call with only the small workspace: strict fallback, bit-exact with the fp32 reference order
+    small = torch.empty(base, dtype=torch.uint8, device=dev)
+    out = torch.empty_like(zt)
+    st = L.finc_inverse_f32(zt.data_ptr(), wc.data_ptr(), out.data_ptr(), B, 4, Cq, H, W, K, K, ORIENT_FASTFLOW,
+                            _lib.ALGO["auto"], small.data_ptr(), small.numel(), torch.cuda.current_stream().cuda_stream)
+    assert st == 0
+    assert np.array_equal(out.cpu().numpy(), oracle.inverse_f32(z, wco))
+    # and through the module (cached weights -> falls through to the same ABI call)
+    unit = FastFlowUnit(C, C, K).to(dev)
+    with torch.no_grad():
+        for m, o in zip((unit.conv_tl, unit.conv_tr, unit.conv_bl, unit.conv_br), range(4)):
+            m.conv.weight.copy_(torch.from_numpy(ws[o * Cq:(o + 1) * Cq]))
+    assert rel_err(unit.reverse(zt).cpu().numpy(), ref) <= TOL
+    assert rel_err(unit(t(x, dev))[0].detach().cpu().numpy(), z) <= TOL
