@@ -61,7 +61,7 @@ struct Cfg {
     // NW > 1 ("K-split"): wave w of the workgroup owns k-steps [w*NKZ, (w+1)*NKZ) of the z-term and
     // [w*NKD, (w+1)*NKD) of every tap, i.e. 1/NW of the fragments; the output registers it finalises after the
     // per-step exchange are exactly the D registers that are its own operands.
-    static_assert(NW == 1 || (NSM == 0 && NKZT % NW == 0 && NKDT % NW == 0), "K-split needs full tiles and divisibility");
+    static_assert(NW == 1 || (NKZT % NW == 0 && NKDT % NW == 0), "K-split must divide the k-steps and the output registers");
     static constexpr int NKZ = NKZT / NW;                 // per wave
     static constexpr int NKD = NKDT / NW;
     static constexpr int NK = NKD;                        // k-steps per neighbour tap (per wave)
@@ -689,14 +689,10 @@ __global__ __launch_bounds__(64 * NW) void finc_wave_kernel(const float *__restr
             if constexpr (NW > 1) {
                 // K-split exchange: acc holds this wave's share of ALL output registers.  Ship the registers other waves
                 // own, keep ours; after the barrier post1 adds the NW-1 shares it received.
-                float vv[MT * 4];
+                float vv[C::NKDT];                     // partial sums in operand order (4-row blocks already reduced)
+                pack_d<C>(acc, vv);
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    const float v0 = acc[mt].x, v1 = acc[mt].y, v2 = acc[mt].z, v3 = acc[mt].w;
-                    vv[4 * mt + 0] = v0; vv[4 * mt + 1] = v1; vv[4 * mt + 2] = v2; vv[4 * mt + 3] = v3;
-                }
-#pragma unroll
-                for (int d = 0; d < MT * 4; ++d) {
+                for (int d = 0; d < C::NKDT; ++d) {
                     const int dst = d / NKD;
                     if (dst != wv) xch[((dst * NW + wv) * NKD + d % NKD) * 64 + lane] = vv[d];
                     else xown[d % NKD] = vv[d];
