@@ -271,12 +271,15 @@ __global__ __launch_bounds__(64 * NW) void finc_wave_kernel(const float *__restr
     // never-loaded piece before the first real one, groups (e + 2 + fl4, +1) of event window e
     int lslot = SEC ? ((4 * (fl4 - 2 + (fl4 & 1))) % 12 + 12) % 12 : ((4 * fl4) % 12 + 12) % 12;
     int sph = fl4 & 1;                        // SEC: parity of the group read next (odd: the pair is complete)
-    unsigned coff[NKD];                       // per-lane channel byte offsets of the registers this wave stores
+    // Store offsets: lane part (column/row of the piece + the lane row's share of the channel) in the VGPR offset, the
+    // uniform share of the channel and the piece half in the instruction's scalar offset.  Register jj of a solved pixel
+    // holds channel 16(jj>>2) + 4q + (jj&3) (a 16-row tile's D register) or 16*MTB + 4(jj-4MTB) + q (a reduced 4-row
+    // block): two lane parts.  Channels >= CQ exist only in the last group of four, so only the registers that can hold
+    // one carry a mask (validity must sit in the VGPR offset: the scalar offset is not range checked).
+    const unsigned lane_t = 4u * (unsigned)q * HW * 4u, lane_b = (unsigned)q * HW * 4u;
+    unsigned cmask[NKD];
 #pragma unroll
-    for (int j = 0; j < NKD; ++j) {
-        const int c = chan_d(C::MTB, wv * NKD + j, q);
-        coff[j] = c < CQ ? (unsigned)c * HW * 4u : OFF_BAD_CHANNEL;
-    }
+    for (int j = 0; j < NKD; ++j) cmask[j] = chan_d(C::MTB, wv * NKD + j, q) < CQ ? 0u : OFF_BAD_CHANNEL;
     v4u zb[NKZ][NPC];                         // in flight HBM -> z ring (raw: nothing may touch it until it lands)
 #pragma unroll
     for (int j = 0; j < NKZ; ++j)
@@ -394,11 +397,22 @@ __global__ __launch_bounds__(64 * NW) void finc_wave_kernel(const float *__restr
     auto io_swrite = [&](int j0, int j1) {
         // every lane issues; lanes whose pair is not complete (or that are off the image) drop by offset
         const unsigned base = st_fire ? st_off : OFF_INVALID;
-        const unsigned o_even = fw ? 16u : 0u, o_odd = fw ? 0u : 16u; // held (even) group / fresh (odd) group
+        const unsigned vt = base == OFF_INVALID ? OFF_INVALID : base + lane_t;
+        const unsigned vb = base == OFF_INVALID ? OFF_INVALID : base + lane_b;
+        // (readfirstlane: tells the compiler these are wave-uniform, or it wraps every store in a waterfall loop)
+        const int o_even = __builtin_amdgcn_readfirstlane(fw ? 16 : 0);   // held (even) group / fresh (odd) group
+        const int o_odd = 16 - o_even;
+        const int cpad = C::CQP - CQ;                           // 0..3 padded channels (uniform)
 #pragma unroll
         for (int j = 0; j < NKD; ++j) {
             if (j < j0 || j >= j1) continue;
-            const unsigned vo = base == OFF_INVALID ? OFF_INVALID : base + coff[j];
+            const int jj = wv * NKD + j;
+            const bool tile = jj < 4 * C::MTB;
+            const int uni = __builtin_amdgcn_readfirstlane((tile ? 16 * (jj >> 2) + (jj & 3) : 16 * C::MTB + 4 * (jj - 4 * C::MTB)) * HW * 4);
+            unsigned vo = tile ? vt : vb;
+            // only a register of the last channel group can hold a padded channel
+            const bool last_group = tile ? (C::NSM == 0 && (jj >> 2) == C::MTB - 1) : jj == C::NKDT - 1;
+            if (last_group && cpad != 0) vo += cmask[j];
             v4u v;
             v.x = __builtin_bit_cast(unsigned, sv[j][0]);
             v.y = __builtin_bit_cast(unsigned, sv[j][1]);
@@ -410,12 +424,12 @@ __global__ __launch_bounds__(64 * NW) void finc_wave_kernel(const float *__restr
                 h.y = __builtin_bit_cast(unsigned, sh[j][1]);
                 h.z = __builtin_bit_cast(unsigned, sh[j][2]);
                 h.w = __builtin_bit_cast(unsigned, sh[j][3]);
-                __builtin_amdgcn_raw_buffer_store_b128(h, rout, vo + o_even, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(v, rout, vo + o_odd, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(h, rout, vo, uni + o_even, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(v, rout, vo, uni + o_odd, 0);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) sh[j][k] = st_fire ? sh[j][k] : sv[j][k]; // even group: hold it
             } else {
-                __builtin_amdgcn_raw_buffer_store_b128(v, rout, vo, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(v, rout, vo, uni, 0);
             }
         }
     };
@@ -506,12 +520,12 @@ __global__ __launch_bounds__(64 * NW) void finc_wave_kernel(const float *__restr
         push_p += push_stride;
 #pragma unroll
         for (int a = 1; a < KH; ++a) pop_p[a] += pop_stride[a];
-        if (fslot == D) {
+        if (__builtin_expect(fslot == D, 0)) {
             FINC_COLD();
             fslot = 0;
             push_p = fifo + push_base;
         }
-        if (fslot + 1 == D) {
+        if (__builtin_expect(fslot + 1 == D, 0)) {
             FINC_COLD();
 #pragma unroll
             for (int a = 1; a < KH; ++a) pop_p[a] = fifo + pop_base[a];
@@ -629,7 +643,7 @@ __global__ __launch_bounds__(64 * NW) void finc_wave_kernel(const float *__restr
                         for (int j = 0; j < NK; ++j) R[a][0][j] = DL[a][a - 2][j];
                     }
                 }
-                if (any_wrap) {
+                if (__builtin_expect(any_wrap, 0)) {
                     FINC_COLD();
                     const bool wrapn = p == tm;
 #pragma unroll
@@ -648,7 +662,7 @@ __global__ __launch_bounds__(64 * NW) void finc_wave_kernel(const float *__restr
             // ---- RA2
 #pragma unroll
             for (int j = 0; j < NKZ; ++j) zv[j] = zraw[j];
-            if (any_idle) {
+            if (__builtin_expect(any_idle, 0)) {
                 FINC_COLD();
                 const bool started = p <= tp1;
 #pragma unroll
@@ -659,7 +673,7 @@ __global__ __launch_bounds__(64 * NW) void finc_wave_kernel(const float *__restr
             if constexpr (ROT) {
                 // the operands phase A just read unmasked (b = 0 / 1 of this step) become b >= 1 taps of a step that
                 // starts a row: zero them, for the wrapping lanes only, after phase A has issued and before phase B
-                if (any_wrap) {
+                if (__builtin_expect(any_wrap, 0)) {
                     FINC_COLD();
                     const bool wrapn = p == tm;
 #pragma unroll
@@ -728,7 +742,7 @@ __global__ __launch_bounds__(64 * NW) void finc_wave_kernel(const float *__restr
                     fifo_pop_all();
                 }
                 if constexpr (KW > 1) {                // S_0(t): tap (0,1) of the next step
-                    if (any_wrap) {
+                    if (__builtin_expect(any_wrap, 0)) {
                         FINC_COLD();
                         const bool wrapn = p == tm;
 #pragma unroll
