@@ -18,7 +18,7 @@ SYMBOLS = [
     "finc_check_invariant_f32", "finc_workspace_bytes", "finc_inverse_algo_for", "finc_forward_algo_for",
     "finc_inverse_f32", "finc_forward_f32", "finc_pack_inverse_weights_f32", "finc_pack_forward_weights_f32",
     "finc_inverse_packed_f32", "finc_forward_packed_f32", "finc_backward_f32", "finc_backward_workspace_bytes",
-    "finc_inverse_workspace_bytes",
+    "finc_inverse_workspace_bytes", "finc_pack_inverse_weights_affine_f32",
 ]
 
 _lib = None
@@ -52,6 +52,7 @@ def lib():
     L.finc_inverse_f32.argtypes = run
     L.finc_forward_f32.argtypes = run
     L.finc_pack_inverse_weights_f32.argtypes = [vp, vp, i, i, i, i, vp]
+    L.finc_pack_inverse_weights_affine_f32.argtypes = [vp, vp, vp, vp, i, i, i, i, vp]
     L.finc_pack_forward_weights_f32.argtypes = [vp, vp, i, i, i, i, vp]
     runp = [vp, vp, vp, i, i, i, i, i, i, i, u, vp]
     L.finc_inverse_packed_f32.argtypes = runp

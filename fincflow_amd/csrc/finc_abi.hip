@@ -173,7 +173,7 @@ static int run(const float *in, const float *w_canon, float *out, int B, int G, 
             float *zp = (float *)((char *)workspace + pk), *xp = (float *)((char *)workspace + pk + act);
             const long long rows = (long long)B * G * Cq * H;
             if (int e = finc_launch_repitch(in, zp, rows, W, Wp, st)) return e;
-            if (int e = finc_mfma_pack(w_canon, workspace, G, Cq, KH, KW, st)) return e;
+            if (int e = finc_mfma_pack(w_canon, nullptr, nullptr, workspace, G, Cq, KH, KW, st)) return e;
             FincShape sp{B, G, Cq, H, Wp, KH, KW, orient};
             if (int e = finc_mfma_launch(zp, workspace, xp, sp, st)) return e;
             return finc_launch_repitch(xp, out, rows, Wp, W, st);
@@ -193,7 +193,7 @@ static int run(const float *in, const float *w_canon, float *out, int B, int G, 
     }
     if (!finc_mfma_supported(Cq, H, W, KH, KW)) return FINC_ERR_UNSUPPORTED;
     if (!workspace || workspace_bytes < finc_mfma_packed_bytes(G, Cq, KH, KW)) return FINC_ERR_WORKSPACE;
-    if (int e = finc_mfma_pack(w_canon, workspace, G, Cq, KH, KW, st)) return e;
+    if (int e = finc_mfma_pack(w_canon, nullptr, nullptr, workspace, G, Cq, KH, KW, st)) return e;
     return finc_mfma_launch(in, workspace, out, s, st);
 }
 
@@ -218,13 +218,22 @@ static int pack(const float *w_canon, void *packed, int G, int Cq, int KH, int K
         return finc_conv_pack(w_canon, packed, G, Cq, KH, KW, false, (hipStream_t)stream);
     }
     if (finc_mfma_packed_bytes(G, Cq, KH, KW) == 0) return FINC_ERR_UNSUPPORTED;
-    return finc_mfma_pack(w_canon, packed, G, Cq, KH, KW, (hipStream_t)stream);
+    return finc_mfma_pack(w_canon, nullptr, nullptr, packed, G, Cq, KH, KW, (hipStream_t)stream);
 }
 
 int finc_pack_inverse_weights_f32(const float *w_canon, void *packed, int G, int Cq, int KH, int KW,
                                   finc_stream_t stream)
 {
     return pack(w_canon, packed, G, Cq, KH, KW, stream, false);
+}
+
+int finc_pack_inverse_weights_affine_f32(const float *w_canon, const float *scale, const float *shift, void *packed,
+                                         int G, int Cq, int KH, int KW, finc_stream_t stream)
+{
+    if (!w_canon || !packed) return FINC_ERR_NULL_POINTER;
+    if (int e = check_shape(1, G, Cq, 1, 1, KH, KW)) return e;
+    if (finc_mfma_packed_bytes(G, Cq, KH, KW) == 0) return FINC_ERR_UNSUPPORTED;
+    return finc_mfma_pack(w_canon, scale, shift, packed, G, Cq, KH, KW, (hipStream_t)stream);
 }
 
 int finc_pack_forward_weights_f32(const float *w_canon, void *packed, int G, int Cq, int KH, int KW,

@@ -50,7 +50,9 @@ int finc_launch_repitch(const float *in, float *out, long long rows, int Win, in
 
 bool finc_mfma_supported(int Cq, int H, int W, int KH, int KW);
 size_t finc_mfma_packed_bytes(int G, int Cq, int KH, int KW);
-int finc_mfma_pack(const float *wc, void *packed, int G, int Cq, int KH, int KW, hipStream_t st);
+// scale / shift [G*Cq] or nullptr: the affine map z = scale*y + shift folded in front of the inverse
+int finc_mfma_pack(const float *wc, const float *scale, const float *shift, void *packed, int G, int Cq, int KH, int KW,
+                   hipStream_t st);
 int finc_mfma_launch(const float *in, const void *packed, float *out, const FincShape &s, hipStream_t st);
 
 // ---- forward / grad-input, MFMA strip kernel: finc_conv.hip ----

@@ -67,7 +67,11 @@ struct Cfg {
     static constexpr int NK = NKD;                        // k-steps per neighbour tap (per wave)
     static constexpr int NTAP = KH * KW;
     static constexpr int NFRAG = (NKZ + (NTAP - 1) * NKD) * MT;   // fragments a wave holds
-    static constexpr int NFRAGT = (NKZT + (NTAP - 1) * NKDT) * MT; // fragments packed per group
+    static constexpr int NFRAGT = (NKZT + (NTAP - 1) * NKDT) * MT; // filter fragments packed per group
+    // then, per group: 4*MT registers of BIAS in accumulator layout (an affine map in front of the inverse,
+    // z = s*y + t, is folded into the bank -- Linv*diag(s) as the z-term, Linv*t as the accumulators' initial value) and
+    // 4*MT registers of zeros (what the waves w > 0 of a K-split start from)
+    static constexpr int NPACK = NFRAGT + 8 * MT;
     static constexpr int ZSLOTS = 12, XSLOTS = 8;
     static constexpr int ZRING = NKZ * ZSLOTS * 64;       // floats
     static constexpr int XRING = NKD * XSLOTS * 64;
@@ -229,7 +233,7 @@ __global__ __launch_bounds__(64 * NW) void finc_wave_kernel(const float *__restr
     float af[NFRAG];
     {
         // packed index: z-term (j*MT + mt), then taps ((tap-1)*NKDT + j)*MT + mt, j global; this wave's j = wv*N + jl
-        const float *pk = packed + (size_t)g * C::NFRAGT * 64 + lane;
+        const float *pk = packed + (size_t)g * C::NPACK * 64 + lane;
 #pragma unroll
         for (int f = 0; f < NFRAG; ++f) {
             int gi;
@@ -250,6 +254,13 @@ __global__ __launch_bounds__(64 * NW) void finc_wave_kernel(const float *__restr
             if (NW == 1 && f < NKZ * MT && finc_zterm_is_zero(C::MTB, f / MT, f % MT)) continue;   // never read
             asm volatile("" : "+a"(af[f]));
         }
+    }
+    v4f bias[MT];                             // initial value of a pixel's accumulators (zero unless an affine map is folded in)
+    {
+        const float *pb = packed + ((size_t)g * C::NPACK + C::NFRAGT + (wv == 0 ? 0 : 4 * MT)) * 64 + lane;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+            bias[mt] = (v4f){pb[(4 * mt + 0) * 64], pb[(4 * mt + 1) * 64], pb[(4 * mt + 2) * 64], pb[(4 * mt + 3) * 64]};
     }
     for (int i = lane; i < fifo_n + SS + 64; i += 64) fifo[i] = 0.f;
 
@@ -590,7 +601,7 @@ __global__ __launch_bounds__(64 * NW) void finc_wave_kernel(const float *__restr
         constexpr int NCH = BT::count();
         v4f acc[MT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[mt] = (v4f){0.f, 0.f, 0.f, 0.f};
+        for (int mt = 0; mt < MT; ++mt) acc[mt] = (v4f){0.f, 0.f, 0.f, 0.f};   // set in the prologue (step -1)
 
         auto phase_a = [&](auto pha_c, int j0, int j1) {
             constexpr int PHA = decltype(pha_c)::value;
@@ -691,7 +702,18 @@ __global__ __launch_bounds__(64 * NW) void finc_wave_kernel(const float *__restr
             FINC_SB();
             // ---- RB0: z-term of the next step
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) accn[mt] = (v4f){0.f, 0.f, 0.f, 0.f};
+            for (int mt = 0; mt < MT; ++mt) accn[mt] = bias[mt];
+            if (__builtin_expect(any_idle, 0)) {
+                // a lane that has not started must keep producing exact zeros: its "pixels" are what lane p+1 and, through
+                // the FIFO, the first band's lanes 0..KH-2 read as the (non-existent) rows above the image
+                FINC_COLD();
+                const bool started = p <= tp1;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const float b0 = bias[mt].x, b1 = bias[mt].y, b2 = bias[mt].z, b3 = bias[mt].w;
+                    accn[mt] = (v4f){started ? b0 : 0.f, started ? b1 : 0.f, started ? b2 : 0.f, started ? b3 : 0.f};
+                }
+            }
 #pragma unroll
             for (int j = 0; j < NKZ; ++j)
 #pragma unroll
@@ -813,6 +835,11 @@ __global__ __launch_bounds__(64 * NW) void finc_wave_kernel(const float *__restr
         {                                              // step -1: acc = Linv * z of the position lanes with p == 0 start at
             const bool started = p <= tp1;             // tp1 == 0 here
 #pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const float b0 = bias[mt].x, b1 = bias[mt].y, b2 = bias[mt].z, b3 = bias[mt].w;
+                acc[mt] = (v4f){started ? b0 : 0.f, started ? b1 : 0.f, started ? b2 : 0.f, started ? b3 : 0.f};
+            }
+#pragma unroll
             for (int j = 0; j < NKZ; ++j) {
                 const float v = zrd[j * C::ZSLOTS * 64];
                 const float zvj = started ? v : 0.f;
@@ -850,21 +877,26 @@ __global__ __launch_bounds__(64 * NW) void finc_wave_kernel(const float *__restr
 
 // -----------------------------------------------------------------------------------------------
 // Fragment packing (fp64 math, one workgroup per group): Linv = L^-1 by forward substitution;
-// z-term fragment = Linv; tap (a,b) fragment = -(Linv * Wc[:,:,KH-1-a,KW-1-b]).
+// z-term fragment = Linv * diag(scale); tap (a,b) fragment = -(Linv * Wc[:,:,KH-1-a,KW-1-b]); bias = Linv * shift
+// (scale / shift: the affine map z = scale*y + shift folded in front of the inverse, per channel of the group;
+// nullptr = identity).  After the nfrag filter fragments of a group come 4*MT bias registers in accumulator layout
+// (16-row tile: lane (q,p), register r = row 16mt+4q+r; 4-row block: register i = row base+i, in lane row 0 only,
+// because the block's 4 lane rows are summed) and 4*MT registers of zeros.
 // Lane (q,i) of fragment (tap, j, mt) holds row 16mt+i for a 16-row tile (mt < MTB), row 16*MTB + 4(mt-MTB) + (i&3)
 // for a 4-row block (the 4x4x1 A operand: lane 4*blk+i' = row i' of block blk, the same for all 4 pixel quads);
 // column = channel of k-slot q of k-step j (z-term: 4j+q; taps: chan_d, the order in which the solved pixels leave
 // the accumulators).
 // -----------------------------------------------------------------------------------------------
-__global__ void pack_kernel(const float *__restrict__ wc, float *__restrict__ packed, int Cq, int KH, int KW, int MT,
-                            int NKZ, int NKD, int MTB, int unused, int nfrag)
+__global__ void pack_kernel(const float *__restrict__ wc, const float *__restrict__ scale,
+                            const float *__restrict__ shift, float *__restrict__ packed, int Cq, int KH, int KW, int MT,
+                            int NKZ, int NKD, int MTB, int nfrag)
 {
     extern __shared__ __attribute__((aligned(16))) double sm[]; // Linv [Cq][Cq]
     const int g = blockIdx.x;
     const float *wg = wc + (size_t)g * Cq * Cq * KH * KW;
     const int KK = KH * KW;
     double *Linv = sm;
-    (void)unused;
+    const int npack = nfrag + 8 * MT;
     // column j of Linv: solve L y = e_j  (L unit lower triangular)
     for (int j = threadIdx.x; j < Cq; j += blockDim.x) {
         for (int r = 0; r < Cq; ++r) {
@@ -890,7 +922,7 @@ __global__ void pack_kernel(const float *__restrict__ wc, float *__restrict__ pa
         double v = 0.0;
         if (row < Cq && col < Cq) {
             if (zterm) {
-                v = Linv[row * Cq + col];
+                v = Linv[row * Cq + col] * (scale ? (double)scale[g * Cq + col] : 1.0);
             } else {
                 const int a = tap / KW, b = tap % KW;
                 const int widx = (KH - 1 - a) * KW + (KW - 1 - b);
@@ -899,7 +931,16 @@ __global__ void pack_kernel(const float *__restrict__ wc, float *__restrict__ pa
                 v = -s;
             }
         }
-        packed[((size_t)g * nfrag + f) * 64 + lane] = (float)v;
+        packed[((size_t)g * npack + f) * 64 + lane] = (float)v;
+    }
+    for (int e = threadIdx.x; e < 8 * MT * 64; e += blockDim.x) {
+        const int lane = e & 63, f = e >> 6;           // f < 4*MT: bias register r of tile mt; then the zero block
+        const int q = lane >> 4, mt = (f % (4 * MT)) >> 2, r = f & 3;
+        const int row = mt < MTB ? 16 * mt + 4 * q + r : (q == 0 ? 16 * MTB + 4 * (mt - MTB) + r : Cq);
+        double v = 0.0;
+        if (f < 4 * MT && shift && row < Cq)
+            for (int k = 0; k <= row; ++k) v += Linv[row * Cq + k] * (double)shift[g * Cq + k];
+        packed[((size_t)g * npack + nfrag + f) * 64 + lane] = (float)v;
     }
 }
 
@@ -976,15 +1017,16 @@ bool finc_mfma_supported(int Cq, int H, int W, int KH, int KW)
 size_t finc_mfma_packed_bytes(int G, int Cq, int KH, int KW)
 {
     const Inst *a = find_inst(Cq, KH, KW);
-    return a ? (size_t)a->nfrag * 64 * sizeof(float) * (size_t)G : 0;
+    return a ? (size_t)(a->nfrag + 8 * a->mt) * 64 * sizeof(float) * (size_t)G : 0;
 }
 
-int finc_mfma_pack(const float *wc, void *packed, int G, int Cq, int KH, int KW, hipStream_t st)
+int finc_mfma_pack(const float *wc, const float *scale, const float *shift, void *packed, int G, int Cq, int KH, int KW,
+                   hipStream_t st)
 {
     const Inst *i = find_inst(Cq, KH, KW);
     if (!i) return FINC_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(pack_kernel, dim3(G), dim3(256), sizeof(double) * Cq * Cq, st, wc, (float *)packed, Cq, KH, KW,
-                       i->mt, i->nkz, i->nkd, i->mtb, 0, i->nfrag);
+    hipLaunchKernelGGL(pack_kernel, dim3(G), dim3(256), sizeof(double) * Cq * Cq, st, wc, scale, shift, (float *)packed, Cq,
+                       KH, KW, i->mt, i->nkz, i->nkd, i->mtb, i->nfrag);
     FINC_CHECK_LAUNCH();
     return FINC_OK;
 }

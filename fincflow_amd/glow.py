@@ -65,6 +65,11 @@ class ActNorm(FlowLayer):
         t, ls = self._shaped(input)
         return input * torch.exp(ls) + t
 
+    def reverse_affine_params(self):
+        """reverse(y) = exp(log_scale) * y + translation, per channel: what FlowSequential folds into the FastFlowUnit
+        that comes next in the reverse chain."""
+        return self.log_scale, self.translation
+
     def logdet(self, input, context=None):
         pixels = int(np.prod(input.shape[2:])) if input.dim() > 2 else 1
         return -self.log_scale.sum().expand(input.size(0)) * pixels

@@ -155,6 +155,8 @@ class PackedWeights:
         self.w_canon = None
         self.packed_inv = None
         self.packed_fwd = None
+        self.packed_aff = None
+        self.aff_key = None
 
     def invalidate(self):
         """Force a rebuild on the next call.  Needed after writes that do not bump Tensor._version
@@ -162,6 +164,7 @@ class PackedWeights:
         self.key = None
         self.packed_inv = None
         self.packed_fwd = None
+        self.packed_aff = None
 
     def get(self, weights, G, orient):
         key = tuple((w.data_ptr(), w._version) for w in weights) + (orient,)
@@ -171,6 +174,7 @@ class PackedWeights:
             check_invariant(self.w_canon, G)
             self.packed_inv = None
             self.packed_fwd = None
+            self.packed_aff = None
             self.key = key
         return self.w_canon
 
@@ -209,6 +213,35 @@ class PackedWeights:
                 out = torch.empty_like(z)
             _lib.check(L.finc_inverse_packed_f32(z.data_ptr(), self.packed_inv.data_ptr(), out.data_ptr(), B, G, Cq, H, W,
                                                  KH, KW, orient, _stream_ptr(z)), "finc_inverse_packed_f32")
+        return out
+
+
+    def inverse_affine(self, y, weights, G, orient, log_scale, translation, out=None):
+        """inverse(exp(log_scale) * y + translation) in ONE launch: the per-channel affine layer in front
+        of the unit in the reverse chain (ActNorm.reverse, layers/actnorm.py:39-52) is folded into the packed bank.
+        Returns None when the shape has no MFMA instantiation (the caller then runs the two layers one after the other)."""
+        w_canon = self.get(weights, G, orient)
+        _require_device(y, "input")
+        B, Cq, H, W, KH, KW = _dims(y, w_canon, G)
+        L = _lib.lib()
+        if y.numel() == 0 or L.finc_inverse_algo_for(Cq, H, W, KH, KW) != _lib.ALGO["mfma"]:
+            return None
+        key = (log_scale.data_ptr(), log_scale._version, translation.data_ptr(), translation._version)
+        with torch.cuda.device(y.device):
+            if self.packed_aff is None or self.aff_key != key:
+                scale = torch.exp(log_scale.detach().float()).contiguous()
+                shift = translation.detach().float().contiguous()
+                if scale.numel() != G * Cq or shift.numel() != G * Cq:
+                    raise ValueError("affine parameters must have one entry per channel")
+                self.packed_aff = torch.empty(L.finc_workspace_bytes(G, Cq, KH, KW), dtype=torch.uint8, device=y.device)
+                _lib.check(L.finc_pack_inverse_weights_affine_f32(w_canon.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                                                  self.packed_aff.data_ptr(), G, Cq, KH, KW, _stream_ptr(y)),
+                           "finc_pack_inverse_weights_affine_f32")
+                self.aff_key = key
+            if out is None:
+                out = torch.empty_like(y)
+            _lib.check(L.finc_inverse_packed_f32(y.data_ptr(), self.packed_aff.data_ptr(), out.data_ptr(), B, G, Cq, H, W,
+                                                 KH, KW, orient, _stream_ptr(y)), "finc_inverse_packed_f32")
         return out
 
 

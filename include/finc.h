@@ -127,6 +127,17 @@ int finc_pack_inverse_weights_f32(const float *w_canon, void *packed, int G, int
                                   finc_stream_t stream);
 int finc_pack_forward_weights_f32(const float *w_canon, void *packed, int G, int Cq, int KH, int KW,
                                   finc_stream_t stream);
+/*
+ * SURVEY 8 f3 -- the per-channel affine layer that precedes the unit in the reverse chain folded into the bank:
+ * with fragments packed by this call, finc_inverse_packed_f32(y, ...) returns inverse(scale * y + shift), i.e.
+ * FastFlowUnit.reverse(ActNorm.reverse(y)) (layers/actnorm.py:39-52: scale = exp(log_scale), shift = translation;
+ * called back to back by FlowSequential.sample, layers/flowsequential.py:89-115) in the one launch and at the
+ * per-step cost of the plain inverse: Linv*diag(scale) replaces Linv as the z-term and Linv*shift is the
+ * accumulators' initial value.  scale / shift: [G*Cq] device floats, either may be NULL (identity).
+ * FINC_ERR_UNSUPPORTED when the shape has no MFMA instantiation (there is no strict twin of this call).
+ */
+int finc_pack_inverse_weights_affine_f32(const float *w_canon, const float *scale, const float *shift, void *packed,
+                                         int G, int Cq, int KH, int KW, finc_stream_t stream);
 int finc_inverse_packed_f32(const float *z, const void *packed, float *x, int B, int G, int Cq, int H, int W,
                             int KH, int KW, unsigned orient, finc_stream_t stream);
 int finc_forward_packed_f32(const float *x, const void *packed, float *z, int B, int G, int Cq, int H, int W,

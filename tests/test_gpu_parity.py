@@ -480,3 +480,47 @@ def test_odd_widths_run_on_the_padded_mfma_path(shape, dev):
             m.conv.weight.copy_(torch.from_numpy(ws[o * Cq:(o + 1) * Cq]))
     assert rel_err(unit.reverse(zt).cpu().numpy(), ref) <= TOL
     assert rel_err(unit(t(x, dev))[0].detach().cpu().numpy(), z) <= TOL
+
+
+@pytest.mark.parametrize("shape", [(3, 96, 20, 24, 3), (2, 48, 16, 16, 3), (2, 12, 8, 8, 3), (2, 24, 9, 8, 3), (2, 192, 12, 16, 3)])
+def test_affine_fold_into_the_inverse(shape, dev):
+    """FastFlowUnit.reverse(ActNorm.reverse(y)) in one launch.  The folded bank gives the same result as
+    the two layers one after the other and as the oracle on the affinely mapped input; FlowSequential takes the fused
+    path by itself and a parameter update (optimizer step: in-place, bumps the version) is picked up."""
+    from fincflow_amd import FastFlowUnit, FlowSequential, glow
+    from fincflow_amd.layers import StandardNormal
+    B, C, H, W, K = shape
+    torch.manual_seed(sum(shape))
+    unit = FastFlowUnit(C, C, K).to(dev)
+    an = glow.ActNorm(C).to(dev)
+    with torch.no_grad():
+        an.log_scale.copy_(0.3 * torch.randn(C, device=dev))
+        an.translation.copy_(torch.randn(C, device=dev))
+        an.initialized.fill_(1)
+    y = torch.randn(B, C, H, W, device=dev)
+    with torch.no_grad():
+        two = unit.reverse(an.reverse(y))
+        fused = unit.reverse_affine(y, an.log_scale, an.translation)
+    assert fused is not None, "this shape has an MFMA instantiation"
+    assert rel_err(fused.cpu().numpy(), two.cpu().numpy()) <= TOL
+    ws = torch.cat(unit._weights()).detach().cpu().numpy()
+    wco = oracle.canonicalize(ws, 4, ORIENT_FASTFLOW)
+    z = (y * torch.exp(an.log_scale).view(1, -1, 1, 1) + an.translation.view(1, -1, 1, 1)).detach().cpu().numpy()
+    assert rel_err(fused.cpu().numpy(), oracle.inverse_via_f64(z, wco)) <= TOL
+    # through the container: [unit, actnorm] forward order -> actnorm.reverse then unit.reverse, fused
+    seq = FlowSequential(StandardNormal((C, H, W)), unit, an)
+    x = torch.randn(B, C, H, W, device=dev)
+    with torch.no_grad():
+        zz = seq(x)[0]
+        seq.fuse_affine = True
+        a = seq._reverse_chain(zz, None)
+        seq.fuse_affine = False
+        b = seq._reverse_chain(zz, None)
+        assert rel_err(a.cpu().numpy(), b.cpu().numpy()) <= TOL and rel_err(a.cpu().numpy(), x.cpu().numpy()) <= 1e-4
+        an.translation.add_(1.0)                     # in-place update: the cached bank must follow
+        seq.fuse_affine = True
+        a2 = seq._reverse_chain(zz, None)
+        seq.fuse_affine = False
+        b2 = seq._reverse_chain(zz, None)
+    assert rel_err(a2.cpu().numpy(), b2.cpu().numpy()) <= TOL
+    assert rel_err(a2.cpu().numpy(), a.cpu().numpy()) > 1e-3

@@ -35,8 +35,9 @@ def zterm_is_zero(MTB, j, mt):
     return 4 * j > 16 * mt + 15 if mt < MTB else 4 * j > 16 * MTB + 4 * (mt - MTB) + 3
 
 
-def pack_fragments(wc, CQP, fwd):
-    """pack_kernel: returns {('z', j, mt) | ((a,b), j, mt): array[64]} in fp64."""
+def pack_fragments(wc, CQP, fwd, scale=None, shift=None):
+    """pack_kernel: returns {('z', j, mt) | ((a,b), j, mt): array[64]} in fp64, plus ('bias', mt): array[64, 4]
+    (the affine map z = scale*y + shift folded in: z-term Linv*diag(scale), accumulators start from Linv*shift)."""
     Cq, _, KH, KW = wc.shape
     c = cfg(CQP, KH, KW, fwd)
     MT, MTB, NKZ, NK = c["MT"], c["MTB"], c["NKZ"], c["NK"]
@@ -62,7 +63,17 @@ def pack_fragments(wc, CQP, fwd):
             for b in range(KW):
                 frag(w[:, :, KH - 1 - a, KW - 1 - b], lambda j, q: 4 * j + q, NKZ, (a, b))
     else:
-        frag(Linv, lambda j, q: 4 * j + q, NKZ, "z")
+        frag(Linv * (np.ones(Cq) if scale is None else np.asarray(scale, np.float64))[None, :], lambda j, q: 4 * j + q, NKZ, "z")
+        bvec = Linv @ (np.zeros(Cq) if shift is None else np.asarray(shift, np.float64))
+        for mt in range(MT):
+            bias = np.zeros((LANES, 4))
+            for lane in range(LANES):
+                q = lane >> 4
+                for r in range(4):
+                    row = 16 * mt + 4 * q + r if mt < MTB else (16 * MTB + 4 * (mt - MTB) + r if q == 0 else Cq)
+                    if row < Cq:
+                        bias[lane, r] = bvec[row]
+            frags[("bias", mt)] = bias
         for a in range(KH):
             for b in range(KW):
                 if (a, b) != (0, 0):
@@ -132,7 +143,7 @@ def pack_d(acc, c):
     return xpk
 
 
-def run(inp, wc, fwd=False):
+def run(inp, wc, fwd=False, scale=None, shift=None):
     """inp [Cq,H,W] (z for inverse, x for forward), wc [Cq,Cq,KH,KW] canonical -> out [Cq,H,W] (fp64)."""
     CQ, H, W = inp.shape
     KH, KW = wc.shape[2:]
@@ -145,7 +156,7 @@ def run(inp, wc, fwd=False):
     NB = (H + P - 1) // P
     Tend = (NB * W + P - 1 + 3) // 4 * 4
     D = W - P + 1
-    fr = pack_fragments(wc, CQP, fwd)
+    fr = pack_fragments(wc, CQP, fwd, scale, shift)
     out = np.full((CQ, H, W), np.nan)
     lanes = np.arange(LANES)
     q, p = lanes >> 4, lanes & 15
@@ -301,7 +312,7 @@ def run(inp, wc, fwd=False):
     cn = -3 - p
     assert not fwd, 'the forward is finc_conv.hip (no skewed wavefront); only the inverse is modelled'
     if True:
-        acc = [np.zeros((LANES, 4)) for _ in range(MT)]
+        acc = [np.zeros((LANES, 4)) for _ in range(MT)]   # idle lanes stay at exact zero (the bias starts with the lane)
         for t in range(-4, Tend):
             wrapn = cn == 0
             zv = np.stack([np.where(cn >= 0, zring[j, nslot, lanes], 0.0) for j in range(NKZ)])
@@ -317,7 +328,7 @@ def run(inp, wc, fwd=False):
                         acc[mt] = mm((0, 1), j, mt, R[0, 1, j], acc[mt])
                     if KH > 1:
                         acc[mt] = mm((1, 0), j, mt, R[1, 0, j], acc[mt])
-            accn = [np.zeros((LANES, 4)) for _ in range(MT)]
+            accn = [np.where((cn >= 0)[:, None], fr[("bias", mt)], 0.0) for mt in range(MT)]
             for j in range(NKZ):
                 for mt in range(MT):
                     if zterm_is_zero(MTB, j, mt):      # Linv is lower triangular: the kernel skips these MFMAs
