@@ -1,0 +1,45 @@
+"""GPU helper: random-shape parity sweep of the product path against the oracle (inverse auto/strict, forward, grad-input
+through autograd).  Usage: python scripts/fuzz_parity.py [n_cases] [seed].  Exits non-zero on the first mismatch."""
+import os, sys
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from fincflow_amd import ops
+from oracle import oracle
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 80
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+dev = torch.device("cuda:0")
+ORI = 0xE4
+worst = 0.0
+for case in range(n):
+    K = int(rng.choice([2, 3, 3, 3, 5]))
+    cq_opts = [1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48] if K == 3 else ([1, 3, 4, 13, 16] if K == 2 else [2, 4, 16, 32, 48])
+    Cq = int(rng.choice(cq_opts))
+    G = int(rng.choice([1, 4, 4, 4]))
+    H = int(rng.integers(1, 41))
+    W = int(rng.choice([rng.integers(1, 41), 4 * rng.integers(1, 12), 8 * rng.integers(1, 9)]))
+    B = int(rng.integers(1, 4))
+    orient = ORI if G == 4 else int(rng.integers(0, 4))
+    std = 0.05 if K < 5 else 0.02
+    ws = oracle.make_stored_weights(G, Cq, K, K, orient=orient, seed=case, std=std)
+    wco = oracle.canonicalize(ws, G, orient)
+    x = rng.standard_normal((B, G * Cq, H, W)).astype(np.float32)
+    z = oracle.forward_f32(x, wco, G, orient)
+    ref = oracle.inverse_via_f64(z, wco, G, orient)
+    wc = ops.canonicalize(torch.from_numpy(ws).to(dev), G, orient)
+    zt, xt = torch.from_numpy(z).to(dev), torch.from_numpy(x).to(dev)
+    auto = ops.finc_inverse(zt, wc, G, orient, algo="auto").cpu().numpy()
+    fwd = ops.finc_forward(xt, wc, G, orient).cpu().numpy()
+    scale = max(np.abs(ref).max(), 1e-30)
+    e_inv = np.abs(auto - ref).max() / scale
+    e_fwd = np.abs(fwd - z).max() / max(np.abs(z).max(), 1e-30)
+    strict = ops.finc_inverse(zt, wc, G, orient, algo="strict").cpu().numpy()
+    exact = np.array_equal(strict, oracle.inverse_f32(z, wco, G, orient))
+    tol = 1e-5 if np.abs(ref).max() < 1e3 else 1e-3      # ill-conditioned random draws amplify fp32 rounding in any solver
+    worst = max(worst, e_inv, e_fwd)
+    tag = "ok" if (e_inv <= tol and e_fwd <= 1e-5 and exact) else "MISMATCH"
+    print(f"{case:3d} B{B} G{G} Cq{Cq} {H}x{W} k{K} orient {orient:#x}: inv {e_inv:.1e} fwd {e_fwd:.1e} strict-exact {exact} |x|max {np.abs(ref).max():.1e} {tag}", flush=True)
+    if tag != "ok":
+        sys.exit(1)
+print("all ok, worst rel err %.2e" % worst)
