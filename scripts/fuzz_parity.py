@@ -35,8 +35,11 @@ for case in range(n):
     e_inv = np.abs(auto - ref).max() / scale
     e_fwd = np.abs(fwd - z).max() / max(np.abs(z).max(), 1e-30)
     strict = ops.finc_inverse(zt, wc, G, orient, algo="strict").cpu().numpy()
-    exact = np.array_equal(strict, oracle.inverse_f32(z, wco, G, orient))
-    tol = 1e-5 if np.abs(ref).max() < 1e3 else 1e-3      # ill-conditioned random draws amplify fp32 rounding in any solver
+    ref32 = oracle.inverse_f32(z, wco, G, orient)
+    exact = np.array_equal(strict, ref32)
+    # 1e-5 where the problem is well conditioned; a random bank at Cq >= 32 on a large map is not (the reference's own
+    # fp32 order then differs from its fp64 path by 1e-4 and more), so the yardstick there is that fp32-order error
+    tol = max(1e-5, 2.0 * np.abs(ref32 - ref).max() / scale)
     worst = max(worst, e_inv, e_fwd)
     tag = "ok" if (e_inv <= tol and e_fwd <= 1e-5 and exact) else "MISMATCH"
     print(f"{case:3d} B{B} G{G} Cq{Cq} {H}x{W} k{K} orient {orient:#x}: inv {e_inv:.1e} fwd {e_fwd:.1e} strict-exact {exact} |x|max {np.abs(ref).max():.1e} {tag}", flush=True)
