@@ -280,7 +280,13 @@ def main():
                          "traffic": (traffic or {}).get("inverse_hbm_bytes_per_launch"),
                          "traffic_source": (traffic or {}).get("source"),
                          "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": inv_launch_ms,
-                         "frac_fp32_peak": alg_flops / (inv_launch_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS},
+                         "frac_fp32_peak": alg_flops / (inv_launch_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
+                         # the shape is compute-bound (K^2*Cq/4 flop/B against a ridge of ~20): the same launch against
+                         # the ceiling that actually limits it, the dense fp32 MFMA peak
+                         "compute": {"bound": "mfma", "achieved": alg_flops / (inv_launch_ms * 1e-3) / 1e12,
+                                     "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                     "frac": alg_flops / (inv_launch_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
+                                     "algorithmic_flops_per_launch": alg_flops}},
         }
         if not args.no_cpu and world == 1:          # the CPU baseline is an N=1 measurement (rank 0 only)
             sample = args.cpu_sample or (4 * (os.cpu_count() or 1) if args.workload == "c3" else B)
