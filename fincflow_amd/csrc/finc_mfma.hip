@@ -266,78 +266,192 @@ __global__ __launch_bounds__(64 * NW) void finc_wave_kernel(const float *__restr
 
     // ---- per-lane HBM stream state -------------------------------------------------------------
     const int fl4 = -((p + 3) >> 2);          // floor(-p/4): first 4-column group this lane ever needs
-    // SEC (W % 8 == 0): HBM is touched in aligned 32-byte pieces (two 4-column groups), the write atom of the
-    // fabric.  (16-byte pieces cost 4 fetches per 64-byte sector and a 32-byte partial write per store: FETCH_SIZE
-    // 4x, WRITE_SIZE 2x, and the fabric saturates at B=256.)  Loads: every other window ("event", step 3 of the
-    // window, one parity class of lanes per window) a lane lands BOTH groups of the piece it issued two windows ago
-    // and issues the next one at once: that is the one step at which the ring slots of both groups are free (the
-    // first group's until step +4, the second's from step -1), and it gives every load 8 steps (~15 us) to come back.
-    // Stores: a lane holds the even group one window and stores it together with the odd one.
-    constexpr int NPC = SEC ? 2 : 1;          // 16-byte pieces held per channel
-    // first chunk this lane loads: window -3 if fl4 is even, else -2; chunk index floor(fl4/2) rounded up for odd
-    int lcol = SEC ? 8 * ((fl4 - (fl4 & 1)) / 2 + (fl4 & 1)) : 4 * fl4, lrow = p;
-    int lph = fl4 & 1;                        // SEC: window parity; this lane loads when it is 0
-    int scol = 4 * (fl4 - 2), srow = p;       // next group to store
-    // z-ring slot of the next landing.  SEC: the first event (window -4 for an even fl4, -3 for an odd one) "lands" the
-    // never-loaded piece before the first real one, groups (e + 2 + fl4, +1) of event window e
-    int lslot = SEC ? ((4 * (fl4 - 2 + (fl4 & 1))) % 12 + 12) % 12 : ((4 * fl4) % 12 + 12) % 12;
-    int sph = fl4 & 1;                        // SEC: parity of the group read next (odd: the pair is complete)
-    // Store offsets: lane part (column/row of the piece + the lane row's share of the channel) in the VGPR offset, the
-    // uniform share of the channel and the piece half in the instruction's scalar offset.  Register jj of a solved pixel
-    // holds channel 16(jj>>2) + 4q + (jj&3) (a 16-row tile's D register) or 16*MTB + 4(jj-4MTB) + q (a reduced 4-row
-    // block): two lane parts.  Channels >= CQ exist only in the last group of four, so only the registers that can hold
-    // one carry a mask (validity must sit in the VGPR offset: the scalar offset is not range checked).
+    // A W-flipped group (TR/BR) is mirrored by choosing the ring SLOT of each element, never by moving data:
+    // a select on a loaded value would drag the s_waitcnt for the whole HBM latency up to the issue point.
+    const int k0 = fw ? 3 : 0, k1 = fw ? 2 : 1, k2 = fw ? 1 : 2, k3 = fw ? 0 : 3;
+    // Offsets: lane part (row/column of the piece + the lane row's share of the channel) in the VGPR offset, the uniform
+    // share of the channel in the instruction's scalar offset.  Register jj of a solved pixel holds channel
+    // 16(jj>>2) + 4q + (jj&3) (a 16-row tile's D register) or 16*MTB + 4(jj-4MTB) + q (a reduced 4-row block): two lane
+    // parts.  Channels >= CQ exist only in the last group of four, so only the registers that can hold one carry a
+    // mask (validity must sit in the VGPR offset: the scalar offset is not range checked).
     const unsigned lane_t = 4u * (unsigned)q * HW * 4u, lane_b = (unsigned)q * HW * 4u;
     unsigned cmask[NKD];
 #pragma unroll
     for (int j = 0; j < NKD; ++j) cmask[j] = chan_d(C::MTB, wv * NKD + j, q) < CQ ? 0u : OFF_BAD_CHANNEL;
-    v4u zb[NKZ][NPC];                         // in flight HBM -> z ring (raw: nothing may touch it until it lands)
-#pragma unroll
-    for (int j = 0; j < NKZ; ++j)
-#pragma unroll
-        for (int m = 0; m < NPC; ++m) zb[j][m] = (v4u){0u, 0u, 0u, 0u};
-    float sv[NKD][4];                         // group just read from the x ring
-    float sh[NKD][4];                         // SEC: the even group held for one window
-#pragma unroll
-    for (int j = 0; j < NKD; ++j)
-#pragma unroll
-        for (int k = 0; k < 4; ++k) sh[j][k] = 0.f;
-    unsigned st_off = OFF_INVALID;
-    bool st_fire = false;
-    // A W-flipped group (TR/BR) is mirrored by choosing the ring SLOT of each element, never by moving data:
-    // a select on a loaded value would drag the s_waitcnt for the whole HBM latency up to the issue point.
-    const int k0 = fw ? 3 : 0, k1 = fw ? 2 : 1, k2 = fw ? 1 : 2, k3 = fw ? 0 : 3;
-    // x-ring read indices of the group to store: slot of element k = (4gs + k + p) & 7 = ((p+k)&7) ^ 4*(gs&1)
-    const int sidx[4] = {((p + k0) & 7) * 64 + lane, ((p + k1) & 7) * 64 + lane, ((p + k2) & 7) * 64 + lane,
-                         ((p + k3) & 7) * 64 + lane};
-    int stog = 256 * (fl4 & 1);               // 4 slots x 64 floats, toggled once per window (gs parity)
-
-    // Load offsets are kept incrementally: canonical column +8 (+4) is a constant byte step in memory, a row change
-    // another constant; the per-channel part j*4*HW*4 is uniform and rides in the buffer instruction's scalar offset.
-    const int lstep = (SEC ? 32 : 16) * (fw ? -1 : 1);                       // bytes per chunk along the row
-    const int lwrap = (fh ? -P : P) * W * 4 - (fw ? -1 : 1) * W * 4;         // extra bytes when the chunk wraps to row+P
-    int loff = ((fh ? H - 1 - lrow : lrow) * W + (fw ? W - (SEC ? 8 : 4) - lcol : lcol)) * 4 + (4 * wv * NKZ + q) * HW * 4;
     const unsigned zlast = (4 * (wv * NKZ + NKZ - 1) + q) < CQ ? 0u : OFF_BAD_CHANNEL;  // only the last k-step can hold a padded channel
-    auto io_issue = [&](int j0, int j1, bool advance) {     // 16-byte pieces (W % 8 != 0): one group per window
+    const int rowstep = (fh ? -P : P) * W * 4;                               // bytes from a row to the same column of row+P
+    const int dirw = fw ? -1 : 1;
+
+    // ================= 32-byte pieces (SEC, W % 8 == 0): lane-pair I/O =================
+    // HBM is touched in aligned 32-byte pieces (two 4-column groups), the write atom of the fabric.  (16-byte pieces cost
+    // 4 fetches per 64-byte sector and a 32-byte partial write per store: FETCH_SIZE 4x, WRITE_SIZE 2x.)  The rows of a
+    // band fall into two classes by the parity of ceil(row/4); a row's piece is due every other window, class c rows in
+    // the windows of parity c.  In such a window EVERY lane moves one 16-byte half of a due piece: the lanes of a class-c
+    // row the first group, the lanes of its partner row (the i-th row of the other class) the second group.  So every
+    // memory instruction has all 64 lanes busy on 32 whole pieces (half as many instructions as one piece per lane),
+    // and nothing is selected or copied per lane: the two register sets (loads Z[parity], stores XS[parity]) simply
+    // alternate with the window -- the main loop is unrolled x8 (two windows).  LDS does the redistribution: a landing
+    // writes the OWNER lane's z-ring column, a store reads the owner's x-ring column.
+    // Loads: in its window ("event", step 3) a lane lands the group it issued two windows ago and re-issues at once:
+    // that is the one step at which the ring slots of both groups of a piece are free, and every load gets 8 steps.
+    // Stores: at step 0 the lanes of the class that does NOT fire read their own row's first group (held one window in
+    // XS[parity ^ 1]) and their partner's just completed second group (into XS[parity]); steps 1-3 store XS[parity].
+    constexpr unsigned long long PARTNER = 0xCBAFED8943276501ull;           // nibble p = partner row of row p
+    const int cls = ((p + 3) >> 2) & 1;
+    const int part = (int)((PARTNER >> (4 * p)) & 15);
+    int srvrow[2], srvhalf[2];                // window parity wp: the class-wp row this lane serves and which group of its piece
+#pragma unroll
+    for (int wp = 0; wp < 2; ++wp) {
+        const bool own = cls == wp || p >= P; // (lanes beyond the band serve themselves: masked loads, their own ring column)
+        srvrow[wp] = own ? p : part;
+        srvhalf[wp] = own ? 0 : 1;
+    }
+    // load stream wp: piece (groups Ga, Ga+1) of row srvrow[wp] with Ga = e + 2 + fl4(row) at event window e; first
+    // events: window -4 (class 0) / -3 (class 1); the piece issued at e lands at e + 2
+    int lcolS[2], lrowS[2], loffS[2], lslotS[2], ldst[2];
+    // store stream wp: the pair (gs-1, gs) of row srvrow[wp], gs = u - 1 + fl4(row) at fire window u; first fire
+    // windows: 0 (class 0) / -1 (class 1, the prologue)
+    int scolS[2], srowS[2], soffS[2];
+#pragma unroll
+    for (int wp = 0; wp < 2; ++wp) {
+        const int R = srvrow[wp], h = srvhalf[wp];
+        const int f = -((R + 3) >> 2);
+        lcolS[wp] = 4 * ((wp ? -3 : -4) + 4 + f);
+        lrowS[wp] = R;
+        lslotS[wp] = ((4 * (((wp ? -3 : -4) + 2 + f + h) % 3 + 3)) % 12);
+        ldst[wp] = q * 16 + R;
+        const int c = lcolS[wp] + 4 * h;
+        loffS[wp] = ((fh ? H - 1 - R : R) * W + (fw ? W - 4 - c : c)) * 4 + (4 * wv * NKZ + q) * HW * 4;
+        scolS[wp] = 4 * ((wp ? -1 : 0) - 2 + f);
+        srowS[wp] = R;
+        const int sc = scolS[wp] + 4 * h;
+        soffS[wp] = ((fh ? H - 1 - R : R) * W + (fw ? W - 4 - sc : sc)) * 4;
+    }
+    v4u Z[2][NKZ];                            // in flight HBM -> z ring (raw: nothing may touch it until it lands)
+#pragma unroll
+    for (int wp = 0; wp < 2; ++wp)
+#pragma unroll
+        for (int j = 0; j < NKZ; ++j) Z[wp][j] = (v4u){0u, 0u, 0u, 0u};
+    float XS[2][NKD][4];                      // x ring -> HBM
+#pragma unroll
+    for (int wp = 0; wp < 2; ++wp)
+#pragma unroll
+        for (int j = 0; j < NKD; ++j)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) XS[wp][j][k] = 0.f;
+    // x-ring read indices (the ring is indexed by TIME: element k of group g of row r was written at step 4g + k + r,
+    // slot = step & 7): a row's first group of a pair is an even group, the second an odd one, so the slots are constants
+    const int xown[4] = {((p + k0) & 7) * 64 + lane, ((p + k1) & 7) * 64 + lane, ((p + k2) & 7) * 64 + lane,
+                         ((p + k3) & 7) * 64 + lane};
+    const int xprt[4] = {(((part + k0) & 7) ^ 4) * 64 + q * 16 + part, (((part + k1) & 7) ^ 4) * 64 + q * 16 + part,
+                         (((part + k2) & 7) ^ 4) * 64 + q * 16 + part, (((part + k3) & 7) ^ 4) * 64 + q * 16 + part};
+    unsigned st_off = OFF_INVALID;
+
+    auto sec_event = [&](auto wp_c) {
+        constexpr int WP = decltype(wp_c)::value;
+        if constexpr (!SEC) return;
+        float *dst = zring + lslotS[WP] * 64 + ldst[WP];
+#pragma unroll
+        for (int j = 0; j < NKZ; ++j) {
+            const unsigned a0 = Z[WP][j].x, a1 = Z[WP][j].y, a2 = Z[WP][j].z, a3 = Z[WP][j].w;
+            float *d = dst + j * C::ZSLOTS * 64;
+            d[k0 * 64] = __builtin_bit_cast(float, a0);
+            d[k1 * 64] = __builtin_bit_cast(float, a1);
+            d[k2 * 64] = __builtin_bit_cast(float, a2);
+            d[k3 * 64] = __builtin_bit_cast(float, a3);
+        }
+        lslotS[WP] = lslotS[WP] >= 4 ? lslotS[WP] - 4 : lslotS[WP] + 8;   // + 8 mod 12
+        const bool ok = lcolS[WP] >= 0 && lrowS[WP] < H && p < P;
+        const unsigned vb = ok ? (unsigned)loffS[WP] : OFF_INVALID;
+#pragma unroll
+        for (int j = 0; j < NKZ; ++j)
+            Z[WP][j] = __builtin_amdgcn_raw_buffer_load_b128(rin, j == NKZ - 1 ? vb + zlast : vb, j * 16 * HW, 0);
+        lcolS[WP] += 8;
+        loffS[WP] += 32 * dirw;
+        if (lcolS[WP] == W) { lcolS[WP] = 0; lrowS[WP] += P; loffS[WP] += rowstep - dirw * W * 4; }
+    };
+    auto sec_sread = [&](auto wp_c) {          // window of parity WP: class WP fires
+        constexpr int WP = decltype(wp_c)::value;
+        if constexpr (!SEC) return;
+        if (cls != WP && p < P) {              // (divergent) own row: first group of its next pair; partner: second group, due now
+#pragma unroll
+            for (int j = 0; j < NKD; ++j) {
+                const float *xo = xring + j * C::XSLOTS * 64, *xp = xring + j * C::XSLOTS * 64;
+                XS[WP ^ 1][j][0] = xo[xown[0]];
+                XS[WP ^ 1][j][1] = xo[xown[1]];
+                XS[WP ^ 1][j][2] = xo[xown[2]];
+                XS[WP ^ 1][j][3] = xo[xown[3]];
+                XS[WP][j][0] = xp[xprt[0]];
+                XS[WP][j][1] = xp[xprt[1]];
+                XS[WP][j][2] = xp[xprt[2]];
+                XS[WP][j][3] = xp[xprt[3]];
+            }
+        }
+        const bool ok = scolS[WP] >= 0 && srowS[WP] < H && p < P;
+        st_off = ok ? (unsigned)soffS[WP] : OFF_INVALID;
+        scolS[WP] += 8;
+        soffS[WP] += 32 * dirw;
+        if (scolS[WP] == W) { scolS[WP] = 0; srowS[WP] += P; soffS[WP] += rowstep - dirw * W * 4; }
+    };
+    auto sec_swrite = [&](auto wp_c, int j0, int j1) {
+        constexpr int WP = decltype(wp_c)::value;
+        if constexpr (!SEC) return;
+        const unsigned vt = st_off == OFF_INVALID ? OFF_INVALID : st_off + lane_t;
+        const unsigned vb = st_off == OFF_INVALID ? OFF_INVALID : st_off + lane_b;
+        const int cpad = C::CQP - CQ;                           // 0..3 padded channels (uniform)
+#pragma unroll
+        for (int j = 0; j < NKD; ++j) {
+            if (j < j0 || j >= j1) continue;
+            const int jj = wv * NKD + j;
+            const bool tile = jj < 4 * C::MTB;
+            // (readfirstlane: tells the compiler this is wave-uniform, or it wraps every store in a waterfall loop)
+            const int uni = __builtin_amdgcn_readfirstlane((tile ? 16 * (jj >> 2) + (jj & 3) : 16 * C::MTB + 4 * (jj - 4 * C::MTB)) * HW * 4);
+            unsigned vo = tile ? vt : vb;
+            // only a register of the last channel group can hold a padded channel
+            const bool last_group = tile ? (C::NSM == 0 && (jj >> 2) == C::MTB - 1) : jj == C::NKDT - 1;
+            if (last_group && cpad != 0) vo += cmask[j];
+            v4u v;
+            v.x = __builtin_bit_cast(unsigned, XS[WP][j][0]);
+            v.y = __builtin_bit_cast(unsigned, XS[WP][j][1]);
+            v.z = __builtin_bit_cast(unsigned, XS[WP][j][2]);
+            v.w = __builtin_bit_cast(unsigned, XS[WP][j][3]);
+            __builtin_amdgcn_raw_buffer_store_b128(v, rout, vo, uni, 0);
+        }
+    };
+
+    // ================= 16-byte pieces (W % 4 == 0 only): one group per lane and window =================
+    int lcol = 4 * fl4, lrow = p;
+    int scol = 4 * (fl4 - 2), srow = p;       // next group to store
+    int lslot = ((4 * fl4) % 12 + 12) % 12;   // z-ring slot of the next landing
+    v4u zb[NKZ];
+#pragma unroll
+    for (int j = 0; j < NKZ; ++j) zb[j] = (v4u){0u, 0u, 0u, 0u};
+    float sv[NKD][4];                         // group just read from the x ring
+    // x-ring read indices of the group to store: slot of element k = (4gs + k + p) & 7 = ((p+k)&7) ^ 4*(gs&1)
+    int stog = 256 * (fl4 & 1);               // 4 slots x 64 floats, toggled once per window (gs parity)
+    // Load offsets are kept incrementally: canonical column +4 is a constant byte step in memory, a row change another
+    // constant; the per-channel part j*4*HW*4 is uniform and rides in the buffer instruction's scalar offset.
+    int loff = ((fh ? H - 1 - lrow : lrow) * W + (fw ? W - 4 - lcol : lcol)) * 4 + (4 * wv * NKZ + q) * HW * 4;
+    auto io_issue = [&](int j0, int j1, bool advance) {
         const bool ok = lcol >= 0 && lrow < H && p < P;
         const unsigned vb = ok ? (unsigned)loff : OFF_INVALID;
 #pragma unroll
         for (int j = 0; j < NKZ; ++j) {
             if (j < j0 || j >= j1) continue;
-            zb[j][0] = __builtin_amdgcn_raw_buffer_load_b128(rin, j == NKZ - 1 ? vb + zlast : vb, j * 16 * HW, 0);
+            zb[j] = __builtin_amdgcn_raw_buffer_load_b128(rin, j == NKZ - 1 ? vb + zlast : vb, j * 16 * HW, 0);
         }
         if (advance) {
             lcol += 4;
-            loff += lstep;
-            if (lcol == W) { lcol = 0; lrow += P; loff += lwrap; }
+            loff += 16 * dirw;
+            if (lcol == W) { lcol = 0; lrow += P; loff += rowstep - dirw * W * 4; }
         }
     };
-    auto io_land = [&]() {                                   // 16-byte pieces
+    auto io_land = [&]() {
         float *b0 = zring + (lslot + k0) * 64 + lane, *b1 = zring + (lslot + k1) * 64 + lane;
         float *b2 = zring + (lslot + k2) * 64 + lane, *b3 = zring + (lslot + k3) * 64 + lane;
 #pragma unroll
         for (int j = 0; j < NKZ; ++j) {
-            const unsigned v0 = zb[j][0].x, v1 = zb[j][0].y, v2 = zb[j][0].z, v3 = zb[j][0].w;
+            const unsigned v0 = zb[j].x, v1 = zb[j].y, v2 = zb[j].z, v3 = zb[j].w;
             b0[j * C::ZSLOTS * 64] = __builtin_bit_cast(float, v0);
             b1[j * C::ZSLOTS * 64] = __builtin_bit_cast(float, v1);
             b2[j * C::ZSLOTS * 64] = __builtin_bit_cast(float, v2);
@@ -345,54 +459,14 @@ __global__ __launch_bounds__(64 * NW) void finc_wave_kernel(const float *__restr
         }
         lslot = lslot == 8 ? 0 : lslot + 4;
     };
-    auto io_event = [&]() {                   // SEC only
-        if constexpr (!SEC) return;
-        constexpr int HI = NPC - 1;           // (== 1; spelled so that the 16-byte instantiations still compile)
-        if (lph == 0) {                       // this window's parity class (divergent: the other lanes' loads stay in flight)
-            // memory piece 0 / 1 of the pair = canonical group first / second, or second / first when W-flipped
-            float *ga = zring + lslot * 64 + lane;
-            float *gb = zring + (lslot == 8 ? 0 : lslot + 4) * 64 + lane;
-            float *p0 = fw ? gb : ga, *p1 = fw ? ga : gb;
-#pragma unroll
-            for (int j = 0; j < NKZ; ++j) {
-                const unsigned a0 = zb[j][0].x, a1 = zb[j][0].y, a2 = zb[j][0].z, a3 = zb[j][0].w;
-                const unsigned c0 = zb[j][HI].x, c1 = zb[j][HI].y, c2 = zb[j][HI].z, c3 = zb[j][HI].w;
-                float *q0 = p0 + j * C::ZSLOTS * 64, *q1 = p1 + j * C::ZSLOTS * 64;
-                q0[k0 * 64] = __builtin_bit_cast(float, a0);
-                q0[k1 * 64] = __builtin_bit_cast(float, a1);
-                q0[k2 * 64] = __builtin_bit_cast(float, a2);
-                q0[k3 * 64] = __builtin_bit_cast(float, a3);
-                q1[k0 * 64] = __builtin_bit_cast(float, c0);
-                q1[k1 * 64] = __builtin_bit_cast(float, c1);
-                q1[k2 * 64] = __builtin_bit_cast(float, c2);
-                q1[k3 * 64] = __builtin_bit_cast(float, c3);
-            }
-            lslot = lslot >= 4 ? lslot - 4 : lslot + 8;   // + 8 mod 12
-            const bool ok = lcol >= 0 && lrow < H && p < P;
-            const unsigned vb = ok ? (unsigned)loff : OFF_INVALID;
-#pragma unroll
-            for (int j = 0; j < NKZ; ++j) {
-                const unsigned vo = j == NKZ - 1 ? vb + zlast : vb;
-                zb[j][0] = __builtin_amdgcn_raw_buffer_load_b128(rin, vo, j * 16 * HW, 0);
-                zb[j][HI] = __builtin_amdgcn_raw_buffer_load_b128(rin, vo + 16u, j * 16 * HW, 0);
-            }
-            lcol += 8;
-            loff += lstep;
-            if (lcol == W) { lcol = 0; lrow += P; loff += lwrap; }
-        }
-        lph ^= 1;
-    };
     auto io_sread = [&]() {
         const bool ok = scol >= 0 && srow < H && p < P;
         const int mrow = fh ? H - 1 - srow : srow;
-        // SEC: offset of the pair's memory-first piece, meaningful in the window that reads the odd group
-        const int ccol = SEC ? scol - 4 : scol;
-        const int mcol = fw ? W - (SEC ? 8 : 4) - ccol : ccol;
+        const int mcol = fw ? W - 4 - scol : scol;
         st_off = ok ? (unsigned)(mrow * W + mcol) * 4u : OFF_INVALID;
-        st_fire = !SEC || sph != 0;
         // the x ring is indexed by TIME (slot = step & 7): element k of this group was written at step 4gs+k+p
-        const float *b0 = xring + (sidx[0] ^ stog), *b1 = xring + (sidx[1] ^ stog);
-        const float *b2 = xring + (sidx[2] ^ stog), *b3 = xring + (sidx[3] ^ stog);
+        const float *b0 = xring + (xown[0] ^ stog), *b1 = xring + (xown[1] ^ stog);
+        const float *b2 = xring + (xown[2] ^ stog), *b3 = xring + (xown[3] ^ stog);
 #pragma unroll
         for (int j = 0; j < NKD; ++j) {
             sv[j][0] = b0[j * C::XSLOTS * 64];
@@ -400,20 +474,14 @@ __global__ __launch_bounds__(64 * NW) void finc_wave_kernel(const float *__restr
             sv[j][2] = b2[j * C::XSLOTS * 64];
             sv[j][3] = b3[j * C::XSLOTS * 64];
         }
-        sph ^= 1;
         stog ^= 256;
         scol += 4;
         if (scol == W) { scol = 0; srow += P; }
     };
     auto io_swrite = [&](int j0, int j1) {
-        // every lane issues; lanes whose pair is not complete (or that are off the image) drop by offset
-        const unsigned base = st_fire ? st_off : OFF_INVALID;
-        const unsigned vt = base == OFF_INVALID ? OFF_INVALID : base + lane_t;
-        const unsigned vb = base == OFF_INVALID ? OFF_INVALID : base + lane_b;
-        // (readfirstlane: tells the compiler these are wave-uniform, or it wraps every store in a waterfall loop)
-        const int o_even = __builtin_amdgcn_readfirstlane(fw ? 16 : 0);   // held (even) group / fresh (odd) group
-        const int o_odd = 16 - o_even;
-        const int cpad = C::CQP - CQ;                           // 0..3 padded channels (uniform)
+        const unsigned vt = st_off == OFF_INVALID ? OFF_INVALID : st_off + lane_t;
+        const unsigned vb = st_off == OFF_INVALID ? OFF_INVALID : st_off + lane_b;
+        const int cpad = C::CQP - CQ;
 #pragma unroll
         for (int j = 0; j < NKD; ++j) {
             if (j < j0 || j >= j1) continue;
@@ -421,7 +489,6 @@ __global__ __launch_bounds__(64 * NW) void finc_wave_kernel(const float *__restr
             const bool tile = jj < 4 * C::MTB;
             const int uni = __builtin_amdgcn_readfirstlane((tile ? 16 * (jj >> 2) + (jj & 3) : 16 * C::MTB + 4 * (jj - 4 * C::MTB)) * HW * 4);
             unsigned vo = tile ? vt : vb;
-            // only a register of the last channel group can hold a padded channel
             const bool last_group = tile ? (C::NSM == 0 && (jj >> 2) == C::MTB - 1) : jj == C::NKDT - 1;
             if (last_group && cpad != 0) vo += cmask[j];
             v4u v;
@@ -429,43 +496,36 @@ __global__ __launch_bounds__(64 * NW) void finc_wave_kernel(const float *__restr
             v.y = __builtin_bit_cast(unsigned, sv[j][1]);
             v.z = __builtin_bit_cast(unsigned, sv[j][2]);
             v.w = __builtin_bit_cast(unsigned, sv[j][3]);
-            if constexpr (SEC) {
-                v4u h;
-                h.x = __builtin_bit_cast(unsigned, sh[j][0]);
-                h.y = __builtin_bit_cast(unsigned, sh[j][1]);
-                h.z = __builtin_bit_cast(unsigned, sh[j][2]);
-                h.w = __builtin_bit_cast(unsigned, sh[j][3]);
-                __builtin_amdgcn_raw_buffer_store_b128(h, rout, vo, uni + o_even, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(v, rout, vo, uni + o_odd, 0);
-#pragma unroll
-                for (int k = 0; k < 4; ++k) sh[j][k] = st_fire ? sh[j][k] : sv[j][k]; // even group: hold it
-            } else {
-                __builtin_amdgcn_raw_buffer_store_b128(v, rout, vo, uni, 0);
-            }
+            __builtin_amdgcn_raw_buffer_store_b128(v, rout, vo, uni, 0);
         }
     };
     // the window's HBM work, spread over its 4 steps: step 0 reads the x ring; steps 1-3 store a third of the registers
-    // each; step 2 lands the loads of the previous window and re-issues the first half, step 3 the second half
+    // each; step 3 (32-byte pieces) lands and re-issues / steps 2-3 (16-byte pieces) land and issue the two halves
     constexpr int S1 = (NKD + 2) / 3, S2 = (2 * NKD + 2) / 3, L1 = (NKZ + 1) / 2;
-    auto io_phase = [&](auto ph_c) {
+    auto io_phase = [&](auto ph_c, auto wp_c) {
         constexpr int PH = decltype(ph_c)::value;
         if constexpr (FINC_ABLATE >= 1) return;
         constexpr int AB = FINC_ABLATE_IO;
-        if constexpr (PH == 0 && !(AB & 8)) io_sread();
-        if constexpr (PH == 1 && !(AB & 2)) io_swrite(0, S1);
-        if constexpr (PH == 2) {
-            if constexpr (!(AB & 2)) io_swrite(S1, S2);
-            if constexpr (!SEC && !(AB & 4)) io_land();
-            if constexpr (!SEC && !(AB & 1)) io_issue(0, L1, false);
-        }
-        if constexpr (PH == 3) {
-            if constexpr (!(AB & 2)) io_swrite(S2, NKD);
-            if constexpr (!SEC && !(AB & 1)) io_issue(L1, NKZ, true);
-            if constexpr (SEC && !(AB & 5)) io_event();
+        if constexpr (SEC) {
+            if constexpr (PH == 0 && !(AB & 8)) sec_sread(wp_c);
+            if constexpr (PH == 1 && !(AB & 2)) sec_swrite(wp_c, 0, S1);
+            if constexpr (PH == 2 && !(AB & 2)) sec_swrite(wp_c, S1, S2);
+            if constexpr (PH == 3 && !(AB & 2)) sec_swrite(wp_c, S2, NKD);
+            if constexpr (PH == 3 && !(AB & 5)) sec_event(wp_c);
+        } else {
+            if constexpr (PH == 0 && !(AB & 8)) io_sread();
+            if constexpr (PH == 1 && !(AB & 2)) io_swrite(0, S1);
+            if constexpr (PH == 2) {
+                if constexpr (!(AB & 2)) io_swrite(S1, S2);
+                if constexpr (!(AB & 4)) io_land();
+                if constexpr (!(AB & 1)) io_issue(0, L1, false);
+            }
+            if constexpr (PH == 3) {
+                if constexpr (!(AB & 2)) io_swrite(S2, NKD);
+                if constexpr (!(AB & 1)) io_issue(L1, NKZ, true);
+            }
         }
     };
-    auto io_swrite_all = [&]() { io_swrite(0, NKD); };
-    auto io_issue_all = [&]() { io_issue(0, NKZ, true); };
 
     // ---- neighbour operands --------------------------------------------------------------------
     // S_a(tau) = row_shr:a of the pixels solved at step tau (S_0 = the pixels themselves).  Tap (a,b) of step t reads
@@ -578,13 +638,13 @@ __global__ __launch_bounds__(64 * NW) void finc_wave_kernel(const float *__restr
 
     // pre-loop = the HBM side of the two windows before the first computed one
     if constexpr (SEC) {
-        io_event();  // window -4: even-fl4 lanes issue their first piece
-        io_event();  // window -3: odd-fl4 lanes
-        io_event();  // window -2: the first pieces land, the second ones leave
+        sec_event(IC<0>{});  // window -4: the first pieces of the class-0 rows leave
+        sec_event(IC<1>{});  // window -3: class 1
+        sec_event(IC<0>{});  // window -2: the first pieces land, the second ones leave
     } else {
-        io_issue_all();
+        io_issue(0, NKZ, true);
         io_land();
-        io_issue_all();  // left in flight, lands in window -1
+        io_issue(0, NKZ, true);  // left in flight, lands in window -1
     }
 
     int nslot = ((-3 - p) % 12 + 12) % 12;    // z-ring slot of the position of step t+1 ...
@@ -625,8 +685,8 @@ __global__ __launch_bounds__(64 * NW) void finc_wave_kernel(const float *__restr
         unsigned long long stamp_prev = 0;
         bool stamp_on = false;
 #endif
-        auto step = [&](auto ph_c) {
-            constexpr int PH = decltype(ph_c)::value;   // == t & 3
+        auto step = [&](auto ph_c, auto wp_c) {
+            constexpr int PH = decltype(ph_c)::value;   // == t & 3; wp_c: parity of the window (32-byte I/O)
             FINC_STAMP_AT(9);                           // segment 9: loop latch (between two steps)
             // the masks cost VALU issue that f32 MFMAs do not hide: apply them only on the steps where a lane
             // wraps (P of every W steps) / has not started yet (the first P steps); both tests are scalar
@@ -788,14 +848,14 @@ __global__ __launch_bounds__(64 * NW) void finc_wave_kernel(const float *__restr
                         finc_mma<C::MTB>(accn[mt], mt, af[FT + ((a * KW + b - 1) * NK + j) * MT + mt],
                                     ROT ? Q[a][(PH + 9 - a - b) & 3][j] : R[a][b][j]);
                 if constexpr (CI == 0) post1();
-                if constexpr (CI == (NCH > 1 ? 1 : 0)) io_phase(ph_c);
+                if constexpr (CI == (NCH > 1 ? 1 : 0)) io_phase(ph_c, wp_c);
                 if constexpr (CI == (NCH > 2 ? 2 : NCH - 1)) post2();
                 FINC_SB();
                 if constexpr (CI < 6) FINC_STAMP_AT(2 + CI); // segments 2.. : phase-B chunks (0: post1, 1: HBM I/O, 2: post2)
             };
             if constexpr (NCH == 0) {
                 post1();
-                io_phase(ph_c);
+                io_phase(ph_c, wp_c);
                 post2();
                 FINC_SB();
             } else {
@@ -817,13 +877,15 @@ __global__ __launch_bounds__(64 * NW) void finc_wave_kernel(const float *__restr
 
         // Window -4 (steps -4..-1) solves nothing: every lane is still before its first pixel.  Only its HBM side
         // and the z-term of lane 0's first pixel (phase B of step -1) matter, so it runs without the other 3.9 steps.
-        io_sread();
-        io_swrite_all();
-        if constexpr (SEC) {
-            io_event();
+        if constexpr (SEC) {                           // window -1 has parity 1
+            sec_sread(IC<1>{});
+            sec_swrite(IC<1>{}, 0, NKD);
+            sec_event(IC<1>{});
         } else {
+            io_sread();
+            io_swrite(0, NKD);
             io_land();
-            io_issue_all();
+            io_issue(0, NKZ, true);
         }
 #pragma unroll
         for (int k = 0; k < 3; ++k) {                  // steps -4, -3, -2: bookkeeping only (the FIFO ring is zero)
@@ -855,17 +917,29 @@ __global__ __launch_bounds__(64 * NW) void finc_wave_kernel(const float *__restr
             xwin ^= 256;
             fifo_advance();
         }
-        for (int t0 = 0; t0 < Tend; t0 += 4) {
+        // 32-byte I/O alternates two register sets with the window: two windows per iteration (Tend % 8 == 0)
+        for (int t0 = 0; t0 < Tend; t0 += SEC ? 8 : 4) {
 #ifdef FINC_STAMP
             stamp_on = t0 >= 64 && t0 < 192;
 #endif
-            step(IC<0>{});
-            step(IC<1>{});
-            step(IC<2>{});
-            step(IC<3>{});
+            step(IC<0>{}, IC<0>{});
+            step(IC<1>{}, IC<0>{});
+            step(IC<2>{}, IC<0>{});
+            step(IC<3>{}, IC<0>{});
+            if constexpr (SEC) {
+                step(IC<0>{}, IC<1>{});
+                step(IC<1>{}, IC<1>{});
+                step(IC<2>{}, IC<1>{});
+                step(IC<3>{}, IC<1>{});
+            }
         }
-        io_sread();
-        io_swrite_all();
+        if constexpr (SEC) {                           // window Tend/4 (parity 0): the last pieces leave
+            sec_sread(IC<0>{});
+            sec_swrite(IC<0>{}, 0, NKD);
+        } else {
+            io_sread();
+            io_swrite(0, NKD);
+        }
 #ifdef FINC_STAMP
         if (blockIdx.x == 517 && threadIdx.x == 0) {
 #pragma unroll
@@ -1038,7 +1112,7 @@ int finc_mfma_launch(const float *in, const void *packed, float *out, const Finc
     if (((uintptr_t)in & 15u) || ((uintptr_t)out & 15u)) return FINC_ERR_ALIGNMENT;
     const int P = s.W < 16 ? s.W : 16;
     const int NB = (s.H + P - 1) / P;
-    const int Tend = (NB * s.W + P - 1 + 3) / 4 * 4;
+    const int Tend = s.W % 8 == 0 ? (NB * s.W + P - 1 + 7) / 8 * 8 : (NB * s.W + P - 1 + 3) / 4 * 4;  // 32-byte I/O: x8 loop
     const size_t lds = lds_bytes(*i, s.W, P);
     const wave_fn fn = (s.W % 8 == 0) ? i->fn_sec : i->fn;
     static thread_local const void *attr_done[128];

@@ -154,7 +154,7 @@ def run(inp, wc, fwd=False, scale=None, shift=None):
     P = min(16, W)
     assert P >= KH - 1
     NB = (H + P - 1) // P
-    Tend = (NB * W + P - 1 + 3) // 4 * 4
+    Tend = (NB * W + P - 1 + 7) // 8 * 8 if W % 8 == 0 else (NB * W + P - 1 + 3) // 4 * 4   # SEC: the loop is unrolled x8
     D = W - P + 1
     fr = pack_fragments(wc, CQP, fwd, scale, shift)
     out = np.full((CQ, H, W), np.nan)
@@ -198,64 +198,131 @@ def run(inp, wc, fwd=False, scale=None, shift=None):
         lcol = np.where(wrap, 0, lcol)
         lrow = np.where(wrap, lrow + P, lrow)
 
+    # ---- SEC (32-byte pieces), lane-pair I/O ---------------------------------------------------------------------
+    # Rows of a band fall into two classes by the parity of ceil(row/4): a row's 32-byte piece (two 4-column groups)
+    # is due every other window, class c rows in windows of parity c.  In such a window EVERY lane moves one 16-byte
+    # half: the lanes of a class-c row its first group, the lanes of the partner row (the i-th row of the other
+    # class) its second group -- so each memory instruction has all 64 lanes busy on 32 whole pieces, and the two
+    # register sets (loads: Z[parity], stores: XS[parity]) alternate with the window (the loop is unrolled x8).
+    rows0 = [r for r in range(P) if (((r + 3) >> 2) & 1) == 0]
+    rows1 = [r for r in range(P) if (((r + 3) >> 2) & 1) == 1]
+    assert not SEC or len(rows0) == len(rows1)
+    partner = {}
+    for a_, b_ in zip(rows0, rows1):
+        partner[a_], partner[b_] = b_, a_
+    cls = ((p + 3) >> 2) & 1
+    svrow = np.full((2, LANES), -1)
+    half = np.zeros((2, LANES), int)
+    for lane in range(LANES):
+        if SEC and p[lane] < P:
+            for wp in (0, 1):
+                own = cls[lane] == wp
+                svrow[wp, lane] = p[lane] if own else partner[int(p[lane])]
+                half[wp, lane] = 0 if own else 1
+    fl4r = -((svrow + 3) >> 2)                       # of the service row
+    e0 = np.array([-4, -3])                          # first event window of class 0 / 1
+    lcolS = np.stack([4 * (e0[wp] + 4 + fl4r[wp]) for wp in (0, 1)])
+    lrowS = svrow.copy()
+    lslotS = np.stack([(4 * ((e0[wp] + 2 + fl4r[wp]) % 3)) for wp in (0, 1)])
+    Z = np.zeros((2, NKZ, 4, LANES))
+    # stores: stream wp = the class-wp row a lane serves; pair base column at its first fire window (class 1: -1, class 0: 0)
+    f0 = np.array([0, -1])
+    scolS = np.stack([4 * (f0[wp] - 2 + fl4r[wp]) for wp in (0, 1)])
+    srowS = svrow.copy()
+    XS = np.full((2, NKD, 4, LANES), np.nan)
+    st2 = dict(ok=np.zeros(LANES, bool), row=np.zeros(LANES, int), col=np.zeros(LANES, int), par=0)
+    win = [-4]                                       # window counter of the event stream (the pre-loop runs -4, -3, -2)
+
     def io_event():
-        """SEC: one parity class per window lands BOTH groups of the piece issued two windows ago, then issues the next."""
-        nonlocal lcol, lrow, lph, lslot
+        u = win[0]
+        wp = u & 1
         for lane in range(LANES):
-            if lph[lane] != 0:
+            R_ = svrow[wp, lane]
+            if R_ < 0:
                 continue
-            sa = lslot[lane]
-            sb_ = 0 if sa == 8 else sa + 4
+            h = half[wp, lane]
+            sl = (lslotS[wp, lane] + 4 * h) % 12
+            dst = q[lane] * 16 + R_
             for j in range(NKZ):
                 for k in range(4):
-                    zring[j, sa + k, lane] = zb[j, 0, k, lane]
-                    zring[j, sb_ + k, lane] = zb[j, 1, k, lane]
-            lslot[lane] = sa - 4 if sa >= 4 else sa + 8
-            ok = lcol[lane] >= 0 and lrow[lane] < H and p[lane] < P
+                    zring[j, sl + k, dst] = Z[wp, j, k, lane]
+            lslotS[wp, lane] = (lslotS[wp, lane] + 8) % 12
+            c0 = lcolS[wp, lane]
+            ok = c0 >= 0 and lrowS[wp, lane] < H
             for j in range(NKZ):
                 ch = 4 * j + q[lane]
-                for m in range(2):
-                    for k in range(4):
-                        zb[j, m, k, lane] = inp[ch, lrow[lane], lcol[lane] + 4 * m + k] if (ok and ch < CQ) else 0.0
-            lcol[lane] += 8
-            if lcol[lane] == W:
-                lcol[lane] = 0
-                lrow[lane] += P
-        lph = lph ^ 1
+                for k in range(4):
+                    Z[wp, j, k, lane] = inp[ch, lrowS[wp, lane], c0 + 4 * h + k] if (ok and ch < CQ) else 0.0
+            lcolS[wp, lane] += 8
+            if lcolS[wp, lane] == W:
+                lcolS[wp, lane] = 0
+                lrowS[wp, lane] += P
+        win[0] += 1
 
-    sh = np.zeros((NKD, 4, LANES))        # SEC: the even group, held one window
-    sph = fl4 & 1
+    swin = [-1]                                      # window counter of the store stream (first: the prologue, -1)
 
     def io_sread():
-        nonlocal scol, srow, sslot, sph
+        if not SEC:
+            return io_sread16()
+        u = swin[0]
+        c_ = u & 1                                   # the class that fires in this window
+        for lane in range(LANES):
+            if p[lane] >= P:
+                st2["ok"][lane] = False
+                continue
+            T = svrow[c_, lane]
+            h = half[c_, lane]
+            if cls[lane] != c_:
+                own = cls[lane]                      # own row: stream `own`, first group of its NEXT pair -> held
+                oc = scolS[own, lane]
+                for j in range(NKD):
+                    for k in range(4):
+                        XS[(u + 1) & 1, j, k, lane] = xring[j, (oc + k) & 7, q[lane] * 16 + p[lane]]
+                        XS[u & 1, j, k, lane] = xring[j, (scolS[c_, lane] + 4 + k) & 7, q[lane] * 16 + T]
+            st2["ok"][lane] = scolS[c_, lane] >= 0 and srowS[c_, lane] < H
+            st2["row"][lane] = srowS[c_, lane]
+            st2["col"][lane] = scolS[c_, lane] + 4 * h
+            scolS[c_, lane] += 8
+            if scolS[c_, lane] == W:
+                scolS[c_, lane] = 0
+                srowS[c_, lane] += P
+        st2["par"] = u & 1
+        swin[0] += 1
+
+    def io_swrite():
+        if not SEC:
+            return io_swrite16()
+        for lane in range(LANES):
+            if st2["ok"][lane]:
+                for j in range(NKD):
+                    ch = chan_d(MTB, j, q[lane])
+                    if ch < CQ:
+                        for k in range(4):
+                            out[ch, st2["row"][lane], st2["col"][lane] + k] = XS[st2["par"], j, k, lane]
+
+    sph = fl4 & 1
+
+    def io_sread16():
+        nonlocal scol, srow, sslot
         st["ok"] = (scol >= 0) & (srow < H) & (p < P)
-        st["row"], st["col"] = srow.copy(), (scol - 4 if SEC else scol)
-        st["fire"] = (sph != 0) if SEC else np.ones(LANES, bool)
+        st["row"], st["col"] = srow.copy(), scol
         for j in range(NKD):
             for k in range(4):
                 sv[j, k] = xring[j, sslot + k, lanes]
-        sph = sph ^ 1
         sslot = sslot ^ 4
         scol = scol + 4
         wrap = scol == W
         scol = np.where(wrap, 0, scol)
         srow = np.where(wrap, srow + P, srow)
 
-    def io_swrite():
+    def io_swrite16():
         for lane in range(LANES):
-            if st["fire"][lane]:
-                if st["ok"][lane]:
-                    for j in range(NKD):
-                        ch = chan_d(MTB, j, q[lane])
-                        if ch < CQ:
-                            for k in range(4):
-                                if SEC:
-                                    out[ch, st["row"][lane], st["col"][lane] + k] = sh[j, k, lane]
-                                    out[ch, st["row"][lane], st["col"][lane] + 4 + k] = sv[j, k, lane]
-                                else:
-                                    out[ch, st["row"][lane], st["col"][lane] + k] = sv[j, k, lane]
-            else:
-                sh[:, :, lane] = sv[:, :, lane]
+            if st["ok"][lane]:
+                for j in range(NKD):
+                    ch = chan_d(MTB, j, q[lane])
+                    if ch < CQ:
+                        for k in range(4):
+                            out[ch, st["row"][lane], st["col"][lane] + k] = sv[j, k, lane]
 
     def io_phase(ph):
         if SEC:
