@@ -761,8 +761,9 @@ __global__ __launch_bounds__(64 * NW) void finc_wave_kernel(const float *__restr
             }
             FINC_SB();
             // ---- RB0: z-term of the next step
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) accn[mt] = bias[mt];
+            // The accumulators of the next pixel start from the bias: it is the C operand of the first z-term MFMA of
+            // every tile (k-step 0 is never a structural zero), so the start costs no instruction.  Both branches define
+            // accn by that MFMA -- a select on accn itself would make the common path copy the bias every step.
             if (__builtin_expect(any_idle, 0)) {
                 // a lane that has not started must keep producing exact zeros: its "pixels" are what lane p+1 and, through
                 // the FIFO, the first band's lanes 0..KH-2 read as the (non-existent) rows above the image
@@ -772,10 +773,17 @@ __global__ __launch_bounds__(64 * NW) void finc_wave_kernel(const float *__restr
                 for (int mt = 0; mt < MT; ++mt) {
                     const float b0 = bias[mt].x, b1 = bias[mt].y, b2 = bias[mt].z, b3 = bias[mt].w;
                     accn[mt] = (v4f){started ? b0 : 0.f, started ? b1 : 0.f, started ? b2 : 0.f, started ? b3 : 0.f};
+                    finc_mma<C::MTB>(accn[mt], mt, af[FZ + mt], zv[0]);
+                }
+            } else {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    accn[mt] = bias[mt];
+                    finc_mma<C::MTB>(accn[mt], mt, af[FZ + mt], zv[0]);
                 }
             }
 #pragma unroll
-            for (int j = 0; j < NKZ; ++j)
+            for (int j = 1; j < NKZ; ++j)
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     if (NW == 1 && finc_zterm_is_zero(C::MTB, j, mt)) continue;   // Linv is lower triangular
