@@ -2,7 +2,9 @@
 
 It re-enacts, step by step and lane by lane, the schedule of `finc_wave_kernel`
 for ONE (image, group) problem in canonical orientation: the skewed row-per-lane
-wavefront, the z / x LDS rings with their 4-step I/O cadence, the DPP row_shr
+wavefront, the z / x LDS rings with their 4-step I/O cadence (16-byte pieces, or the lane-pair
+streams of 32-byte pieces: every lane moves one half of a due piece per window and LDS
+redistributes it to the owner lane), the DPP row_shr
 neighbour exchange, the band hand-over FIFO, the accumulator -> operand packing (16-row
 tiles as they are, 4-row blocks through the permlane transpose-reduce) and
 the fragment layout produced by `pack_kernel`.  The MFMA itself is modelled as
