@@ -450,9 +450,12 @@ constexpr ConvInst make_conv()
                         nullptr};
 }
 const ConvInst g_conv[] = {
-    make_conv<4, 3, 3>(),  make_conv<8, 3, 3>(),  make_conv<12, 3, 3>(), make_conv<16, 3, 3>(), make_conv<24, 3, 3>(),
-    make_conv<32, 3, 3>(), make_conv<48, 3, 3, 2>(), make_conv<48, 5, 5, 4>(), make_conv<4, 2, 2>(),  make_conv<16, 2, 2>(), make_conv<4, 5, 5>(),
-    make_conv<16, 5, 5>(), make_conv<4, 3, 5>(),  make_conv<4, 1, 3>(),  make_conv<4, 3, 1>(),
+    make_conv<4, 3, 3>(),  make_conv<8, 3, 3>(),  make_conv<12, 3, 3>(), make_conv<16, 3, 3>(), make_conv<20, 3, 3>(),
+    make_conv<24, 3, 3>(), make_conv<28, 3, 3>(), make_conv<32, 3, 3>(), make_conv<48, 3, 3, 2>(), make_conv<64, 3, 3, 4>(),
+    make_conv<4, 2, 2>(),  make_conv<8, 2, 2>(),  make_conv<12, 2, 2>(), make_conv<16, 2, 2>(), make_conv<24, 2, 2>(),
+    make_conv<32, 2, 2>(),
+    make_conv<4, 5, 5>(),  make_conv<8, 5, 5>(),  make_conv<12, 5, 5>(), make_conv<16, 5, 5>(), make_conv<48, 5, 5, 4>(),
+    make_conv<4, 3, 5>(),  make_conv<4, 1, 3>(),  make_conv<4, 3, 1>(),
 };
 const ConvInst *find_conv(int Cq, int KH, int KW)
 {

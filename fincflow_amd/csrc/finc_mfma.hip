@@ -1050,12 +1050,14 @@ constexpr Inst make_inst()
 #define FINC_BOTH(cqp, kh, kw) make_inst<cqp, kh, kw>()
 
 const Inst g_insts[] = {
-    FINC_BOTH(4, 3, 3),  FINC_BOTH(8, 3, 3),  FINC_BOTH(12, 3, 3), FINC_BOTH(16, 3, 3),
-    FINC_BOTH(24, 3, 3), FINC_BOTH(32, 3, 3),
-    FINC_BOTH(4, 2, 2),  FINC_BOTH(16, 2, 2),
-    FINC_BOTH(4, 5, 5),  FINC_BOTH(16, 5, 5),
+    // 3x3: every Cq % 4 == 0 up to 32, then K-split (2 / 4 waves per problem) for the banks one wave cannot hold
+    FINC_BOTH(4, 3, 3),  FINC_BOTH(8, 3, 3),  FINC_BOTH(12, 3, 3), FINC_BOTH(16, 3, 3), FINC_BOTH(20, 3, 3),
+    FINC_BOTH(24, 3, 3), FINC_BOTH(28, 3, 3), FINC_BOTH(32, 3, 3),
+    make_inst<40, 3, 3, 2>(), make_inst<48, 3, 3, 2>(), make_inst<64, 3, 3, 4>(),
+    FINC_BOTH(4, 2, 2),  FINC_BOTH(8, 2, 2),  FINC_BOTH(12, 2, 2), FINC_BOTH(16, 2, 2), FINC_BOTH(24, 2, 2), FINC_BOTH(32, 2, 2),
+    FINC_BOTH(4, 5, 5),  FINC_BOTH(8, 5, 5),  FINC_BOTH(12, 5, 5), FINC_BOTH(16, 5, 5),
+    make_inst<32, 5, 5, 4>(), make_inst<48, 5, 5, 4>(),
     FINC_BOTH(4, 3, 5),
-    make_inst<48, 3, 3, 2>(), make_inst<48, 5, 5, 4>(), make_inst<32, 5, 5, 4>(),
 };
 
 const Inst *find_inst(int Cq, int KH, int KW)

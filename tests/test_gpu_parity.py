@@ -524,3 +524,28 @@ def test_affine_fold_into_the_inverse(shape, dev):
         b2 = seq._reverse_chain(zz, None)
     assert rel_err(a2.cpu().numpy(), b2.cpu().numpy()) <= TOL
     assert rel_err(a2.cpu().numpy(), a.cpu().numpy()) > 1e-3
+
+
+@pytest.mark.parametrize("cfg", [(20, 3, 0.05), (28, 3, 0.04), (40, 3, 0.03), (64, 3, 0.02), (8, 2, 0.05), (12, 2, 0.05), (24, 2, 0.05),
+                                 (32, 2, 0.05), (8, 5, 0.03), (12, 5, 0.03)])
+def test_wider_instantiation_table(cfg, dev):
+    """Every (Cq, K) of the instantiation table beyond the reference's own model shapes: one- and K-split waves, 16-row
+    tiles mixed with 1-3 four-row blocks.  Inverse on the MFMA path (32-byte and 16-byte I/O variants), forward, and
+    the strict kernel's bit-exactness, all against the oracle."""
+    from fincflow_amd import _lib, ops
+    Cq, K, std = cfg
+    L = _lib.lib()
+    for (B, H, W) in ((2, 19, 24), (1, 9, 20)):          # W % 8 == 0 and W % 8 == 4
+        assert L.finc_inverse_algo_for(Cq, H, W, K, K) == _lib.ALGO["mfma"]
+        rng = np.random.default_rng(Cq * 10 + K + W)
+        ws = oracle.make_stored_weights(4, Cq, K, K, seed=Cq + K, std=std)
+        wco = oracle.canonicalize(ws, 4, ORIENT_FASTFLOW)
+        x = rng.standard_normal((B, 4 * Cq, H, W)).astype(np.float32)
+        z = oracle.forward_f32(x, wco)
+        ref, ref32 = oracle.inverse_via_f64(z, wco), oracle.inverse_f32(z, wco)
+        tol = max(TOL, 2.0 * rel_err(ref32, ref))        # the reference's own fp32-vs-fp64 gap where the bank is stiff
+        wc = canon(ws, 4, ORIENT_FASTFLOW, dev)
+        auto = ops.finc_inverse(t(z, dev), wc, algo="auto").cpu().numpy()
+        assert rel_err(auto, ref) <= tol
+        assert np.array_equal(ops.finc_inverse(t(z, dev), wc, algo="strict").cpu().numpy(), ref32)
+        assert rel_err(ops.finc_forward(t(x, dev), wc, algo="auto").cpu().numpy(), z) <= TOL
