@@ -59,11 +59,11 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 1
                                                             int G, int CQ, int H, int W, int NS, unsigned orient)
 {
     constexpr int MTB = CQP / 16, NSM = (CQP % 16) / 4, MT = MTB + NSM, NKZT = CQP / 4, NTAP = KH * KW;
-    static_assert(NW == 1 || (NSM == 0 && NKZT % NW == 0 && (MT * 4) % NW == 0),
-                  "K-split needs full tiles and must divide the k-steps and the output registers");
+    constexpr int NOUT = 4 * MTB + NSM;                   // output registers of a row: 4 per 16-row tile, 1 per reduced block
+    static_assert(NW == 1 || (NKZT % NW == 0 && NOUT % NW == 0), "K-split must divide the k-steps and the output registers");
     constexpr int NKZ = NKZT / NW;                        // k-steps this wave owns
     constexpr int NFRAG = NTAP * NKZ * MT;                // fragments this wave holds
-    constexpr int DREG = MT * 4 / NW;                     // output registers this wave finalises and stores
+    constexpr int DREG = (4 * (CQP / 16) + (CQP % 16) / 4) / NW; // output registers this wave finalises and stores
     __shared__ float xch[NW > 1 ? 2 * NW * NW * DREG * 64 : 1]; // [parity][dst wave][src wave][reg][lane]
     const int wv = NW > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
     const int lane = threadIdx.x & 63;
@@ -120,15 +120,13 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 1
 #pragma unroll
     for (int r = 0; r < 4; ++r)
         lo_tail[r] = (colok && 16 * (MTB - 1) + 4 * q + r < CQ) ? coloff + 4u * qoff : OFF_BAD_CHANNEL;
-    unsigned lout[NW > 1 ? MT : 1][4];                    // K-split store path: per-register lane offsets
+    unsigned lout[NW > 1 ? 4 * MTB + NSM : 1];            // K-split store path: per-register lane offsets
     if constexpr (NW > 1) {
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int c = 16 * mt + 4 * q + r;
-                lout[mt][r] = (colok && c < CQ) ? coloff + (unsigned)c * HW * 4u : OFF_BAD_CHANNEL;
-            }
+        for (int d = 0; d < 4 * MTB + NSM; ++d) {
+            const int c = d < 4 * MTB ? 16 * (d >> 2) + 4 * q + (d & 3) : 16 * MTB + 4 * (d - 4 * MTB) + q;
+            lout[d] = (colok && c < CQ) ? coloff + (unsigned)c * HW * 4u : OFF_BAD_CHANNEL;
+        }
     }
     auto rowoff = [&](int h) {                            // scalar
         return (h >= 0 && h < H) ? (unsigned)((fh ? H - 1 - h : h) * W) * 4u : OFF_INVALID;
@@ -186,15 +184,17 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 1
         } else {
             // exchange: register d of the output belongs to wave d / DREG; everybody ships the registers it does not
             // own, one barrier, the owner adds the NW-1 partials it received and stores (double-buffered by parity)
-            float vv[MT * 4];
+            float vv[NOUT];                               // partial sums; a 4-row block is reduced first (linear)
 #pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
+            for (int mt = 0; mt < MTB; ++mt) {
                 const float v0 = ac[mt].x, v1 = ac[mt].y, v2 = ac[mt].z, v3 = ac[mt].w;
                 vv[4 * mt + 0] = v0; vv[4 * mt + 1] = v1; vv[4 * mt + 2] = v2; vv[4 * mt + 3] = v3;
             }
+#pragma unroll
+            for (int sb = 0; sb < NSM; ++sb) vv[4 * MTB + sb] = finc_block_reduce(ac[MTB + sb]);
             float *xb = xch + parity * (NW * NW * DREG * 64);
 #pragma unroll
-            for (int d = 0; d < MT * 4; ++d) {
+            for (int d = 0; d < NOUT; ++d) {
                 const int dst = d / DREG;
                 if (dst != wv) xb[((dst * NW + wv) * DREG + d % DREG) * 64 + lane] = vv[d];
             }
@@ -203,15 +203,15 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 1
             for (int dl = 0; dl < DREG; ++dl) {
                 float sum = 0.f;
 #pragma unroll
-                for (int d = 0; d < MT * 4; ++d)
+                for (int d = 0; d < NOUT; ++d)
                     if (d / DREG == wv && d % DREG == dl) sum = vv[d];       // own partial (wv is wave-uniform)
 #pragma unroll
                 for (int src = 0; src < NW; ++src)
                     if (src != wv) sum += xb[((wv * NW + src) * DREG + dl) * 64 + lane];
                 unsigned off = OFF_BAD_CHANNEL;
 #pragma unroll
-                for (int d = 0; d < MT * 4; ++d)
-                    if (d / DREG == wv && d % DREG == dl) off = lout[d / 4][d % 4];
+                for (int d = 0; d < NOUT; ++d)
+                    if (d / DREG == wv && d % DREG == dl) off = lout[d];
                 __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, sum), rout, ro + off, 0, 0);
             }
             parity ^= 1;
@@ -451,7 +451,7 @@ constexpr ConvInst make_conv()
 }
 const ConvInst g_conv[] = {
     make_conv<4, 3, 3>(),  make_conv<8, 3, 3>(),  make_conv<12, 3, 3>(), make_conv<16, 3, 3>(), make_conv<20, 3, 3>(),
-    make_conv<24, 3, 3>(), make_conv<28, 3, 3>(), make_conv<32, 3, 3>(), make_conv<48, 3, 3, 2>(), make_conv<64, 3, 3, 4>(),
+    make_conv<24, 3, 3>(), make_conv<28, 3, 3>(), make_conv<32, 3, 3>(), make_conv<40, 3, 3, 2>(), make_conv<48, 3, 3, 2>(), make_conv<64, 3, 3, 4>(),
     make_conv<4, 2, 2>(),  make_conv<8, 2, 2>(),  make_conv<12, 2, 2>(), make_conv<16, 2, 2>(), make_conv<24, 2, 2>(),
     make_conv<32, 2, 2>(),
     make_conv<4, 5, 5>(),  make_conv<8, 5, 5>(),  make_conv<12, 5, 5>(), make_conv<16, 5, 5>(), make_conv<48, 5, 5, 4>(),
