@@ -29,9 +29,11 @@
 //   * only the taps with a+b == 1 depend on the pixel solved in the previous
 //     step; every other MFMA of step t+1 is issued while step t's result is
 //     still being post-processed.
-//   * HBM traffic: every lane streams its row with 16-byte loads / stores that
-//     are staged through per-lane LDS rings, because lane p is (t-p) mod 4
-//     into its 4-column group.
+//   * HBM traffic: 16-byte loads / stores staged through per-lane LDS rings
+//     (lane p is (t-p) mod 4 into its 4-column group, so per-lane LDS
+//     addressing does the de-skew).  When W % 8 == 0 the unit is the aligned
+//     32-byte piece and every lane moves one half of a due piece per window,
+//     for its own row or for a partner row ("lane-pair I/O", below).
 //
 // The forward has no recurrence and uses a different, simpler mapping: finc_conv.hip.
 #include "finc_common.h"
@@ -191,9 +193,9 @@ constexpr unsigned OFF_BAD_CHANNEL = 0x40000000u; // added to a valid offset it 
 //
 // A step is cut into scheduling regions by sched_barrier(0); every region holds a block of
 // independent MFMAs plus side work (LDS traffic, DPP shifts, masks, HBM loads/stores) whose inputs
-// were produced at least one region earlier, so the in-order wave never waits and the side work
-// issues in the shadow of the 32-cycle MFMAs.  The loop is unrolled x4 so the 4-step I/O cadence
-// (read x ring / store / land z / issue loads) falls on fixed steps.
+// were produced at least one region earlier, so the in-order wave never waits on them.  The loop is
+// unrolled x4 (x8 with 32-byte I/O) so the 4-step I/O cadence (read x ring / store / land z and issue
+// loads) and the alternation of the I/O register sets fall on fixed steps.
 // -----------------------------------------------------------------------------------------------
 template <int CQP, int KH, int KW, bool SEC, int NW = 1>
 __global__ __launch_bounds__(64 * NW) void finc_wave_kernel(const float *__restrict__ in,
