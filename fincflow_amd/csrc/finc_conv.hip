@@ -51,10 +51,16 @@ __device__ inline float row_shl(float src)
 // tap -- 1/NW of the fragments and of the input rows -- and the partial output tiles are summed through LDS once per
 // row.  That is how a filter bank that does not fit one wave's registers (Cq=48, 5x5: 900 fragments) still runs with
 // every fragment register-resident.
-// Two waves per SIMD (256 registers each) is what hides one wave's loads, stores and VALU behind the other's MFMAs:
-// single-wave workgroups ask for that register budget (the K-split variants keep theirs: their waves are many).
+// fragments one wave of the strip kernel keeps in registers
 template <int CQP, int KH, int KW, int NW>
-__global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 1 ? 2 : 1))) void finc_conv_kernel(const float *__restrict__ in,
+constexpr int conv_nfrag() { return KH * KW * (CQP / 4 / NW) * (CQP / 16 + (CQP % 16) / 4); }
+
+// Two waves per SIMD (256 registers each) is what hides one wave's loads, stores and VALU behind the other's MFMAs:
+// single-wave workgroups ask for that register budget when the bank leaves room for the working set (a 252-fragment
+// bank squeezed into 256 registers spills: 10x slower); the K-split variants keep theirs (their waves are many).
+template <int CQP, int KH, int KW, int NW>
+__global__ __launch_bounds__(64 * NW)
+    __attribute__((amdgpu_waves_per_eu(NW == 1 && conv_nfrag<CQP, KH, KW, NW>() <= 176 ? 2 : 1))) void finc_conv_kernel(const float *__restrict__ in,
                                                             const float *__restrict__ packed, float *__restrict__ out,
                                                             int G, int CQ, int H, int W, int NS, unsigned orient)
 {
@@ -91,7 +97,7 @@ __global__ __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(NW == 1
         }
         // MFMA A operands: keep them out of the VGPRs.  With the 256-register budget the files are split 128 : 128, so
         // a bank larger than that pins what fits and leaves the rest to the allocator.
-        constexpr int NPIN = (NW == 1 && NFRAG > 124) ? 124 : NFRAG;
+        constexpr int NPIN = (NW == 1 && NFRAG > 124 && NFRAG <= 176) ? 124 : NFRAG;
 #pragma unroll
         for (int f = 0; f < NPIN; ++f) asm volatile("" : "+a"(af[f]));
     }
