@@ -62,7 +62,8 @@ template <int CQP, int KH, int KW, int NW>
 __global__ __launch_bounds__(64 * NW)
     __attribute__((amdgpu_waves_per_eu(NW == 1 && conv_nfrag<CQP, KH, KW, NW>() <= 176 ? 2 : 1))) void finc_conv_kernel(const float *__restrict__ in,
                                                             const float *__restrict__ packed, float *__restrict__ out,
-                                                            int G, int CQ, int H, int W, int NS, unsigned orient)
+                                                            int G, int CQ, int H, int W, int NS, int RC,
+                                                            unsigned orient)
 {
     constexpr int MTB = CQP / 16, NSM = (CQP % 16) / 4, MT = MTB + NSM, NKZT = CQP / 4, NTAP = KH * KW;
     constexpr int NOUT = 4 * MTB + NSM;                   // output registers of a row: 4 per 16-row tile, 1 per reduced block
@@ -137,6 +138,13 @@ __global__ __launch_bounds__(64 * NW)
     auto rowoff = [&](int h) {                            // scalar
         return (h >= 0 && h < H) ? (unsigned)((fh ? H - 1 - h : h) * W) * 4u : OFF_INVALID;
     };
+    // Row chunks (blockIdx.y): a small problem set has too few strips to fill the chip and each strip walk is a chain of
+    // row-load latencies, so the host cuts the walk into chunks of RC rows.  A chunk starts KH-1 rows early (those
+    // steps only fill the operand slots; their results are not stored) at a multiple of KH (the slot rotation).
+    const int r0 = blockIdx.y * RC, r1 = r0 + RC < H ? r0 + RC : H;
+    auto rowoff_st = [&](int h) {                         // scalar: rows this chunk owns
+        return (h >= r0 && h < r1) ? (unsigned)((fh ? H - 1 - h : h) * W) * 4u : OFF_INVALID;
+    };
 
     float X[KH][KW][NKZ];                                 // X[s][b]: row slot s, shifted b columns
 #pragma unroll
@@ -168,7 +176,7 @@ __global__ __launch_bounds__(64 * NW)
 
     int parity = 0;
     auto store_row = [&](const v4f (&ac)[MT], int h) {   // h = the row those accumulators belong to
-        const unsigned ro = rowoff(h);
+        const unsigned ro = rowoff_st(h);
         if constexpr (NW == 1) {
             const unsigned vb = ro + lo_base;
 #pragma unroll
@@ -264,8 +272,10 @@ __global__ __launch_bounds__(64 * NW)
         for (int mt = 0; mt < MT; ++mt) acc[S][mt] = ac[mt];
     };
 
-    issue(0);
-    for (int h0 = 0; h0 < H + 1; h0 += KH) {
+    int hs = r0 - (KH - 1);
+    hs = hs >= 0 ? hs / KH * KH : -((-hs + KH - 1) / KH * KH);   // floor to a multiple of KH
+    issue(hs);
+    for (int h0 = hs; h0 < r1 + 1; h0 += KH) {
         [&]<int... I>(std::integer_sequence<int, I...>) { (step(IC<I>{}, h0 + I), ...); }
         (std::make_integer_sequence<int, KH>{});
     }
@@ -435,7 +445,7 @@ __global__ void conv_pack_kernel(const float *__restrict__ wc, float *__restrict
     }
 }
 
-typedef void (*conv_fn)(const float *, const float *, float *, int, int, int, int, int, unsigned);
+typedef void (*conv_fn)(const float *, const float *, float *, int, int, int, int, int, int, unsigned);
 typedef void (*gradw_fn)(const float *, const float *, float *, int, int, int, int, int, int, int, unsigned);
 struct ConvInst {
     int cqp, kh, kw;
@@ -533,8 +543,15 @@ int finc_conv_launch(const float *in, const void *packed, float *out, const Finc
     const ConvInst *i = find_conv(s.Cq, s.KH, s.KW);
     if (!i || !finc_conv_supported(s.Cq, s.H, s.W, s.KH, s.KW)) return FINC_ERR_UNSUPPORTED;
     const int NS = (s.W + 15) / 16;
-    hipLaunchKernelGGL(i->fn, dim3(s.B * s.G * NS), dim3(64 * i->nw), 0, st, in, (const float *)packed, out, s.G, s.Cq, s.H,
-                       s.W, NS, s.orient);
+    // about one wave per SIMD (measured: more chunks than that cost more in per-wave bank loads than they gain; 2 chunks
+    // still pay up to 2 waves per SIMD), in chunks of at least 4 rows (every chunk recomputes KH-1 rows of operands)
+    const long long waves = (long long)s.B * s.G * NS * i->nw;
+    int nrc = waves >= 2048 ? 1 : waves >= 1024 ? 2 : (int)((1024 + waves - 1) / waves);
+    if (nrc > s.H / 4) nrc = s.H / 4 > 0 ? s.H / 4 : 1;
+    const int RC = (s.H + nrc - 1) / nrc;
+    nrc = (s.H + RC - 1) / RC;
+    hipLaunchKernelGGL(i->fn, dim3(s.B * s.G * NS, nrc), dim3(64 * i->nw), 0, st, in, (const float *)packed, out, s.G, s.Cq,
+                       s.H, s.W, NS, RC, s.orient);
     FINC_CHECK_LAUNCH();
     return FINC_OK;
 }
