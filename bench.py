@@ -253,7 +253,7 @@ def main():
         inv_gbs = alg_bytes / (inv_launch_ms * 1e-3) / 1e9
         traffic = load_traffic(args.workload)
         line = {
-            "metric": "inverse images/sec (FastFlowUnit 3x3 @64x64x96)" if args.workload == "c3"
+            "metric": "inverse images/sec (+ fwd+logdet ms/img in `forward`), 3x3 conv @64x64x96" if args.workload == "c3"
                       else f"inverse images/sec (FastFlowUnit, workload {args.workload})",
             "value": world * B * args.steps / inv_dt,
             "unit": "images/s",
