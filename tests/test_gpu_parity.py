@@ -554,3 +554,26 @@ def test_wider_instantiation_table(cfg, dev):
         assert rel_err(auto, ref) <= tol
         assert np.array_equal(ops.finc_inverse(t(z, dev), wc, algo="strict").cpu().numpy(), ref32)
         assert rel_err(ops.finc_forward(t(x, dev), wc, algo="auto").cpu().numpy(), z) <= TOL
+
+
+def test_unaligned_activations_fall_back(dev):
+    """A 4-byte aligned (not 16-byte aligned) activation pointer: FINC_ALGO_AUTO takes the strict kernel instead of failing
+    (the MFMA inverse streams 16-byte pieces); asking for the MFMA kernel explicitly reports the alignment."""
+    from fincflow_amd import _lib, ops
+    L = _lib.lib()
+    B, C, H, W, K = 2, 16, 8, 8, 3
+    ws = oracle.make_stored_weights(4, C // 4, K, K, seed=5)
+    wco = oracle.canonicalize(ws, 4, ORIENT_FASTFLOW)
+    wc = canon(ws, 4, ORIENT_FASTFLOW, dev)
+    z = np.random.default_rng(5).standard_normal((B, C, H, W)).astype(np.float32)
+    n = z.size
+    zbuf = torch.zeros(n + 8, device=dev)
+    xbuf = torch.zeros(n + 8, device=dev)
+    zbuf[1:n + 1] = torch.from_numpy(z).to(dev).flatten()                 # data starts 4 bytes into the allocation
+    wsb = torch.empty(L.finc_inverse_workspace_bytes(B, 4, C // 4, H, W, K, K), dtype=torch.uint8, device=dev)
+    args = (zbuf.data_ptr() + 4, wc.data_ptr(), xbuf.data_ptr() + 4, B, 4, C // 4, H, W, K, K, ORIENT_FASTFLOW)
+    st = L.finc_inverse_f32(*args, _lib.ALGO["auto"], wsb.data_ptr(), wsb.numel(), torch.cuda.current_stream().cuda_stream)
+    assert st == 0
+    assert np.array_equal(xbuf[1:n + 1].cpu().numpy().reshape(z.shape), oracle.inverse_f32(z, wco))
+    st = L.finc_inverse_f32(*args, _lib.ALGO["mfma"], wsb.data_ptr(), wsb.numel(), torch.cuda.current_stream().cuda_stream)
+    assert st == 7   # FINC_ERR_ALIGNMENT
