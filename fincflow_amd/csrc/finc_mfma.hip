@@ -77,7 +77,13 @@ struct Cfg {
     static constexpr int ZSLOTS = 12, XSLOTS = 8;
     static constexpr int ZRING = NKZ * ZSLOTS * 64;       // floats
     static constexpr int XRING = NKD * XSLOTS * 64;
-    static constexpr int XCH = NW > 1 ? NW * NW * NKD * 64 : 0;   // exchange buffer [dst][src][reg][lane]
+    // K-split exchange.  Two waves: a wave leaves its share of the partner's registers in the PARTNER's x-ring slot of
+    // this step -- the slot the partner is about to fill with the finished pixel anyway and that nobody reads before
+    // (the oldest element a store-side read touches is 7 steps old, the end-of-step barrier orders the rest) -- so the
+    // exchange needs no LDS of its own: 2 x (2 waves x 20.4 KB) = 81.7 KB lets TWO 4-wave workgroups share a CU.
+    // More waves: a buffer [dst][src][reg][lane].
+    static constexpr bool XALIAS = NW == 2;
+    static constexpr int XCH = (NW > 1 && !XALIAS) ? NW * NW * NKD * 64 : 0;
 };
 
 // channel held by k-slot q of k-step j of an operand made from solved pixels: registers of the 16-row tiles first
@@ -807,7 +813,12 @@ __global__ __launch_bounds__(64 * NW * NPW) void finc_wave_kernel(const float *_
 #pragma unroll
                 for (int d = 0; d < C::NKDT; ++d) {
                     const int dst = d / NKD;
-                    if (dst != wv) xch[((dst * NW + wv) * NKD + d % NKD) * 64 + lane] = vv[d];
+                    if (dst != wv) {
+                        if constexpr (C::XALIAS)
+                            (lds_p + dst * wave_lds + C::ZRING)[(d % NKD) * C::XSLOTS * 64 + PH * 64 + xwin] = vv[d];
+                        else
+                            xch[((dst * NW + wv) * NKD + d % NKD) * 64 + lane] = vv[d];
+                    }
                     else xown[d % NKD] = vv[d];
                 }
                 FINC_SB();
@@ -830,7 +841,9 @@ __global__ __launch_bounds__(64 * NW * NPW) void finc_wave_kernel(const float *_
                         float sum = xown[j];
 #pragma unroll
                         for (int src = 0; src < NW; ++src)
-                            if (src != wv) sum += xch[((wv * NW + src) * NKD + j) * 64 + lane];
+                            if (src != wv)
+                                sum += C::XALIAS ? xring[j * C::XSLOTS * 64 + PH * 64 + xwin]
+                                                 : xch[((wv * NW + src) * NKD + j) * 64 + lane];
                         xpk[j] = sum;
                     }
                 }
@@ -1105,7 +1118,7 @@ size_t lds_bytes(const Inst &i, int W, int P)
     const size_t D = (size_t)(W - P + 1);
     const size_t ss = (size_t)i.nk * 4 * (i.kh - 1);
     const size_t per_wave = (size_t)i.wnkz * 12 * 64 + (size_t)i.wnkd * 8 * 64 + D * ss + ss + 64;
-    const size_t xch = i.nw > 1 ? (size_t)i.nw * i.nw * i.wnkd * 64 : 0;
+    const size_t xch = i.nw > 2 ? (size_t)i.nw * i.nw * i.wnkd * 64 : 0;   // 2 waves exchange through their x rings
     return sizeof(float) * (size_t)i.npw * (xch + (size_t)i.nw * per_wave);
 }
 
