@@ -4,12 +4,18 @@
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment starts the N ranks itself (fresh child processes through
+torch.distributed.run, BEFORE this process imports torch or touches the GPU) and exits with their return code; under
+torchrun (WORLD_SIZE set) it is one rank of the job.  Rank 0 prints ONE JSON line.
+
 Workload (BASELINE.json: "inverse images/sec + fwd+logdet ms/img, 3x3 conv @64x64x96"): one FastFlowUnit,
 3x3, C=96 (Cq=24), 64x64, batch 256 PER GPU (configs[2]); synthetic fp32 data, weights by the reference's
 init rule (layers/conv.py:63-79).  A step = one pass of the hot path over one batch resident in HBM:
-`unit.reverse(z)` (= one launch of the MFMA wavefront kernel).  The timed region is exactly K such steps
-between barrier + torch.cuda.synchronize(); value = images solved by all ranks / max-over-ranks time.
-The forward (+logdet, identically 0) is timed the same way right after and reported next to it.
+`unit.reverse(z)`, the module's public call (allocation of the result included; one launch of the MFMA
+wavefront kernel).  The timed region is exactly K such steps between barrier + torch.cuda.synchronize();
+value = images solved by all ranks / max-over-ranks time.  The forward (+logdet, identically 0) is timed the
+same way right after and reported next to it, and so is the inverse on z ~ N(0,1) (the sampling distribution,
+train/losses.py:42-45).
 
 Images are independent, so ranks shard the batch with no data-path collective ("weak" scaling: the per-GPU
 batch is fixed); the only RCCL traffic is one broadcast of the layer's weights before the timed region.
@@ -17,12 +23,21 @@ batch is fixed); the only RCCL traffic is one broadcast of the layer's weights b
 Extra objects on the JSON line:
   roofline      dominant kernel (inverse): algorithmic bytes per launch (8*E + 4*C*Cq*KH*KW)
                 / mean launch duration from HIP events on the launch stream, vs 8 TB/s HBM peak; `traffic`
-                = HBM bytes per launch from rocprofv3 PMC passes (profiles/traffic_*.json) or null.
-  cpu_baseline  the CPU solve timed on this box's host cores on a bounded sample of the same workload.
+                = HBM bytes per launch from rocprofv3 PMC passes (profiles/traffic_*.json; a profiler pass, not
+                measured in this run) or null.
+  cpu_baseline  the pinned CPU port (oracle/finc_oracle.c) timed on this box's host cores on a bounded sample of
+                the same workload: one thread fp64 (how the reference runs its solver) and all cores; plus the
+                reference's own solver as measured in the build container (a constant with provenance -- the
+                compiled reference does not travel).
+
+FINC_BENCH_STUB=1 replaces the step by a host-only stand-in (no GPU, no HIP library): it exists so that the
+launcher / rendezvous / gather logic is covered by a CPU test (tests/test_bench_launcher.py), never for numbers.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -40,58 +55,188 @@ WORKLOADS = {
     # layers/conv.py:64 makes the inverse itself unstable; 0.02 matches the operator norm of c3.
     "c5": (64, 192, 128, 128, 5, 0.02),
 }
+CONFIG_INDEX = {"c3": 2, "c2": 1, "c5": 4}
+# single-thread CPU sample sizes (images): about 10-20 s of host work per workload
+CPU_SAMPLE_1T = {"c3": 64, "c2": 64, "c5": 2}
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS) + ["c4"])
-    ap.add_argument("--cpu-sample", type=int, default=None, help="images in the CPU baseline sample")
+    ap.add_argument("--cpu-sample", type=int, default=None, help="images in the single-thread CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
-    return ap.parse_args()
+    ap.add_argument("--master-port", type=int, default=None, help="rendezvous port when this process starts the ranks")
+    return ap.parse_args(argv)
 
 
-def cpu_baseline(B_sample, C, H, W, K, std):
-    """CPU solve of `B_sample` images of the same workload on this box's cores.  Preferred: the reference's own
-    Cython solver rebuilt into oracle/_ref (kind "reference", one thread -- its prange compiles without
-    OpenMP, setup.py:1-5), called per group like FastFlowUnit.reverse_level1 (fastflow.py:57-76).
-    Always also: our C restatement with OpenMP over (image, group) on every core (kind "port")."""
+# ----------------------------------------------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` -> N ranks
+# ----------------------------------------------------------------------------------------------------------------
+def free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args, argv):
+    """Start args.gpus ranks as fresh children of a process that has not touched the GPU (no torch import so far).
+    stdout/stderr pass through, so rank 0's JSON line is this command's JSON line."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("MASTER_ADDR", "127.0.0.1")
+    port = args.master_port or free_port()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.run(cmd, env=env).returncode
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# the rank harness (shared by the GPU step and the host-only stub)
+# ----------------------------------------------------------------------------------------------------------------
+class Harness:
+    def __init__(self, args, stub):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist, self.stub = torch, dist, stub
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={self.world}: launch N ranks with --gpus N")
+        self.backend = None
+        if stub:
+            self.dev = torch.device("cpu")
+        else:
+            ndev = max(torch.cuda.device_count(), 1)
+            self.dev = torch.device("cuda", self.local_rank % ndev if self.world > 1 else 0)
+            torch.cuda.set_device(self.dev)
+        if self.world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            # one rank per GPU over RCCL ("nccl" IS RCCL on ROCm).  FINC_BENCH_BACKEND=gloo lets the N>1 code path be
+            # rehearsed on the CPU (stub) or with several ranks on ONE GPU (RCCL refuses two ranks per device); never
+            # used for numbers.
+            self.backend = os.environ.get("FINC_BENCH_BACKEND", "gloo" if stub else "nccl")
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", device_id=self.dev)
+            else:
+                dist.init_process_group(self.backend)
+        self.spin_up_s = 0.0 if stub else 0.25
+
+    def sync(self):
+        if not self.stub:
+            self.torch.cuda.synchronize()
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+        self.sync()
+
+    def spin_up(self, fn):
+        """Untimed preamble, before the W warmup steps: the card needs ~50 launches (tens of ms) after idling
+        before its clocks settle; a 20-step run measured cold reads 15-20 % low.  Not a step, not timed;
+        its length is reported as `spin_up_s`."""
+        t_end = time.perf_counter() + self.spin_up_s
+        while time.perf_counter() < t_end:
+            for _ in range(10):
+                fn()
+            self.sync()
+
+    def timed(self, fn, steps, warmup):
+        """W untimed steps, then exactly K steps between barrier+synchronize; per-launch durations from HIP events on
+        the launch stream (torch's current stream IS the stream the ABI call launches on).  Returns the max-over-ranks
+        wall time, every rank's wall time and the sorted per-launch milliseconds of this rank."""
+        torch = self.torch
+        self.spin_up(fn)
+        for _ in range(warmup):
+            fn()
+        if self.stub:
+            stamps = []
+            self.barrier()
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                a = time.perf_counter()
+                fn()
+                stamps.append((time.perf_counter() - a) * 1e3)
+            self.barrier()
+            dt = time.perf_counter() - t0
+            per = sorted(stamps)
+        else:
+            evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+            self.barrier()
+            t0 = time.perf_counter()
+            for a, b in evs:
+                a.record()
+                fn()
+                b.record()
+            self.barrier()
+            dt = time.perf_counter() - t0
+            per = sorted(a.elapsed_time(b) for a, b in evs)
+        ranks = [dt]
+        if self.world > 1:
+            tt = torch.tensor([dt], device=self.dev if self.backend == "nccl" else "cpu", dtype=torch.float64)
+            gathered = [torch.zeros_like(tt) for _ in range(self.world)]
+            self.dist.all_gather(gathered, tt)
+            ranks = [float(g.item()) for g in gathered]
+        return max(ranks), ranks, per
+
+    def finish(self):
+        if self.world > 1:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+def launch_stats(per):
+    n = len(per)
+    pick = lambda f: per[min(n - 1, max(0, int(round(f * (n - 1)))))]
+    return {"mean_ms": sum(per) / n, "median_ms": pick(0.5), "p10_ms": pick(0.1), "p90_ms": pick(0.9)}
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# CPU baseline
+# ----------------------------------------------------------------------------------------------------------------
+def cpu_baseline(workload, B, C, H, W, K, std, sample_1t):
+    """The pinned port (oracle/finc_oracle.c: a restatement of solve_parallel_mc.pyx:77-126, bit-equal to the rebuilt
+    reference solver on the golden vectors) on this box's host cores.  `value`: one thread, fp64 -- how the reference
+    runs it (its prange compiles without OpenMP, setup.py:1-5).  `all_cores`: OpenMP over (image, group)."""
     import numpy as np
-    from oracle import build_ref, oracle
+    from oracle import oracle
     ws = oracle.make_stored_weights(4, C // 4, K, K, std=std)
     wc = oracle.canonicalize(ws, 4, oracle.ORIENT_FASTFLOW)
     rng = np.random.default_rng(0)
-    x = rng.standard_normal((B_sample, C, H, W)).astype(np.float32)
-    z = oracle.forward_f32(x, wc, nthreads=oracle.max_threads())
     ncores = os.cpu_count() or 1
     nthreads = min(oracle.max_threads(), ncores)
+    n_all = min(B, max(sample_1t, 2 * nthreads))
+    x = rng.standard_normal((n_all, C, H, W)).astype(np.float32)
+    z = oracle.forward_f32(x, wc, nthreads=nthreads)
+    n1 = min(sample_1t, n_all)
     t0 = time.perf_counter()
-    xp = oracle.inverse_via_f64(z, wc, nthreads=nthreads)
-    t_port = time.perf_counter() - t0
-    assert np.abs(xp - x).max() / np.abs(x).max() < 1e-4
-    port = {"value": B_sample / t_port, "unit": "images/s", "cores": nthreads, "kind": "port",
-            "sample": f"{B_sample} images of the bench workload, fp64 solve (oracle/finc_oracle.c), OpenMP over image x group"}
-    solve_parallel = None
-    try:
-        solve_parallel = build_ref.load()
-    except Exception:
-        pass
-    if solve_parallel is None:
-        return port
-    nref = max(1, min(B_sample, 4))
-    Cq = C // 4
+    x1 = oracle.inverse_via_f64(z[:n1], wc, nthreads=1)
+    t_1 = time.perf_counter() - t0
+    assert np.abs(x1 - x[:n1]).max() / np.abs(x[:n1]).max() < 1e-4
     t0 = time.perf_counter()
-    for b in range(nref):
-        for g in range(4):  # canonical-orientation solve of each group, as layers/conv.py:113-163 does after its flips
-            zz = np.ascontiguousarray(z[b:b + 1, g * Cq:(g + 1) * Cq], dtype=np.float64)
-            solve_parallel(zz, np.ascontiguousarray(wc[g * Cq:(g + 1) * Cq], dtype=np.float64), (K, K))
-    t_ref = time.perf_counter() - t0
-    return {"value": nref / t_ref, "unit": "images/s", "cores": 1, "kind": "reference",
-            "sample": f"{nref} images of the bench workload through the reference's solve_parallel_mc.pyx "
-                      f"(oracle/_ref), 4 group solves per image, single thread as the reference runs it",
-            "port_all_cores": port}
+    oracle.inverse_via_f64(z, wc, nthreads=nthreads)
+    t_all = time.perf_counter() - t0
+    out = {"value": n1 / t_1, "unit": "images/s", "cores": 1, "kind": "port",
+           "sample": f"{n1} images of the bench workload, fp64 solve (oracle/finc_oracle.c), single thread as the "
+                     f"reference runs its solver",
+           "all_cores": {"value": n_all / t_all, "unit": "images/s", "cores": nthreads, "kind": "port",
+                         "sample": f"{n_all} images, same solve, OpenMP over image x group"}}
+    path = os.path.join(REPO, "profiles", "reference_cpu_container.json")
+    if os.path.exists(path):
+        with open(path) as f:
+            ref = json.load(f)
+        if workload in ref.get("workloads", {}):
+            r = ref["workloads"][workload]
+            out["reference_in_build_container"] = {
+                "value": r["reference_images_per_s"], "unit": "images/s", "cores": 1, "kind": "reference",
+                "port_same_host_1thread": r["port_1thread_images_per_s"],
+                "provenance": ref.get("source"), "host_cpu_count": ref.get("cpu_count"),
+                "note": "constant, not measured in this run: the compiled reference does not travel to the GPU box"}
+    return out
 
 
 def load_traffic(workload):
@@ -102,6 +247,9 @@ def load_traffic(workload):
     return None
 
 
+# ----------------------------------------------------------------------------------------------------------------
+# --workload c4: the Glow stack
+# ----------------------------------------------------------------------------------------------------------------
 def bench_stack(args):
     """--workload c4: BASELINE configs[3], sampling 128 images through the CIFAR Glow stack of
     fastflow_cifar.py:35-63 (num_blocks=3, block_size=32, actnorm, split prior: 96 FastFlowUnits at 16x16 / 8x8 /
@@ -123,13 +271,13 @@ def bench_stack(args):
             if isinstance(m, glow.ActNorm):
                 m.initialized.fill_(1)
         for _ in range(3):
-            s = model.sample(n)
+            s, _ = model.sample(n)
         torch.cuda.synchronize()
         graph, mode = None, "eager"
         try:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                s = model.sample(n)
+                s, _ = model.sample(n)
             g.replay()
             torch.cuda.synchronize()
             graph, mode = g, "hip-graph"
@@ -157,31 +305,38 @@ def bench_stack(args):
         "roofline": None, "cpu_baseline": None}), flush=True)
 
 
-def main():
-    args = parse()
-    if args.workload == "c4":
-        return bench_stack(args)
-    import torch
-    import torch.distributed as dist
-    from fincflow_amd import FastFlowUnit
+# ----------------------------------------------------------------------------------------------------------------
+# host-only stub (launcher / gather coverage on the CPU)
+# ----------------------------------------------------------------------------------------------------------------
+def bench_stub(args):
+    import numpy as np
+    h = Harness(args, stub=True)
+    B = 4
+    a = np.random.default_rng(h.rank).standard_normal((B, 64, 64))
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    ndev = max(torch.cuda.device_count(), 1)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        # one rank per GPU over RCCL ("nccl" IS RCCL on ROCm).  FINC_BENCH_BACKEND=gloo lets the N>1 code path be
-        # rehearsed with several ranks on ONE GPU (RCCL refuses two ranks per device); never used for numbers.
-        backend = os.environ.get("FINC_BENCH_BACKEND", "nccl")
-        torch.cuda.set_device(local_rank % ndev)
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank % ndev))
-        else:
-            dist.init_process_group(backend)
-    dev = torch.device("cuda", (local_rank % ndev) if world > 1 else 0)
-    torch.cuda.set_device(dev)
+    def fn():
+        np.linalg.norm(a @ a.transpose(0, 2, 1))
+
+    dt, ranks, per = h.timed(fn, args.steps, args.warmup)
+    if h.rank == 0:
+        print(json.dumps({"metric": "stub steps/s (host-only stand-in: launcher test, not a measurement)",
+                          "value": h.world * B * args.steps / dt, "unit": "images/s", "n_gpus": h.world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+                          "data": "stub", "config": {"workload": "host-only stub", "backend": h.backend,
+                                                     "world_size_seen": h.world, "per_rank_ms": [r * 1e3 for r in ranks]},
+                          "launch": launch_stats(per), "roofline": None, "cpu_baseline": None}), flush=True)
+    h.finish()
+
+
+# ----------------------------------------------------------------------------------------------------------------
+# the hot path
+# ----------------------------------------------------------------------------------------------------------------
+def bench_unit(args):
+    h = Harness(args, stub=False)
+    torch = h.torch
+    from fincflow_amd import FastFlowUnit
+    dev, world, rank = h.dev, h.world, h.rank
 
     B, C, H, W, K, std = WORKLOADS[args.workload]
     Cq = C // 4
@@ -197,61 +352,42 @@ def main():
         broadcast_weights(unit, src=0)
     gen = torch.Generator(device=dev).manual_seed(1000 + rank)  # each rank owns different images
     x = torch.randn(B, C, H, W, device=dev, generator=gen)
+    zn = torch.randn(B, C, H, W, device=dev, generator=gen)     # the sampling distribution
     with torch.no_grad():
         z, logdet = unit(x)
         xr = unit.reverse(z)                      # also builds the packed-fragment cache
     torch.cuda.synchronize()
     err = float((xr - x).abs().max() / x.abs().max())
     assert logdet == 0.0 and err <= 1e-5, f"round trip broken before timing: {err}"
-    out = torch.empty_like(z)
+    del xr
+    keep = {}
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+    def step_inverse():
+        keep["x"] = unit.reverse(z)
 
-    def spin_up(fn, seconds=0.25):
-        """Untimed preamble, before the W warmup steps: the card needs ~50 launches (tens of ms) after idling
-        before its clocks settle; a 20-step run measured cold reads 15-20 % low.  Not a step, not timed."""
-        t_end = time.perf_counter() + seconds
-        while time.perf_counter() < t_end:
-            for _ in range(10):
-                fn()
-            torch.cuda.synchronize()
-
-    def timed(fn, steps, warmup):
-        spin_up(fn)
-        for _ in range(warmup):
-            fn()
-        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
-        barrier()
-        t0 = time.perf_counter()
-        for a, b in evs:
-            a.record()
-            fn()
-            b.record()
-        barrier()
-        dt = time.perf_counter() - t0
-        per_launch_ms = sum(a.elapsed_time(b) for a, b in evs) / steps
-        if world > 1:
-            tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt = float(tt.item())
-        return dt, per_launch_ms
+    def step_sampling():
+        keep["xs"] = unit.reverse(zn)
 
     with torch.no_grad():
-        inv_dt, inv_launch_ms = timed(lambda: unit._cache.inverse(z, unit._weights(), 4, 0xE4, out=out),
-                                      args.steps, args.warmup)
-        fwd_dt, fwd_launch_ms = timed(lambda: unit(x), args.steps, args.warmup)
-    err_after = float((out - x).abs().max() / x.abs().max())
+        inv_dt, inv_ranks, inv_per = h.timed(step_inverse, args.steps, args.warmup)
+        fwd_dt, _, fwd_per = h.timed(lambda: unit(x), args.steps, args.warmup)
+        smp_dt, _, smp_per = h.timed(step_sampling, args.steps, args.warmup)
+        err_after = float((keep["x"] - x).abs().max() / x.abs().max())
+        resid = float((unit(keep["xs"])[0] - zn).abs().max() / zn.abs().max())
     assert err_after <= 1e-5, err_after
+    assert resid <= 1e-5, resid
 
     if rank == 0:
         E = B * C * H * W
         alg_bytes = 8 * E + 4 * C * Cq * K * K
         alg_flops = 2 * E * K * K * Cq
+        inv, fwd, smp = launch_stats(inv_per), launch_stats(fwd_per), launch_stats(smp_per)
+        inv_launch_ms, fwd_launch_ms = inv["mean_ms"], fwd["mean_ms"]
         inv_gbs = alg_bytes / (inv_launch_ms * 1e-3) / 1e9
         traffic = load_traffic(args.workload)
+        P = min(16, W)
+        chain = ((H + P - 1) // P) * W + P - 1           # dependent steps of one problem (bands of P rows, chained)
+        hbm_ceiling = (alg_bytes / HBM_PEAK_GBS / 1e9) / (alg_flops / FP32_PEAK_TFLOPS / 1e12)
         line = {
             "metric": "inverse images/sec (+ fwd+logdet ms/img in `forward`), 3x3 conv @64x64x96" if args.workload == "c3"
                       else f"inverse images/sec (FastFlowUnit, workload {args.workload})",
@@ -266,19 +402,29 @@ def main():
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[{ {'c3': 2, 'c2': 1, 'c5': 4}[args.workload] }]: FastFlowUnit {K}x{K}, C={C} "
+            "config": {"workload": f"BASELINE configs[{CONFIG_INDEX[args.workload]}]: FastFlowUnit {K}x{K}, C={C} "
                                    f"(4 groups x Cq={Cq}), {H}x{W}, batch {B} per GPU; step = unit.reverse(z), "
                                    f"z = unit.forward(x), x ~ N(0,1); weights N(0,{std}^2) + reference init rule",
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"batch-sharded x{world}",
-                       "round_trip_rel_err": err_after},
+                       "world_size_seen": world, "backend": h.backend, "per_rank_ms": [r * 1e3 for r in inv_ranks],
+                       "round_trip_rel_err": err_after, "spin_up_s": h.spin_up_s},
+            "launch": inv,
+            "sampling": {"what": "the same step on z ~ N(0,1) (train/losses.py:42-45)",
+                         "images_per_s": world * B * args.steps / smp_dt, "launch": smp,
+                         "forward_residual_rel_err": resid},
             "forward": {"ms_per_img": fwd_dt / args.steps / B * 1e3, "images_per_s": world * B * args.steps / fwd_dt,
-                        "logdet": 0.0, "launch_ms": fwd_launch_ms,
+                        "logdet": 0.0, "launch_ms": fwd_launch_ms, "launch": fwd,
                         "frac_hbm_peak": alg_bytes / (fwd_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                        "frac_fp32_peak": alg_flops / (fwd_launch_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS},
+                        "frac_fp32_peak": alg_flops / (fwd_launch_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
+                        "hbm_frac_ceiling_at_fp32": hbm_ceiling,
+                        "note": f"fp32-compute-bound shape: at 100 % of the fp32 peak this call reaches {hbm_ceiling:.0%} of "
+                                f"HBM peak" + ("; the north_star's 40 % of HBM on the forward is unreachable at fp32 here"
+                                               if hbm_ceiling < 0.4 else "")},
             "roofline": {"kernel": f"finc_wave_kernel<{(Cq + 3) // 4 * 4},{K},{K},SEC> (inverse)", "bound": "hbm", "achieved": inv_gbs,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": inv_gbs / HBM_PEAK_GBS,
                          "traffic": (traffic or {}).get("inverse_hbm_bytes_per_launch"),
                          "traffic_source": (traffic or {}).get("source"),
+                         "traffic_measured_in_this_run": False,
                          "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": inv_launch_ms,
                          "frac_fp32_peak": alg_flops / (inv_launch_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
                          # the shape is compute-bound (K^2*Cq/4 flop/B against a ridge of ~20): the same launch against
@@ -286,16 +432,34 @@ def main():
                          "compute": {"bound": "mfma", "achieved": alg_flops / (inv_launch_ms * 1e-3) / 1e12,
                                      "peak": FP32_PEAK_TFLOPS, "unit": "TFLOP/s",
                                      "frac": alg_flops / (inv_launch_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
-                                     "algorithmic_flops_per_launch": alg_flops}},
+                                     "algorithmic_flops_per_launch": alg_flops},
+                         # the recurrence is a chain: one problem needs `dependent_steps` steps one after the other
+                         "latency": {"dependent_steps": chain, "us_per_step": inv_launch_ms * 1e3 / chain,
+                                     "note": "shapes whose problems do not fill the chip (c2, the c4 units) are bound by "
+                                             "dependent_steps x us_per_step, not by bandwidth"}},
         }
         if not args.no_cpu and world == 1:          # the CPU baseline is an N=1 measurement (rank 0 only)
-            sample = args.cpu_sample or (4 * (os.cpu_count() or 1) if args.workload == "c3" else B)
-            line["cpu_baseline"] = cpu_baseline(min(sample, B), C, H, W, K, std)
+            line["cpu_baseline"] = cpu_baseline(args.workload, B, C, H, W, K, std,
+                                                args.cpu_sample or CPU_SAMPLE_1T[args.workload])
         print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    h.finish()
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse(argv)
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        if args.workload == "c4":
+            raise SystemExit("--workload c4 is a single-GPU bench")
+        return launch_ranks(args, argv)             # nothing above this line touches torch or the GPU
+    if os.environ.get("FINC_BENCH_STUB") == "1":
+        return bench_stub(args)
+    if args.workload == "c4":
+        return bench_stack(args)
+    return bench_unit(args)
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -19,6 +19,8 @@ SYMBOLS = [
     "finc_inverse_f32", "finc_forward_f32", "finc_pack_inverse_weights_f32", "finc_pack_forward_weights_f32",
     "finc_inverse_packed_f32", "finc_forward_packed_f32", "finc_backward_f32", "finc_backward_workspace_bytes",
     "finc_inverse_workspace_bytes", "finc_pack_inverse_weights_affine_f32",
+    "finc_canonicalize_weights_f64", "finc_inverse_f64", "finc_forward_f64",
+    "finc_inverse_kernel_variant", "finc_debug_attr_table_insert", "finc_debug_inverse_table_row",
 ]
 
 _lib = None
@@ -62,10 +64,38 @@ def lib():
     L.finc_inverse_workspace_bytes.argtypes = [i, i, i, i, i, i, i]
     L.finc_backward_workspace_bytes.argtypes = [i, i, i, i, i, i, i]
     L.finc_backward_f32.argtypes = [vp, vp, vp, vp, vp, i, i, i, i, i, i, i, u, vp, sz, vp]
+    L.finc_canonicalize_weights_f64.argtypes = [vp, vp, i, i, i, i, u, vp]
+    run64 = [vp, vp, vp, i, i, i, i, i, i, i, u, vp]
+    L.finc_inverse_f64.argtypes = run64
+    L.finc_forward_f64.argtypes = run64
+    L.finc_inverse_kernel_variant.argtypes = [i, i, i, i, i, i, i, ctypes.POINTER(ctypes.c_int)]
+    L.finc_debug_attr_table_insert.argtypes = [i, sz]
+    L.finc_debug_inverse_table_row.argtypes = [i, ctypes.POINTER(ctypes.c_int)]
     for name in SYMBOLS:
         getattr(L, name)  # AttributeError here = header and library out of sync
     _lib = L
     return L
+
+
+def inverse_variant(B, G, Cq, H, W, KH, KW):
+    """The MFMA inverse kernel variant the library launches for this problem, or None (strict kernel)."""
+    info = (ctypes.c_int * 8)()
+    st = lib().finc_inverse_kernel_variant(B, G, Cq, H, W, KH, KW, info)
+    if st == 3:
+        return None
+    check(st, "finc_inverse_kernel_variant")
+    keys = ("cqp", "nw", "npw", "sec", "lds_bytes", "workgroups", "row", "rows")
+    return dict(zip(keys, list(info)))
+
+
+def inverse_table():
+    """Every row of the MFMA inverse instantiation table (host-only call)."""
+    rows, r = [], 0
+    info = (ctypes.c_int * 6)()
+    while lib().finc_debug_inverse_table_row(r, info) == OK:
+        rows.append(dict(zip(("cqp", "kh", "kw", "nw", "npw", "max_problems"), list(info))))
+        r += 1
+    return rows
 
 
 def check(status, what):

@@ -4,11 +4,32 @@
 
 #include <string.h>
 
+#include <mutex>
+#include <utility>
+#include <vector>
+
 namespace {
 
 thread_local char g_hip_error[256] = "no error";
 
-__global__ void canonicalize_kernel(const float *__restrict__ ws, float *__restrict__ wc, int G, int Cq, int KH,
+// ---- per-process tables (the only global state of the library; include/finc.h) ----
+std::mutex g_table_mutex;
+std::vector<std::pair<int, const void *>> g_attr_done;   // (device, kernel) pairs whose LDS attribute is set
+constexpr int MAX_DEVICES = 64;
+int *g_invariant_flag[MAX_DEVICES];                       // one 4-byte device word per device, allocated on first use
+
+// true if (device, fn) was not in the table yet (and is now)
+bool attr_table_insert(int device, const void *fn)
+{
+    std::lock_guard<std::mutex> lk(g_table_mutex);
+    for (const auto &e : g_attr_done)
+        if (e.first == device && e.second == fn) return false;
+    g_attr_done.emplace_back(device, fn);
+    return true;
+}
+
+template <typename T>
+__global__ void canonicalize_kernel(const T *__restrict__ ws, T *__restrict__ wc, int G, int Cq, int KH,
                                     int KW, unsigned orient)
 {
     const int total = G * Cq * Cq * KH * KW;
@@ -57,6 +78,33 @@ void finc_set_hip_error(hipError_t e)
     g_hip_error[sizeof(g_hip_error) - 1] = 0;
 }
 
+// A kernel's dynamic-LDS ceiling is a per-DEVICE property of the loaded code object: set it once per (device, kernel),
+// whichever thread launches first (a per-thread cache would skip the second device of a process that drives two).
+int finc_ensure_dynamic_lds(const void *fn, size_t bytes)
+{
+    if (bytes <= 48 * 1024) return FINC_OK;
+    int dev = 0;
+    FINC_HIP_TRY(hipGetDevice(&dev));
+    if (!attr_table_insert(dev, fn)) return FINC_OK;
+    FINC_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    return FINC_OK;
+}
+
+template <typename T>
+static int canonicalize(const T *w_stored, T *w_canon, int G, int Cq, int KH, int KW, unsigned orient, finc_stream_t stream)
+{
+    if (!w_stored || !w_canon) return FINC_ERR_NULL_POINTER;
+    if (int e = check_shape(1, G, Cq, 1, 1, KH, KW)) return e;
+    if (w_stored == w_canon) return FINC_ERR_BAD_DIMS;
+    const int total = G * Cq * Cq * KH * KW;
+    int blocks = (total + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(canonicalize_kernel<T>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_stored, w_canon, G,
+                       Cq, KH, KW, orient);
+    FINC_CHECK_LAUNCH();
+    return FINC_OK;
+}
+
 extern "C" {
 
 int finc_version(void) { return 100; }
@@ -81,16 +129,13 @@ const char *finc_last_hip_error(void) { return g_hip_error; }
 int finc_canonicalize_weights_f32(const float *w_stored, float *w_canon, int G, int Cq, int KH, int KW,
                                   unsigned orient, finc_stream_t stream)
 {
-    if (!w_stored || !w_canon) return FINC_ERR_NULL_POINTER;
-    if (int e = check_shape(1, G, Cq, 1, 1, KH, KW)) return e;
-    if (w_stored == w_canon) return FINC_ERR_BAD_DIMS;
-    const int total = G * Cq * Cq * KH * KW;
-    int blocks = (total + 255) / 256;
-    if (blocks > 1024) blocks = 1024;
-    hipLaunchKernelGGL(canonicalize_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w_stored, w_canon, G,
-                       Cq, KH, KW, orient);
-    FINC_CHECK_LAUNCH();
-    return FINC_OK;
+    return canonicalize<float>(w_stored, w_canon, G, Cq, KH, KW, orient, stream);
+}
+
+int finc_canonicalize_weights_f64(const double *w_stored, double *w_canon, int G, int Cq, int KH, int KW,
+                                  unsigned orient, finc_stream_t stream)
+{
+    return canonicalize<double>(w_stored, w_canon, G, Cq, KH, KW, orient, stream);
 }
 
 int finc_check_invariant_f32(const float *w_canon, int G, int Cq, int KH, int KW, finc_stream_t stream)
@@ -98,21 +143,27 @@ int finc_check_invariant_f32(const float *w_canon, int G, int Cq, int KH, int KW
     if (!w_canon) return FINC_ERR_NULL_POINTER;
     if (int e = check_shape(1, G, Cq, 1, 1, KH, KW)) return e;
     hipStream_t st = (hipStream_t)stream;
-    int *d_flag = nullptr;
-    FINC_HIP_TRY(hipMalloc(&d_flag, sizeof(int)));
+    int dev = 0;
+    FINC_HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= MAX_DEVICES) return FINC_ERR_BAD_DIMS;
+    // the call is synchronous anyway: one lock covers the lazily allocated per-device flag word and its use, so
+    // concurrent checks (DataParallel replica threads) neither allocate twice nor share the word
+    std::lock_guard<std::mutex> lk(g_table_mutex);
+    if (!g_invariant_flag[dev]) FINC_HIP_TRY(hipMalloc(&g_invariant_flag[dev], sizeof(int)));
+    int *d_flag = g_invariant_flag[dev];
     int h_flag = 0;
-    hipError_t e = hipMemsetAsync(d_flag, 0, sizeof(int), st);
-    if (e == hipSuccess) {
-        int blocks = (G * Cq * Cq + 255) / 256;
-        hipLaunchKernelGGL(invariant_kernel, dim3(blocks), dim3(256), 0, st, w_canon, G, Cq, KH, KW, d_flag);
-        e = hipGetLastError();
-    }
-    if (e == hipSuccess) e = hipMemcpyAsync(&h_flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, st);
-    if (e == hipSuccess) e = hipStreamSynchronize(st);
-    hipError_t e2 = hipFree(d_flag);
-    if (e != hipSuccess) { finc_set_hip_error(e); return FINC_ERR_LAUNCH; }
-    if (e2 != hipSuccess) { finc_set_hip_error(e2); return FINC_ERR_LAUNCH; }
+    FINC_HIP_TRY(hipMemsetAsync(d_flag, 0, sizeof(int), st));
+    const int blocks = (G * Cq * Cq + 255) / 256;
+    hipLaunchKernelGGL(invariant_kernel, dim3(blocks), dim3(256), 0, st, w_canon, G, Cq, KH, KW, d_flag);
+    FINC_CHECK_LAUNCH();
+    FINC_HIP_TRY(hipMemcpyAsync(&h_flag, d_flag, sizeof(int), hipMemcpyDeviceToHost, st));
+    FINC_HIP_TRY(hipStreamSynchronize(st));
     return h_flag == 0 ? FINC_OK : FINC_ERR_INVARIANT;
+}
+
+int finc_debug_attr_table_insert(int device, size_t kernel_token)
+{
+    return attr_table_insert(device, (const void *)kernel_token) ? 1 : 0;
 }
 
 size_t finc_workspace_bytes(int G, int Cq, int KH, int KW)
@@ -271,6 +322,43 @@ int finc_forward_packed_f32(const float *x, const void *packed, float *z, int B,
                             int KW, unsigned orient, finc_stream_t stream)
 {
     return run_packed(x, packed, z, B, G, Cq, H, W, KH, KW, orient, stream, true);
+}
+
+static int run_f64(const double *in, const double *w_canon, double *out, int B, int G, int Cq, int H, int W, int KH,
+                   int KW, unsigned orient, finc_stream_t stream, bool forward)
+{
+    if (!in || !w_canon || !out) return FINC_ERR_NULL_POINTER;
+    if (int e = check_shape(B, G, Cq, H, W, KH, KW)) return e;
+    if (((uintptr_t)in | (uintptr_t)w_canon | (uintptr_t)out) & 7u) return FINC_ERR_ALIGNMENT;
+    if (in == out) return FINC_ERR_BAD_DIMS;
+    FincShape s{B, G, Cq, H, W, KH, KW, orient};
+    return forward ? finc_launch_forward_generic_f64(in, w_canon, out, s, (hipStream_t)stream)
+                   : finc_launch_inverse_strict_f64(in, w_canon, out, s, (hipStream_t)stream);
+}
+
+int finc_inverse_f64(const double *z, const double *w_canon, double *x, int B, int G, int Cq, int H, int W, int KH,
+                     int KW, unsigned orient, finc_stream_t stream)
+{
+    return run_f64(z, w_canon, x, B, G, Cq, H, W, KH, KW, orient, stream, false);
+}
+
+int finc_forward_f64(const double *x, const double *w_canon, double *z, int B, int G, int Cq, int H, int W, int KH,
+                     int KW, unsigned orient, finc_stream_t stream)
+{
+    return run_f64(x, w_canon, z, B, G, Cq, H, W, KH, KW, orient, stream, true);
+}
+
+int finc_inverse_kernel_variant(int B, int G, int Cq, int H, int W, int KH, int KW, int *info)
+{
+    if (!info) return FINC_ERR_NULL_POINTER;
+    if (int e = check_shape(B, G, Cq, H, W, KH, KW)) return e;
+    return finc_mfma_variant(B, G, Cq, H, W, KH, KW, info);
+}
+
+int finc_debug_inverse_table_row(int row, int *info)
+{
+    if (!info) return FINC_ERR_NULL_POINTER;
+    return finc_mfma_table_row(row, info);
 }
 
 size_t finc_backward_workspace_bytes(int B, int G, int Cq, int H, int W, int KH, int KW)

@@ -33,6 +33,9 @@ void finc_set_hip_error(hipError_t e);
 
 #define FINC_CHECK_LAUNCH() FINC_HIP_TRY(hipGetLastError())
 
+// hipFuncAttributeMaxDynamicSharedMemorySize = 160 KiB, once per (device, kernel), thread-safe (finc_abi.hip)
+int finc_ensure_dynamic_lds(const void *fn, size_t bytes);
+
 struct FincShape {
     int B, G, Cq, H, W, KH, KW;
     unsigned orient;
@@ -41,6 +44,8 @@ struct FincShape {
 // ---- generic (reference-order) kernels: finc_generic.hip ----
 int finc_launch_inverse_strict(const float *z, const float *wc, float *x, const FincShape &s, hipStream_t st);
 int finc_launch_forward_generic(const float *x, const float *wc, float *z, const FincShape &s, hipStream_t st);
+int finc_launch_inverse_strict_f64(const double *z, const double *wc, double *x, const FincShape &s, hipStream_t st);
+int finc_launch_forward_generic_f64(const double *x, const double *wc, double *z, const FincShape &s, hipStream_t st);
 int finc_launch_backward_generic(const float *gz, const float *x, const float *wc, float *gx, float *gw,
                                  const FincShape &s, hipStream_t st);
 
@@ -54,6 +59,11 @@ size_t finc_mfma_packed_bytes(int G, int Cq, int KH, int KW);
 int finc_mfma_pack(const float *wc, const float *scale, const float *shift, void *packed, int G, int Cq, int KH, int KW,
                    hipStream_t st);
 int finc_mfma_launch(const float *in, const void *packed, float *out, const FincShape &s, hipStream_t st);
+// info[0..7] = {Cq padded, waves per problem, problems per workgroup, 32-byte I/O (1) or 16-byte (0), LDS bytes of a
+// workgroup, workgroups, index into the instantiation table, rows of the table}; FINC_ERR_UNSUPPORTED if none applies
+int finc_mfma_variant(int B, int G, int Cq, int H, int W, int KH, int KW, int *info);
+// info[0..5] = {Cq padded, KH, KW, waves per problem, problems per workgroup, max_problems (0 = no limit)}
+int finc_mfma_table_row(int row, int *info);
 
 // ---- forward / grad-input, MFMA strip kernel: finc_conv.hip ----
 bool finc_conv_supported(int Cq, int H, int W, int KH, int KW);

@@ -15,18 +15,27 @@ namespace {
 
 constexpr int STRICT_MAX_BLOCK = 256;
 
-__global__ void inverse_strict_kernel(const float *__restrict__ z, const float *__restrict__ wc, float *x, int G,
+// acc - x*w as two separately rounded operations (the reference's C++ `output -= input*kernel` compiled without
+// contraction, and numpy's elementwise ops in utils/solve_mc.py)
+__device__ inline float mul_sub(float acc, float x, float w) { return __fsub_rn(acc, __fmul_rn(x, w)); }
+__device__ inline double mul_sub(double acc, double x, double w) { return __dsub_rn(acc, __dmul_rn(x, w)); }
+
+// T = float: the fp32 path; T = double: the reference op's other dispatch arm (AT_DISPATCH_FLOATING_TYPES,
+// cinc_cuda_kernel_level2.cu:117) and the arithmetic of its Cython CPU solver (solve_parallel_mc.pyx:77-126).
+template <typename T>
+__global__ void inverse_strict_kernel(const T *__restrict__ z, const T *__restrict__ wc, T *x, int G,
                                       int Cq, int H, int W, int KH, int KW, unsigned orient)
 {
-    extern __shared__ __attribute__((aligned(16))) float own[]; // [Cq][blockDim.x]: this pixel's solved channels
+    extern __shared__ __attribute__((aligned(16))) unsigned char own_raw[];
+    T *own = reinterpret_cast<T *>(own_raw); // [Cq][blockDim.x]: this pixel's solved channels
     const int bg = blockIdx.x;
     const int g = bg % G;
     const unsigned o = finc_group_orient(orient, g);
     const size_t HW = (size_t)H * W;
     const size_t off = (size_t)bg * Cq * HW; // == (b*G*Cq + g*Cq) * HW
-    const float *zg = z + off;
-    float *xg = x + off;
-    const float *wg = wc + (size_t)g * Cq * Cq * KH * KW;
+    const T *zg = z + off;
+    T *xg = x + off;
+    const T *wg = wc + (size_t)g * Cq * Cq * KH * KW;
     const int tid = threadIdx.x, nt = blockDim.x;
 
     for (int d = 0; d < H + W - 1; ++d) {
@@ -39,24 +48,24 @@ __global__ void inverse_strict_kernel(const float *__restrict__ z, const float *
                 const int h = h_lo + idx, w = d - h;
                 const int p = finc_pix(H, W, o, h, w);
                 for (int c = 0; c < Cq; ++c) {
-                    float acc = zg[(size_t)c * HW + p];
+                    T acc = zg[(size_t)c * HW + p];
                     for (int kh = 0; kh < KH; ++kh) {
                         if (h - kh < 0) break;
                         for (int kw = 0; kw < KW; ++kw) {
                             if (w - kw < 0) break;
-                            const float *wrow = wg + (((size_t)c * Cq) * KH + (KH - 1 - kh)) * KW + (KW - 1 - kw);
+                            const T *wrow = wg + (((size_t)c * Cq) * KH + (KH - 1 - kh)) * KW + (KW - 1 - kw);
                             if (kh == 0 && kw == 0) {
                                 for (int kc = 0; kc < c; ++kc) { // kc == c skipped, kc > c: zero taps
-                                    float xv = own[kc * nt + tid];
-                                    float wv = wrow[(size_t)kc * KH * KW];
-                                    acc = __fsub_rn(acc, __fmul_rn(xv, wv));
+                                    T xv = own[kc * nt + tid];
+                                    T wv = wrow[(size_t)kc * KH * KW];
+                                    acc = mul_sub(acc, xv, wv);
                                 }
                             } else {
                                 const int pn = finc_pix(H, W, o, h - kh, w - kw);
                                 for (int kc = 0; kc < Cq; ++kc) {
-                                    float xv = xg[(size_t)kc * HW + pn];
-                                    float wv = wrow[(size_t)kc * KH * KW];
-                                    acc = __fsub_rn(acc, __fmul_rn(xv, wv));
+                                    T xv = xg[(size_t)kc * HW + pn];
+                                    T wv = wrow[(size_t)kc * KH * KW];
+                                    acc = mul_sub(acc, xv, wv);
                                 }
                             }
                         }
@@ -70,8 +79,9 @@ __global__ void inverse_strict_kernel(const float *__restrict__ z, const float *
     }
 }
 
-__global__ void forward_generic_kernel(const float *__restrict__ x, const float *__restrict__ wc,
-                                       float *__restrict__ z, int B, int G, int Cq, int H, int W, int KH, int KW,
+template <typename T>
+__global__ void forward_generic_kernel(const T *__restrict__ x, const T *__restrict__ wc,
+                                       T *__restrict__ z, int B, int G, int Cq, int H, int W, int KH, int KW,
                                        unsigned orient)
 {
     const size_t HW = (size_t)H * W;
@@ -86,14 +96,14 @@ __global__ void forward_generic_kernel(const float *__restrict__ x, const float 
         const unsigned o = finc_group_orient(orient, g);
         const int h = (o & FINC_FLIP_H) ? H - 1 - ph : ph; // canonical coordinates of this output
         const int w = (o & FINC_FLIP_W) ? W - 1 - pw : pw;
-        const float *xg = x + (ch - oc) * HW;
-        const float *wo = wc + ((size_t)(g * Cq + oc) * Cq) * KH * KW;
-        float acc = 0.f;
+        const T *xg = x + (ch - oc) * HW;
+        const T *wo = wc + ((size_t)(g * Cq + oc) * Cq) * KH * KW;
+        T acc = 0;
         for (int ic = 0; ic < Cq; ++ic)
             for (int a = 0; a < KH && a <= h; ++a)
                 for (int b = 0; b < KW && b <= w; ++b)
-                    acc = fmaf(xg[(size_t)ic * HW + finc_pix(H, W, o, h - a, w - b)],
-                               wo[((size_t)ic * KH + (KH - 1 - a)) * KW + (KW - 1 - b)], acc);
+                    acc = fma(xg[(size_t)ic * HW + finc_pix(H, W, o, h - a, w - b)],
+                              wo[((size_t)ic * KH + (KH - 1 - a)) * KW + (KW - 1 - b)], acc);
         z[idx] = acc;
     }
 }
@@ -181,29 +191,48 @@ __global__ void backward_weight_kernel(const float *__restrict__ gz, const float
 
 } // namespace
 
-int finc_launch_inverse_strict(const float *z, const float *wc, float *x, const FincShape &s, hipStream_t st)
+template <typename T>
+static int launch_inverse_strict(const T *z, const T *wc, T *x, const FincShape &s, hipStream_t st)
 {
     int diag = s.H < s.W ? s.H : s.W;
     int block = ((diag + 63) / 64) * 64;
     if (block > STRICT_MAX_BLOCK) block = STRICT_MAX_BLOCK;
-    while (block > 64 && (size_t)block * s.Cq * sizeof(float) > 60 * 1024) block -= 64;
-    size_t lds = (size_t)block * s.Cq * sizeof(float);
+    while (block > 64 && (size_t)block * s.Cq * sizeof(T) > 60 * 1024) block -= 64;
+    size_t lds = (size_t)block * s.Cq * sizeof(T);
     if (lds > 64 * 1024) return FINC_ERR_UNSUPPORTED;
-    hipLaunchKernelGGL(inverse_strict_kernel, dim3(s.B * s.G), dim3(block), lds, st, z, wc, x, s.G, s.Cq, s.H, s.W,
+    hipLaunchKernelGGL(inverse_strict_kernel<T>, dim3(s.B * s.G), dim3(block), lds, st, z, wc, x, s.G, s.Cq, s.H, s.W,
                        s.KH, s.KW, s.orient);
     FINC_CHECK_LAUNCH();
     return FINC_OK;
 }
 
-int finc_launch_forward_generic(const float *x, const float *wc, float *z, const FincShape &s, hipStream_t st)
+template <typename T>
+static int launch_forward_generic(const T *x, const T *wc, T *z, const FincShape &s, hipStream_t st)
 {
     size_t total = (size_t)s.B * s.G * s.Cq * s.H * s.W;
     size_t blocks = (total + 255) / 256;
     if (blocks > 256 * 32) blocks = 256 * 32;
-    hipLaunchKernelGGL(forward_generic_kernel, dim3((unsigned)blocks), dim3(256), 0, st, x, wc, z, s.B, s.G, s.Cq,
+    hipLaunchKernelGGL(forward_generic_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, st, x, wc, z, s.B, s.G, s.Cq,
                        s.H, s.W, s.KH, s.KW, s.orient);
     FINC_CHECK_LAUNCH();
     return FINC_OK;
+}
+
+int finc_launch_inverse_strict(const float *z, const float *wc, float *x, const FincShape &s, hipStream_t st)
+{
+    return launch_inverse_strict<float>(z, wc, x, s, st);
+}
+int finc_launch_inverse_strict_f64(const double *z, const double *wc, double *x, const FincShape &s, hipStream_t st)
+{
+    return launch_inverse_strict<double>(z, wc, x, s, st);
+}
+int finc_launch_forward_generic(const float *x, const float *wc, float *z, const FincShape &s, hipStream_t st)
+{
+    return launch_forward_generic<float>(x, wc, z, s, st);
+}
+int finc_launch_forward_generic_f64(const double *x, const double *wc, double *z, const FincShape &s, hipStream_t st)
+{
+    return launch_forward_generic<double>(x, wc, z, s, st);
 }
 
 int finc_launch_backward_generic(const float *gz, const float *x, const float *wc, float *gx, float *gw,

@@ -1160,6 +1160,32 @@ int finc_mfma_pack(const float *wc, const float *scale, const float *shift, void
     return FINC_OK;
 }
 
+int finc_mfma_variant(int B, int G, int Cq, int H, int W, int KH, int KW, int *info)
+{
+    if (!finc_mfma_supported(Cq, H, W, KH, KW)) return FINC_ERR_UNSUPPORTED;
+    const Inst *i = find_inst(Cq, KH, KW, (long long)B * G, W);
+    if (!i) return FINC_ERR_UNSUPPORTED;
+    const int P = W < 16 ? W : 16;
+    info[0] = i->cqp;
+    info[1] = i->nw;
+    info[2] = i->npw;
+    info[3] = W % 8 == 0 ? 1 : 0;
+    info[4] = (int)lds_bytes(*i, W, P);
+    info[5] = B * G / i->npw;
+    info[6] = (int)(i - g_insts);
+    info[7] = (int)(sizeof(g_insts) / sizeof(g_insts[0]));
+    return FINC_OK;
+}
+
+int finc_mfma_table_row(int row, int *info)
+{
+    const int rows = (int)(sizeof(g_insts) / sizeof(g_insts[0]));
+    if (row < 0 || row >= rows) return FINC_ERR_BAD_DIMS;
+    const Inst &i = g_insts[row];
+    info[0] = i.cqp; info[1] = i.kh; info[2] = i.kw; info[3] = i.nw; info[4] = i.npw; info[5] = i.max_problems;
+    return FINC_OK;
+}
+
 int finc_mfma_launch(const float *in, const void *packed, float *out, const FincShape &s, hipStream_t st)
 {
     if (!finc_mfma_supported(s.Cq, s.H, s.W, s.KH, s.KW)) return FINC_ERR_UNSUPPORTED;
@@ -1171,16 +1197,7 @@ int finc_mfma_launch(const float *in, const void *packed, float *out, const Finc
     const int Tend = s.W % 8 == 0 ? (NB * s.W + P - 1 + 7) / 8 * 8 : (NB * s.W + P - 1 + 3) / 4 * 4;  // 32-byte I/O: x8 loop
     const size_t lds = lds_bytes(*i, s.W, P);
     const wave_fn fn = (s.W % 8 == 0) ? i->fn_sec : i->fn;
-    static thread_local const void *attr_done[128];
-    static thread_local int n_attr = 0;
-    if (lds > 48 * 1024) {
-        bool seen = false;
-        for (int k = 0; k < n_attr; ++k) seen |= attr_done[k] == (const void *)fn;
-        if (!seen) {
-            FINC_HIP_TRY(hipFuncSetAttribute((const void *)fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-            if (n_attr < 128) attr_done[n_attr++] = (const void *)fn;
-        }
-    }
+    if (int e = finc_ensure_dynamic_lds((const void *)fn, lds)) return e;
     hipLaunchKernelGGL(fn, dim3(s.B * s.G / i->npw), dim3(64 * i->nw * i->npw), lds, st, in, (const float *)packed, out, s.G, s.Cq, s.H, s.W, P,
                        Tend, s.orient);
     FINC_CHECK_LAUNCH();

@@ -52,8 +52,6 @@ class PaddedConv2d(FlowLayer):
         super().__init__()
         assert len(kernel_size) == 2
         assert order in {'TL', 'TR', 'BL', 'BR'}, 'unknown order: {}'.format(order)
-        if bias:
-            raise NotImplementedError("bias=True is never used on the FInC hot path (fastflow.py:24-27)")
         if in_channels != out_channels:
             raise ValueError("an invertible conv needs in_channels == out_channels")
         self.kernel_size = kernel_size
@@ -62,7 +60,10 @@ class PaddedConv2d(FlowLayer):
         # (left, right, top, bottom), layers/conv.py:41-55
         self.pad = {'TL': (K_W - 1, 0, K_H - 1, 0), 'TR': (0, K_W - 1, K_H - 1, 0),
                     'BL': (K_W - 1, 0, 0, K_H - 1), 'BR': (0, K_W - 1, 0, K_H - 1)}[order]
-        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size, bias=False)  # parameter holder only
+        # parameter holder only (state-dict keys conv.weight / conv.bias as in the reference).  The FInC unit never sets
+        # bias (fastflow.py:24-27); with it the layer is conv(x) + b and the reverse subtracts b first
+        # (layers/conv.py:113-117) -- a per-channel add around the same two launches.
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size, bias=bool(bias))
         self._cache = ops.PackedWeights()
         self.reset_parameters()
 
@@ -107,10 +108,14 @@ class PaddedConv2d(FlowLayer):
             out = ops.conv_forward(x, self.conv.weight, 1, self._orient)
         else:  # density evaluation / sampling checks: cached fragments, one launch
             out = self._cache.forward(x.contiguous(), [self.conv.weight], 1, self._orient)
+        if self.conv.bias is not None:
+            out = out + self.conv.bias.view(1, -1, 1, 1)
         return out, 0.0
 
     def reverse(self, x, context=None, compute_expensive=None):
         with torch.no_grad():
+            if self.conv.bias is not None:
+                x = x - self.conv.bias.reshape(-1, x.shape[1], 1, 1)
             y = self._cache.inverse(x.contiguous(), [self.conv.weight], 1, self._orient)
         return y, 0
 
@@ -192,7 +197,7 @@ class CINCFlowUnit(nn.Module):
         return self.conv_tl.reverse(x)[0]
 
 
-def load_reference_checkpoint(model, checkpoint, strict=True, validate=True):
+def load_reference_checkpoint(model, checkpoint, strict=True, validate=True, trust_pickle=False):
     """Load a reference training checkpoint (train/experiment.py:400-427: a dict holding 'model_state_dict',
     written by `torch.save`) or a bare state-dict into `model`.
 
@@ -202,10 +207,19 @@ def load_reference_checkpoint(model, checkpoint, strict=True, validate=True):
     fastflow_cifar_multi_gpu.py wraps the model) and what trained weights need: every packed-fragment cache is
     dropped and, with `validate`, each layer's unit-triangular corner tap is checked once on the device
     (a violated invariant raises RuntimeError instead of silently solving a different system).
+    A path is read with `torch.load(weights_only=True)` (tensors and plain containers only).  The reference's files
+    also pickle its config dict; if that holds arbitrary objects the safe load fails, and the caller opts in to full
+    unpickling -- which executes code from the file -- with `trust_pickle=True`.
     Returns the (missing_keys, unexpected_keys) of `load_state_dict`.
     """
     if isinstance(checkpoint, (str, bytes)) or hasattr(checkpoint, "__fspath__"):
-        checkpoint = torch.load(checkpoint, map_location="cpu", weights_only=False)
+        try:
+            checkpoint = torch.load(checkpoint, map_location="cpu", weights_only=True)
+        except Exception as e:
+            if not trust_pickle:
+                raise RuntimeError(f"checkpoint {checkpoint!r} needs full unpickling ({type(e).__name__}); pass "
+                                   "trust_pickle=True only for files you trust") from e
+            checkpoint = torch.load(checkpoint, map_location="cpu", weights_only=False)
     state = checkpoint.get("model_state_dict", checkpoint) if isinstance(checkpoint, dict) else checkpoint
     if state and all(k.startswith("module.") for k in state):
         state = {k[len("module."):]: v for k, v in state.items()}
@@ -270,12 +284,13 @@ class FlowSequential(nn.Module):
     #: FastFlowUnit that follows it in the reverse chain: one launch instead of two, same result
     fuse_affine = True
 
-    def _reverse_chain(self, input, context):
+    def _reverse_chain(self, input, context, fuse=None):
+        fuse = self.fuse_affine if fuse is None else fuse
         mods = list(reversed(self.sequence_modules))
         i = 0
         while i < len(mods):
             m = mods[i]
-            if (self.fuse_affine and i + 1 < len(mods) and hasattr(m, "reverse_affine_params")
+            if (fuse and i + 1 < len(mods) and hasattr(m, "reverse_affine_params")
                     and isinstance(mods[i + 1], FastFlowUnit) and not torch.is_grad_enabled()):
                 fused = mods[i + 1].reverse_affine(input, *m.reverse_affine_params())
                 if fused is not None:
@@ -288,8 +303,18 @@ class FlowSequential(nn.Module):
         return input
 
     def sample(self, n_samples, context=None, compute_expensive=False, also_true_inverse=False):
+        """layers/flowsequential.py:89-115: returns `(input, input_true)` -- the runner unpacks two values
+        (train/experiment.py:311-335).  No layer of the hot path is a ModifiedGradFlowLayer, so the "true inverse"
+        differs from the regular sample only in how it is evaluated: it re-runs the reverse chain from the same z
+        layer by layer (no affine fold), an independent check of the fused launch.  Without `also_true_inverse` (or with
+        `compute_expensive`) the second value IS the first, as in the reference (`input_true = input`)."""
         z, _ = self.base_distribution.sample(n_samples, context)
-        return self._reverse_chain(z, context)
+        x = self._reverse_chain(z, context)
+        if not compute_expensive and also_true_inverse:
+            x_true = self._reverse_chain(z, context, fuse=False)
+        else:
+            x_true = x
+        return x, x_true
 
     def reconstruct(self, input, context=None, compute_expensive=False):
         z = self.forward(input, context)[0]

@@ -7,6 +7,8 @@ RuntimeError for non-device / non-contiguous tensors.  `finc_inverse` /
 `finc_forward` are the orientation-aware calls FastFlowUnit uses (no flips, no
 chunk/cat copies: fastflow.py:78-100 collapses into one launch).
 """
+import threading
+
 import torch
 
 from . import _lib
@@ -21,14 +23,27 @@ def _stream_ptr(t):
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
-def _require_device(t, name):
+def _require_device(t, name, dtype=torch.float32):
     # same conditions, same exception type as CHECK_INPUT (cinc_cuda_level2.cpp:15-17)
     if not t.is_cuda:
         raise RuntimeError(f"{name} must be a CUDA tensor (fincflow_amd has no CPU fallback)")
     if not t.is_contiguous():
         raise RuntimeError(f"{name} must be contiguous")
-    if t.dtype != torch.float32:
-        raise ValueError(f"{name} must be float32, got {t.dtype}")
+    if t.dtype != dtype:
+        raise ValueError(f"{name} must be {dtype}, got {t.dtype}")
+
+
+def _float_dtype(t, name):
+    """float and double, the reference op's dispatch (AT_DISPATCH_FLOATING_TYPES, cinc_cuda_kernel_level2.cu:117)."""
+    if t.dtype not in (torch.float32, torch.float64):
+        raise ValueError(f"{name} must be float32 or float64, got {t.dtype}")
+    return t.dtype
+
+
+def release_workspaces():
+    """Drop every cached per-(device, stream) scratch buffer (they are re-created on demand).  For long-lived
+    processes that cycle through many streams; call it at a synchronisation point."""
+    _workspaces.clear()
 
 
 def _workspace(device, nbytes):
@@ -57,13 +72,15 @@ def _dims(act, w, G):
 def canonicalize(w_stored, G, orient):
     """State-dict form -> TL-canonical (fastflow.py:79-84).  The flip is an involution, so the same call
     maps canonical gradients back to stored form."""
-    _require_device(w_stored, "weights")
+    dt = _float_dtype(w_stored, "weights")
+    _require_device(w_stored, "weights", dt)
     out = torch.empty_like(w_stored)
     Cq = w_stored.shape[0] // G
+    fn = "finc_canonicalize_weights_f32" if dt == torch.float32 else "finc_canonicalize_weights_f64"
     with torch.cuda.device(w_stored.device):
-        st = _lib.lib().finc_canonicalize_weights_f32(w_stored.data_ptr(), out.data_ptr(), G, Cq, w_stored.shape[2],
-                                                      w_stored.shape[3], orient, _stream_ptr(w_stored))
-    _lib.check(st, "finc_canonicalize_weights_f32")
+        st = getattr(_lib.lib(), fn)(w_stored.data_ptr(), out.data_ptr(), G, Cq, w_stored.shape[2],
+                                     w_stored.shape[3], orient, _stream_ptr(w_stored))
+    _lib.check(st, fn)
     return out
 
 
@@ -77,18 +94,28 @@ def check_invariant(w_canon, G):
 
 
 def _run(fn_name, act, w_canon, G, orient, algo, out):
-    _require_device(act, "input")
-    _require_device(w_canon, "kernel")
+    dt = _float_dtype(act, "input")
+    _require_device(act, "input", dt)
+    _require_device(w_canon, "kernel", dt)
     B, Cq, H, W, KH, KW = _dims(act, w_canon, G)
     if out is None:
         out = torch.empty_like(act)
     else:
-        _require_device(out, "output")
+        _require_device(out, "output", dt)
         if out.shape != act.shape or out.device != act.device:
             raise ValueError("output must match input in shape and device")
     if act.numel() == 0:
         return out
     L = _lib.lib()
+    if dt == torch.float64:                # reference-order fp64 kernels: no packed form, no workspace
+        if algo not in ("auto", "strict"):
+            raise _lib.FincError(f"{fn_name}: float64 runs on the reference-order kernel only (algo auto/strict)")
+        fn64 = fn_name.replace("_f32", "_f64")
+        with torch.cuda.device(act.device):
+            st = getattr(L, fn64)(act.data_ptr(), w_canon.data_ptr(), out.data_ptr(), B, G, Cq, H, W, KH, KW, orient,
+                                  _stream_ptr(act))
+        _lib.check(st, fn64)
+        return out
     if fn_name == "finc_inverse_f32":      # room for the zero-padded copy an odd width is solved on
         nbytes = L.finc_inverse_workspace_bytes(B, G, Cq, H, W, KH, KW)
     else:
@@ -138,17 +165,17 @@ def inverse(input, kernel, output):
     kernel [G*Cq,Cq,KH,KW]  TL-canonical (fastflow.py:79-84); G = kernel.shape[0] // kernel.shape[1]
     output [B,C,H,W]        written in place; a one-element list aliasing it is returned.
     """
+    dt = _float_dtype(input, "input")
     for t, n in ((input, "input"), (kernel, "kernel"), (output, "output")):
-        _require_device(t, n)
+        _require_device(t, n, dt)
     G = kernel.shape[0] // kernel.shape[1]
     finc_inverse(input, kernel, G=G, orient=0, out=output)
     return [output]
 
 
-class PackedWeights:
-    """Sampling-time cache for one weight version: the TL-canonical bank (fastflow.py:79-84, done once instead of
-    every call), its invariant check, and the packed MFMA fragments (finc_pack_inverse_weights_f32), so that a
-    sampling step is exactly one kernel launch (finc_inverse_packed_f32).  Rebuilt when a source tensor changes."""
+class _DeviceBank:
+    """What PackedWeights holds for ONE device."""
+    __slots__ = ("key", "w_canon", "packed_inv", "packed_fwd", "packed_aff", "aff_key")
 
     def __init__(self):
         self.key = None
@@ -158,89 +185,130 @@ class PackedWeights:
         self.packed_aff = None
         self.aff_key = None
 
+
+class PackedWeights:
+    """Sampling-time cache for one weight version: the TL-canonical bank (fastflow.py:79-84, done once instead of
+    every call), its invariant check, and the packed MFMA fragments (finc_pack_inverse_weights_f32), so that a
+    sampling step is exactly one kernel launch (finc_inverse_packed_f32).  Rebuilt when a source tensor changes.
+
+    State is kept PER DEVICE: the reference wraps its models in nn.DataParallel (fastflow_cifar_multi_gpu.py:439-440),
+    whose replicas are shallow copies that share this object while their weights live on different devices and their
+    forwards run on different threads."""
+
+    def __init__(self):
+        self._banks = {}
+        self._lock = threading.Lock()
+
+    def _bank(self, device):
+        b = self._banks.get(device)
+        if b is None:
+            with self._lock:
+                b = self._banks.setdefault(device, _DeviceBank())
+        return b
+
     def invalidate(self):
         """Force a rebuild on the next call.  Needed after writes that do not bump Tensor._version
         (torch.distributed collectives, writes through `.data`)."""
-        self.key = None
-        self.packed_inv = None
-        self.packed_fwd = None
-        self.packed_aff = None
+        with self._lock:
+            self._banks = {}
+
+    # what single-device callers and tests read
+    @property
+    def w_canon(self):
+        banks = list(self._banks.values())
+        return banks[0].w_canon if len(banks) == 1 else None
 
     def get(self, weights, G, orient):
+        return self._get(weights, G, orient).w_canon
+
+    def _get(self, weights, G, orient):
+        bank = self._bank(weights[0].device)
         key = tuple((w.data_ptr(), w._version) for w in weights) + (orient,)
-        if key != self.key:
+        if key != bank.key:
             ws = torch.cat([w.detach() for w in weights], dim=0).contiguous()
-            self.w_canon = canonicalize(ws, G, orient)
-            check_invariant(self.w_canon, G)
-            self.packed_inv = None
-            self.packed_fwd = None
-            self.packed_aff = None
-            self.key = key
-        return self.w_canon
+            bank.w_canon = canonicalize(ws, G, orient)
+            check_invariant(bank.w_canon, G)
+            bank.packed_inv = None
+            bank.packed_fwd = None
+            bank.packed_aff = None
+            bank.key = key
+        return bank
 
     def forward(self, x, weights, G, orient, out=None):
         """Inference-time forward (no autograd graph): cached canonical bank + cached strip-kernel fragments."""
-        w_canon = self.get(weights, G, orient)
+        bank = self._get(weights, G, orient)
+        w_canon = bank.w_canon
         _require_device(x, "input")
         B, Cq, H, W, KH, KW = _dims(x, w_canon, G)
         L = _lib.lib()
         if x.numel() == 0 or L.finc_forward_algo_for(Cq, H, W, KH, KW) != _lib.ALGO["mfma"]:
             return finc_forward(x, w_canon, G, orient, out=out)
         with torch.cuda.device(x.device):
-            if self.packed_fwd is None:
-                self.packed_fwd = torch.empty(L.finc_workspace_bytes(G, Cq, KH, KW), dtype=torch.uint8, device=x.device)
-                _lib.check(L.finc_pack_forward_weights_f32(w_canon.data_ptr(), self.packed_fwd.data_ptr(), G, Cq, KH, KW,
+            if bank.packed_fwd is None:
+                bank.packed_fwd = torch.empty(L.finc_workspace_bytes(G, Cq, KH, KW), dtype=torch.uint8, device=x.device)
+                _lib.check(L.finc_pack_forward_weights_f32(w_canon.data_ptr(), bank.packed_fwd.data_ptr(), G, Cq, KH, KW,
                                                            _stream_ptr(x)), "finc_pack_forward_weights_f32")
             if out is None:
                 out = torch.empty_like(x)
-            _lib.check(L.finc_forward_packed_f32(x.data_ptr(), self.packed_fwd.data_ptr(), out.data_ptr(), B, G, Cq, H, W,
+            _lib.check(L.finc_forward_packed_f32(x.data_ptr(), bank.packed_fwd.data_ptr(), out.data_ptr(), B, G, Cq, H, W,
                                                  KH, KW, orient, _stream_ptr(x)), "finc_forward_packed_f32")
         return out
 
+    @staticmethod
+    def _packed_path_ok(L, t, out, Cq, H, W, KH, KW):
+        """The packed launch streams 16-byte pieces: it needs an MFMA instantiation AND 16-byte aligned activations
+        (a view into a larger allocation may be only 4-byte aligned; INTEGRATION.md: such calls fall back)."""
+        if t.numel() == 0 or L.finc_inverse_algo_for(Cq, H, W, KH, KW) != _lib.ALGO["mfma"]:
+            return False
+        ptrs = t.data_ptr() | (out.data_ptr() if out is not None else 0)
+        return (ptrs & 15) == 0
+
     def inverse(self, z, weights, G, orient, out=None):
-        w_canon = self.get(weights, G, orient)
+        bank = self._get(weights, G, orient)
+        w_canon = bank.w_canon
         _require_device(z, "input")
         B, Cq, H, W, KH, KW = _dims(z, w_canon, G)
         L = _lib.lib()
-        if z.numel() == 0 or L.finc_inverse_algo_for(Cq, H, W, KH, KW) != _lib.ALGO["mfma"]:
+        if out is None and z.numel():
+            out = torch.empty_like(z)
+        if not self._packed_path_ok(L, z, out, Cq, H, W, KH, KW):
             return finc_inverse(z, w_canon, G, orient, out=out)
         with torch.cuda.device(z.device):
-            if self.packed_inv is None:
-                self.packed_inv = torch.empty(L.finc_workspace_bytes(G, Cq, KH, KW), dtype=torch.uint8, device=z.device)
-                _lib.check(L.finc_pack_inverse_weights_f32(w_canon.data_ptr(), self.packed_inv.data_ptr(), G, Cq, KH, KW,
+            if bank.packed_inv is None:
+                bank.packed_inv = torch.empty(L.finc_workspace_bytes(G, Cq, KH, KW), dtype=torch.uint8, device=z.device)
+                _lib.check(L.finc_pack_inverse_weights_f32(w_canon.data_ptr(), bank.packed_inv.data_ptr(), G, Cq, KH, KW,
                                                            _stream_ptr(z)), "finc_pack_inverse_weights_f32")
-            if out is None:
-                out = torch.empty_like(z)
-            _lib.check(L.finc_inverse_packed_f32(z.data_ptr(), self.packed_inv.data_ptr(), out.data_ptr(), B, G, Cq, H, W,
+            _lib.check(L.finc_inverse_packed_f32(z.data_ptr(), bank.packed_inv.data_ptr(), out.data_ptr(), B, G, Cq, H, W,
                                                  KH, KW, orient, _stream_ptr(z)), "finc_inverse_packed_f32")
         return out
-
 
     def inverse_affine(self, y, weights, G, orient, log_scale, translation, out=None):
         """inverse(exp(log_scale) * y + translation) in ONE launch: the per-channel affine layer in front
         of the unit in the reverse chain (ActNorm.reverse, layers/actnorm.py:39-52) is folded into the packed bank.
-        Returns None when the shape has no MFMA instantiation (the caller then runs the two layers one after the other)."""
-        w_canon = self.get(weights, G, orient)
+        Returns None when the shape has no MFMA instantiation or the activations are not 16-byte aligned (the caller
+        then runs the two layers one after the other)."""
+        bank = self._get(weights, G, orient)
+        w_canon = bank.w_canon
         _require_device(y, "input")
         B, Cq, H, W, KH, KW = _dims(y, w_canon, G)
         L = _lib.lib()
-        if y.numel() == 0 or L.finc_inverse_algo_for(Cq, H, W, KH, KW) != _lib.ALGO["mfma"]:
+        if out is None and y.numel():
+            out = torch.empty_like(y)
+        if not self._packed_path_ok(L, y, out, Cq, H, W, KH, KW):
             return None
         key = (log_scale.data_ptr(), log_scale._version, translation.data_ptr(), translation._version)
         with torch.cuda.device(y.device):
-            if self.packed_aff is None or self.aff_key != key:
+            if bank.packed_aff is None or bank.aff_key != key:
                 scale = torch.exp(log_scale.detach().float()).contiguous()
                 shift = translation.detach().float().contiguous()
                 if scale.numel() != G * Cq or shift.numel() != G * Cq:
                     raise ValueError("affine parameters must have one entry per channel")
-                self.packed_aff = torch.empty(L.finc_workspace_bytes(G, Cq, KH, KW), dtype=torch.uint8, device=y.device)
+                bank.packed_aff = torch.empty(L.finc_workspace_bytes(G, Cq, KH, KW), dtype=torch.uint8, device=y.device)
                 _lib.check(L.finc_pack_inverse_weights_affine_f32(w_canon.data_ptr(), scale.data_ptr(), shift.data_ptr(),
-                                                                  self.packed_aff.data_ptr(), G, Cq, KH, KW, _stream_ptr(y)),
+                                                                  bank.packed_aff.data_ptr(), G, Cq, KH, KW, _stream_ptr(y)),
                            "finc_pack_inverse_weights_affine_f32")
-                self.aff_key = key
-            if out is None:
-                out = torch.empty_like(y)
-            _lib.check(L.finc_inverse_packed_f32(y.data_ptr(), self.packed_aff.data_ptr(), out.data_ptr(), B, G, Cq, H, W,
+                bank.aff_key = key
+            _lib.check(L.finc_inverse_packed_f32(y.data_ptr(), bank.packed_aff.data_ptr(), out.data_ptr(), B, G, Cq, H, W,
                                                  KH, KW, orient, _stream_ptr(y)), "finc_inverse_packed_f32")
         return out
 

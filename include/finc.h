@@ -11,7 +11,8 @@
  *
  * and the cuDNN convolution behind PaddedConv2d.forward (layers/conv.py:102-107)
  * with plain-pointer functions: no torch types, no global state besides a
- * per-process table of kernel attributes.  Every function is stream-ordered
+ * per-process table of (device, kernel) attributes and one 4-byte flag word per
+ * device (finc_check_invariant_f32).  Every function is stream-ordered
  * and asynchronous unless its comment says otherwise; every pointer is a
  * DEVICE pointer unless its name starts with `h_`.
  *
@@ -75,8 +76,8 @@ const char *finc_last_hip_error(void);
 int finc_canonicalize_weights_f32(const float *w_stored, float *w_canon, int G, int Cq, int KH, int KW,
                                   unsigned orient, finc_stream_t stream);
 
-/* SYNCHRONOUS (one 4-byte D2H copy on `stream`).  Returns FINC_OK or FINC_ERR_INVARIANT.
- * Call once per weight version, not per step. */
+/* SYNCHRONOUS (one 4-byte D2H copy on `stream`; the device flag word is allocated once per device and kept).
+ * Returns FINC_OK or FINC_ERR_INVARIANT.  Call once per weight version, not per step. */
 int finc_check_invariant_f32(const float *w_canon, int G, int Cq, int KH, int KW, finc_stream_t stream);
 
 /* Scratch the AUTO/MFMA algos need (packed filter fragments); 0 is never returned. */
@@ -158,6 +159,36 @@ size_t finc_backward_workspace_bytes(int B, int G, int Cq, int H, int W, int KH,
 int finc_backward_f32(const float *grad_z, const float *x, const float *w_canon, float *grad_x, float *grad_w_canon,
                       int B, int G, int Cq, int H, int W, int KH, int KW, unsigned orient, void *workspace,
                       size_t workspace_bytes, finc_stream_t stream);
+
+/*
+ * Double precision: the reference op dispatches over float AND double (AT_DISPATCH_FLOATING_TYPES,
+ * cinc_cuda_kernel_level2.cu:117), and its CPU solver computes in fp64 (solve_parallel_mc.pyx:77-126, called from
+ * layers/conv.py:113-163).  These entry points run the reference visitation and term order in fp64 (separately
+ * rounded multiply and subtract): finc_inverse_f64 is bit-exact with that solver.  Same layout and orientation rules
+ * as the f32 calls; no workspace, no packed form, any shape.
+ */
+int finc_canonicalize_weights_f64(const double *w_stored, double *w_canon, int G, int Cq, int KH, int KW,
+                                  unsigned orient, finc_stream_t stream);
+int finc_inverse_f64(const double *z, const double *w_canon, double *x, int B, int G, int Cq, int H, int W, int KH,
+                     int KW, unsigned orient, finc_stream_t stream);
+int finc_forward_f64(const double *x, const double *w_canon, double *z, int B, int G, int Cq, int H, int W, int KH,
+                     int KW, unsigned orient, finc_stream_t stream);
+
+/*
+ * Introspection (tests, diagnostics; no reference counterpart).
+ * finc_inverse_kernel_variant: which MFMA inverse kernel FINC_ALGO_AUTO / finc_inverse_packed_f32 launches for this
+ *   problem.  info[8] = {Cq padded to 4, waves per problem (K-split), problems per workgroup, 1 = 32-byte I/O /
+ *   0 = 16-byte I/O, LDS bytes per workgroup, workgroups, row of the instantiation table, rows in the table}.
+ *   FINC_ERR_UNSUPPORTED when the shape runs on the strict kernel.
+ * finc_debug_attr_table_insert: the (device, kernel) table behind the once-per-device kernel attributes; returns 1 if
+ *   the pair was new.  Host-only; exists so the key logic is testable without two GPUs.
+ * finc_debug_inverse_table_row: row `row` of the MFMA inverse instantiation table, info[6] = {Cq padded, KH, KW, waves
+ *   per problem, problems per workgroup, max_problems (0 = none)}; FINC_ERR_BAD_DIMS past the end.  Lets a test walk
+ *   every compiled variant.
+ */
+int finc_inverse_kernel_variant(int B, int G, int Cq, int H, int W, int KH, int KW, int *info);
+int finc_debug_inverse_table_row(int row, int *info);
+int finc_debug_attr_table_insert(int device, size_t kernel_token);
 
 #ifdef __cplusplus
 }

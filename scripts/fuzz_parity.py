@@ -3,7 +3,10 @@ through autograd).  Usage: python scripts/fuzz_parity.py [n_cases] [seed].  Exit
 import os, sys
 import numpy as np
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+sys.path.insert(0, os.path.join(REPO, "tests"))
+from helpers import fuzz_case          # the generator tests/test_gpu_variants.py::test_bounded_fuzz_sweep uses
 from fincflow_amd import ops
 from oracle import oracle
 
@@ -13,15 +16,8 @@ dev = torch.device("cuda:0")
 ORI = 0xE4
 worst = 0.0
 for case in range(n):
-    K = int(rng.choice([2, 3, 3, 3, 5]))
-    cq_opts = [1, 2, 3, 4, 6, 8, 12, 16, 20, 24, 28, 32, 40, 48, 64] if K == 3 else ([1, 3, 4, 8, 12, 13, 16, 24, 32] if K == 2 else [2, 4, 8, 12, 16, 32, 48])
-    Cq = int(rng.choice(cq_opts))
-    G = int(rng.choice([1, 4, 4, 4]))
-    H = int(rng.integers(1, 41))
-    W = int(rng.choice([rng.integers(1, 41), 4 * rng.integers(1, 12), 8 * rng.integers(1, 9)]))
-    B = int(rng.integers(1, 4))
-    orient = ORI if G == 4 else int(rng.integers(0, 4))
-    std = (0.05 if K < 5 else 0.02) * min(1.0, (24.0 / Cq) ** 0.5)   # keep the operator norm of the bank roughly constant
+    c = fuzz_case(rng, case)
+    B, G, Cq, H, W, K, orient, std = c["B"], c["G"], c["Cq"], c["H"], c["W"], c["K"], c["orient"], c["std"]
     ws = oracle.make_stored_weights(G, Cq, K, K, orient=orient, seed=case, std=std)
     wco = oracle.canonicalize(ws, G, orient)
     x = rng.standard_normal((B, G * Cq, H, W)).astype(np.float32)

@@ -75,3 +75,46 @@ def test_check_raises_python_exceptions():
         _lib.check(2, "x")
     with pytest.raises(_lib.FincError):
         _lib.check(3, "x")
+
+
+def test_variant_plan_covers_every_row_and_agrees_with_the_library():
+    """Host side of tests/test_gpu_variants.py: for every row of the MFMA inverse's instantiation table the planned
+    problem counts really select that row (the library's own answer, a host-only call), in the 32-byte-I/O and the
+    16-byte form -- so the GPU test provably launches every compiled variant."""
+    from helpers import problem_counts_for_row, split_problems
+    rows = _lib.inverse_table()
+    assert len(rows) >= 28
+    hit = set()
+    for r, i in enumerate(rows):
+        counts = problem_counts_for_row(rows, r)
+        assert counts, (r, i)
+        for n in counts:
+            B, G, _ = split_problems(n)
+            for sec, (H, W) in ((1, (19, 24)), (0, (9, 20))):
+                v = _lib.inverse_variant(B, G, i["cqp"], H, W, i["kh"], i["kw"])
+                assert v is not None and v["row"] == r and v["sec"] == sec and v["nw"] == i["nw"] and v["npw"] == i["npw"], (r, n, v)
+                assert v["workgroups"] * v["npw"] == B * G and v["lds_bytes"] <= 160 * 1024
+                hit.add((r, sec))
+    assert len(hit) == 2 * len(rows)
+    # the bench shapes: c3 at full batch is the one-wave kernel, at B <= 128 the packed 2-wave split; c5 is the 4-wave split
+    assert _lib.inverse_variant(256, 4, 24, 64, 64, 3, 3)["nw"] == 1
+    assert (_lib.inverse_variant(128, 4, 24, 64, 64, 3, 3)["nw"], _lib.inverse_variant(128, 4, 24, 64, 64, 3, 3)["npw"]) == (2, 2)
+    assert _lib.inverse_variant(64, 4, 48, 128, 128, 5, 5)["nw"] == 4
+    assert _lib.inverse_variant(2, 4, 24, 16, 15, 3, 3) is None          # W % 4 != 0: strict kernel
+
+
+def test_kernel_attribute_table_is_keyed_by_device_and_kernel():
+    """finc_mfma_launch sets the 160 KiB dynamic-LDS attribute once per (device, kernel) -- a per-thread or per-kernel-only
+    cache would skip the second device of a process that drives two.  Key logic, host only."""
+    L = _lib.lib()
+    tok = 0x7E57_0000
+    assert L.finc_debug_attr_table_insert(5, tok) == 1          # new pair
+    assert L.finc_debug_attr_table_insert(5, tok) == 0          # seen
+    assert L.finc_debug_attr_table_insert(6, tok) == 1          # same kernel, other device: must be set again
+    assert L.finc_debug_attr_table_insert(5, tok + 8) == 1      # other kernel, same device
+    import threading
+    got = []
+    th = [threading.Thread(target=lambda: got.append(L.finc_debug_attr_table_insert(7, tok))) for _ in range(8)]
+    [x.start() for x in th]
+    [x.join() for x in th]
+    assert sorted(got) == [0] * 7 + [1]                         # exactly one thread sets it

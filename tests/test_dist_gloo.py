@@ -32,10 +32,10 @@ def _worker(rank, world, port, q):
         torch.manual_seed(100 + rank)                      # ranks start with DIFFERENT weights
         unit = FastFlowUnit(8, 8, 3)
         before = [w.detach().clone() for w in unit._weights()]
-        unit._cache.key = ("stale",)                       # pretend the sampling cache was built before the broadcast
+        unit._cache._bank(torch.device("cpu")).key = ("stale",)   # pretend the sampling cache was built before the broadcast
         fdist.broadcast_weights(unit, src=0)
         after = [w.detach().clone() for w in unit._weights()]
-        bumped = unit._cache.key is None                   # ... and check the broadcast dropped it
+        bumped = not unit._cache._banks                    # ... and check the broadcast dropped it
         full = torch.arange(7 * 3, dtype=torch.float32).reshape(7, 3)
         mine = fdist.shard_batch(full)
         gathered = fdist.gather_shards(mine * 2, 7)

@@ -105,5 +105,10 @@ def test_full_config4_model_samples_and_reconstructs():
         assert z.shape == (8, 192, 4, 4) and logp.shape == (8,) and torch.isfinite(logp).all()
         xr = model.reconstruct(x)
         assert rel_err(xr.cpu().numpy(), x.cpu().numpy()) <= 1e-4
-        s = model.sample(128)
+        s, s_true = model.sample(128)           # (input, input_true): layers/flowsequential.py:89-115
+        assert s_true is s
         assert s.shape == (128, 3, 32, 32) and torch.isfinite(s).all()
+        # the "true inverse" re-runs the chain from the same z layer by layer (no affine fold): same samples
+        torch.manual_seed(5)
+        a, a_true = model.sample(16, also_true_inverse=True)
+        assert a_true is not a and rel_err(a.cpu().numpy(), a_true.cpu().numpy()) <= 1e-4

@@ -200,7 +200,9 @@ def test_padded_module_and_sequential(dev):
     zz, logp = seq(x)
     assert logp.shape == (3,)
     assert rel_err(seq.reconstruct(x).cpu().numpy(), x.cpu().numpy()) <= 1e-5
-    assert seq.sample(2).shape == (2, 8, 16, 16)
+    xs, xs_true = seq.sample(2)                       # the runner unpacks two values (train/experiment.py:311-335)
+    assert xs.shape == (2, 8, 16, 16) and xs_true is xs
+    _, _ = seq.sample(n_samples=1, compute_expensive=False, also_true_inverse=False)
 
 
 def test_weight_update_invalidates_cache(dev):

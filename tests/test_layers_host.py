@@ -66,6 +66,31 @@ def test_flowsequential_protocol_shape():
     assert len(list(seq)) == 2 and hasattr(seq, "sample") and hasattr(seq, "log_prob")
 
 
+def test_flowsequential_sample_contract_of_the_runner():
+    """layers/flowsequential.py:89-115 returns `(input, input_true)`; the runner unpacks two values, with keyword
+    arguments (train/experiment.py:311-335).  Host-only layers here: the contract is container logic."""
+    from fincflow_amd import glow
+    torch.manual_seed(0)
+    an = glow.ActNorm(4)
+    with torch.no_grad():
+        an.log_scale.copy_(torch.tensor([0.1, -0.2, 0.3, 0.0]))
+        an.translation.copy_(torch.tensor([1.0, 2.0, -1.0, 0.5]))
+        an.initialized.fill_(1)
+    model = FlowSequential(StandardNormal((4, 4, 4)), glow.Squeeze(), an)
+    with torch.no_grad():
+        _, _ = model.sample(n_samples=1, compute_expensive=False, also_true_inverse=False)     # experiment.py:311-320
+        x_sample, x_sample_trueinv = model.sample(n_samples=3, compute_expensive=False, also_true_inverse=True)
+    assert x_sample.shape == (3, 1, 8, 8) and x_sample_trueinv.shape == (3, 1, 8, 8)
+    assert x_sample_trueinv is not x_sample and torch.equal(x_sample, x_sample_trueinv)       # same z, same chain
+    with torch.no_grad():
+        a, b = model.sample(2)
+        c, d = model.sample(2, compute_expensive=True, also_true_inverse=True)
+    assert b is a and d is c                                                                  # `input_true = input`
+    x = torch.randn(2, 1, 8, 8)
+    with torch.no_grad():
+        assert torch.allclose(model.reconstruct(x), x, atol=1e-6)
+
+
 def test_cincflowunit_contract():
     """cinc_flow.py:9-24: one TL PaddedConv2d over ALL channels (out_channels overridden), no C%4 rule."""
     from fincflow_amd import CINCFlowUnit
@@ -99,3 +124,20 @@ def test_load_reference_checkpoint(tmp_path):
     with pytest.raises(RuntimeError, match="unit-triangular"):
         load_reference_checkpoint(model, bad)
     load_reference_checkpoint(model, bad, validate=False)
+
+
+def test_packed_cache_is_per_device():
+    """nn.DataParallel replicas (fastflow_cifar_multi_gpu.py:439-440) are shallow copies sharing `_cache`: its state
+    must be keyed by device so replica threads never overwrite each other's bank.  Key logic only (no launch)."""
+    import copy
+    from fincflow_amd.ops import PackedWeights
+    c = PackedWeights()
+    a, b = c._bank(torch.device("cuda", 0)), c._bank(torch.device("cuda", 1))
+    assert a is not b and c._bank(torch.device("cuda", 0)) is a
+    a.key = ("v1",)
+    assert b.key is None
+    u = FastFlowUnit(4, 4, 3)
+    replica = copy.copy(u)                      # what DataParallel.replicate does to a module object
+    assert replica._cache is u._cache
+    c.invalidate()
+    assert not c._banks and c.w_canon is None

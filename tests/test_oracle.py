@@ -162,3 +162,30 @@ def test_openmp_threads_do_not_change_results():
     a = oracle.inverse_f32(z, wc, nthreads=1)
     b = oracle.inverse_f32(z, wc, nthreads=4)
     assert np.array_equal(a, b)
+
+
+def test_config5_init_std_is_unstable_in_the_reference_arithmetic():
+    """configs[4] (5x5, Cq=48) at the reference's init std 0.05 (layers/conv.py:64): the inverse ITSELF diverges -- in the
+    reference's own fp64 arithmetic |inverse(N(0,1))| grows by orders of magnitude across a 48x48 map -- so no fp32
+    implementation (the reference's included) can hold 1e-5 there.  The c5 parity and bench runs therefore use std 0.02
+    (same operator norm as 3x3 / Cq=24; precedent for scaling with k^2: cuda/cinc_cuda/test_large_cuda_kernel.py:12-13).
+    This test pins the measurement behind that deviation."""
+    rng = np.random.default_rng(0)
+    z = rng.standard_normal((1, 48, 48, 48)).astype(np.float32)
+    grow = {}
+    for std in (0.05, 0.02):
+        wc = oracle.make_stored_weights(1, 48, 5, 5, orient=0, seed=1234, std=std)
+        x = oracle.inverse_f64(z, wc, 1)
+        grow[std] = float(np.abs(x).max())
+    assert grow[0.05] > 1e5, grow          # diverges (3e7 measured)
+    assert grow[0.02] < 50, grow           # the std the c5 runs use stays O(|z|)
+    # and a round trip through fp32 storage cannot survive the unstable case even with an fp64 solve: the 1e-7 rounding
+    # of z = forward(x) is amplified like everything else
+    x = rng.standard_normal((1, 48, 48, 48)).astype(np.float32)
+    err = {}
+    for std in (0.05, 0.02):
+        wc = oracle.make_stored_weights(1, 48, 5, 5, orient=0, seed=1234, std=std)
+        zz = oracle.forward_f32(x, wc, 1, 0)
+        xr = oracle.inverse_via_f64(zz, wc, 1, 0)
+        err[std] = float(np.abs(xr - x).max() / np.abs(x).max())
+    assert err[0.05] > 1e-3 and err[0.02] < 1e-5, err
