@@ -39,6 +39,8 @@
 #include "finc_common.h"
 #include "finc_tile.h"
 
+#include <stdlib.h>
+
 #include <type_traits>
 #include <utility>
 
@@ -170,6 +172,14 @@ struct BTaps {
 #ifndef FINC_ABLATE_IO   // timing-only bit mask: 1 no loads, 2 no stores, 4 no landing, 8 no x-ring read
 #define FINC_ABLATE_IO 0
 #endif
+// Experiment builds only (scripts/build_variant.sh): cache-policy bits of the activation loads / stores
+// (gfx940+: bit 0 = sc0, bit 1 = nt, bit 4 = sc1).  The product is built with 0.
+#ifndef FINC_LD_AUX
+#define FINC_LD_AUX 0
+#endif
+#ifndef FINC_ST_AUX
+#define FINC_ST_AUX 0
+#endif
 template <int I>
 using IC = std::integral_constant<int, I>;
 
@@ -207,7 +217,24 @@ constexpr unsigned OFF_BAD_CHANNEL = 0x40000000u; // added to a valid offset it 
 // workgroup do not spread over the CU: with 2-wave workgroups only two of the four SIMDs ever get work (measured: the
 // time of a 2-wave K-split doubles as soon as a CU holds two workgroups), so two such problems are packed into one
 // 4-wave workgroup.  The packed problems share nothing but the barrier.
-template <int CQP, int KH, int KW, bool SEC, int NW = 1, int NPW = 1>
+// S64 ("sector pairing", W % 16 == 0, one wave per problem): HBM is touched in whole 64-byte sectors.  The memory system
+// behind L2 pays per request, and a 32-byte write is a partial write of the 64-byte memory granule: with 32-byte pieces
+// the c3 inverse hits a wall as soon as all four SIMDs of every CU stream (B = 256: 0.48 ms against 0.41 at B = 192;
+// profiles/r02/notes).  A sector's two pieces are therefore moved by the SAME lanes in two instructions back to back
+// (the second is an L2 hit / completes the line the first one opened):
+//   loads   at the event of a LOWER piece a lane asks for the lower piece (-> ZL, lands one event later, as before) and
+//           the upper piece (-> ZU, lands two events later -- exactly when the old schedule landed it); nothing is
+//           requested at the event of an upper piece.
+//   stores  a completed LOWER piece is parked (PK) instead of stored; one event later the upper piece is complete and
+//           both leave together.
+// S64 is a bit mask: 1 = stores paired, 2 = loads paired too.
+// ZU and PK live in accumulation registers -- the one resource this kernel has to spare (VGPRs: 234 of 256, LDS:
+// 40.6 of 40.96 KB per wave, AGPRs: 159 of 256) -- and are read where they are: VMEM loads write AGPRs, DS and VMEM
+// stores read them, so the parked data costs no VALU instruction.  The price is that these loads are inline asm, which
+// hipcc does not count: the kernel waits for them itself (one s_waitcnt vmcnt per event; the instruction order of a
+// window is fixed, so the count is a constant) and ALL z loads of this variant are asm so that hipcc has no VMEM load of
+// its own to mis-count around them.
+template <int CQP, int KH, int KW, bool SEC, int NW = 1, int NPW = 1, int S64 = 0>
 __global__ __launch_bounds__(64 * NW * NPW) void finc_wave_kernel(const float *__restrict__ in,
                                                             const float *__restrict__ packed, float *__restrict__ out,
                                                             int G, int CQ, int H, int W, int P, int Tend,
@@ -229,10 +256,14 @@ __global__ __launch_bounds__(64 * NW * NPW) void finc_wave_kernel(const float *_
     const bool fh = (o & FINC_FLIP_H) != 0, fw = (o & FINC_FLIP_W) != 0;
     const int HW = H * W;
     const unsigned slab_bytes = (unsigned)CQ * (unsigned)HW * 4u;
+#ifndef FINC_SAMEBUF     // timing-only experiment: bit 0 = every problem reads one of 32 slabs, bit 1 = writes one of 32
+#define FINC_SAMEBUF 0   // (the working set then lives in L2 / Infinity Cache: separates DRAM from CU-side limits)
+#endif
+    const int bg_in = (FINC_SAMEBUF & 1) ? bg % 32 : bg, bg_out = (FINC_SAMEBUF & 2) ? bg % 32 : bg;
     const __amdgpu_buffer_rsrc_t rin =
-        __builtin_amdgcn_make_buffer_rsrc((void *)(in + (size_t)bg * CQ * HW), 0, (int)slab_bytes, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc((void *)(in + (size_t)bg_in * CQ * HW), 0, (int)slab_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rout =
-        __builtin_amdgcn_make_buffer_rsrc((void *)(out + (size_t)bg * CQ * HW), 0, (int)slab_bytes, 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc((void *)(out + (size_t)bg_out * CQ * HW), 0, (int)slab_bytes, 0x00020000);
     const int D = W - P + 1;                  // FIFO depth (steps between a band's last rows and the next band's first)
     const int fifo_n = D * SS;
     // LDS: [exchange buffer (K-split only)] then per wave: z ring | x ring | FIFO + trash
@@ -245,31 +276,61 @@ __global__ __launch_bounds__(64 * NW * NPW) void finc_wave_kernel(const float *_
     const int trash = fifo_n + lane;          // per-lane scratch word(s): lanes that neither push nor pop point here
 
     // ---- filter fragments -> registers -------------------------------------------------------
+    // 16-row-tile fragments: one register each (af[f], f = the fragment's index); 4-row-block fragments: four to a
+    // register (afs[s >> 2], ABID = s & 3, s = the block fragment's ordinal in issue order -- finc_tile.h).  The packed
+    // bank in memory keeps one 64-lane fragment per (tap, k-step, tile): a lane of a packed register simply reads the
+    // fragment its pixel quad stands for.
+    constexpr int NSMALL = (NFRAG / MT) * C::NSM, NSR = (NSMALL + 3) / 4;
     float af[NFRAG];
+    float afs[NSR > 0 ? NSR : 1];
     {
         // packed index: z-term (j*MT + mt), then taps ((tap-1)*NKDT + j)*MT + mt, j global; this wave's j = wv*N + jl
         const float *pk = packed + (size_t)g * C::NPACK * 64 + lane;
+        auto gindex = [&](int f) {
+            if (f < NKZ * MT) return (wv * NKZ + f / MT) * MT + f % MT;
+            const int ff = f - NKZ * MT;
+            return C::NKZT * MT + ((ff / (MT * NKD)) * C::NKDT + wv * NKD + (ff / MT) % NKD) * MT + ff % MT;
+        };
 #pragma unroll
         for (int f = 0; f < NFRAG; ++f) {
-            int gi;
+            if (f % MT >= C::MTB) continue;    // a 4-row block: packed below
             if (NW == 1 && f < NKZ * MT && finc_zterm_is_zero(C::MTB, f / MT, f % MT)) { af[f] = 0.f; continue; }
-            if (f < NKZ * MT) {
-                gi = (wv * NKZ + f / MT) * MT + f % MT;
-            } else {
-                const int ff = f - NKZ * MT;
-                gi = C::NKZT * MT + ((ff / (MT * NKD)) * C::NKDT + wv * NKD + (ff / MT) % NKD) * MT + ff % MT;
+            af[f] = pk[gindex(f) * 64];
+        }
+        const int quad = (lane & 15) >> 2;
+#pragma unroll
+        for (int r = 0; r < NSR; ++r) {
+            int gi = 0;
+#pragma unroll
+            for (int a = 3; a >= 0; --a) {
+                const int sfr = 4 * r + a < NSMALL ? 4 * r + a : NSMALL - 1;
+                const int f = (sfr / C::NSM) * MT + C::MTB + sfr % C::NSM;
+                const int ga = gindex(f);
+                gi = (a == 3 || quad == a) ? ga : gi;
             }
-            af[f] = pk[gi * 64];
+            afs[r] = pk[gi * 64];
         }
         // The fragments are only ever MFMA A operands, which may be AGPRs; everything the VALU touches must be a
         // VGPR and there are only 256 of each.  Pin the fragments to AGPRs so the allocator does not shuffle
         // operands between the two files (v_accvgpr_* moves are VALU issue that f32 MFMAs do not hide).
 #pragma unroll
         for (int f = 0; f < NFRAG; ++f) {
+            if (f % MT >= C::MTB) continue;
             if (NW == 1 && f < NKZ * MT && finc_zterm_is_zero(C::MTB, f / MT, f % MT)) continue;   // never read
             asm volatile("" : "+a"(af[f]));
         }
+#pragma unroll
+        for (int r = 0; r < NSR; ++r) asm volatile("" : "+a"(afs[r]));
     }
+    // one accumulator update with fragment f (tile mt = f % MT)
+    auto mma = [&](v4f &acc_, int f, float b) {
+        const int mt = f % MT;
+        if (mt < C::MTB) acc_ = __builtin_amdgcn_mfma_f32_16x16x4f32(af[f], b, acc_, 0, 0, 0);
+        else {
+            const int sfr = (f / MT) * C::NSM + (mt - C::MTB);
+            finc_mma_small(acc_, afs[sfr >> 2], b, sfr & 3);
+        }
+    };
     v4f bias[MT];                             // initial value of a pixel's accumulators (zero unless an affine map is folded in)
     {
         const float *pb = packed + ((size_t)g * C::NPACK + C::NFRAGT + (wv == 0 ? 0 : 4 * MT)) * 64 + lane;
@@ -361,10 +422,89 @@ __global__ __launch_bounds__(64 * NW * NPW) void finc_wave_kernel(const float *_
     const int xprt[4] = {(((part + k0) & 7) ^ 4) * 64 + q * 16 + part, (((part + k1) & 7) ^ 4) * 64 + q * 16 + part,
                          (((part + k2) & 7) ^ 4) * 64 + q * 16 + part, (((part + k3) & 7) ^ 4) * 64 + q * 16 + part};
     unsigned st_off = OFF_INVALID;
+    // ---- sector pairing state (S64: bit 0 stores, bit 1 loads)
+    static_assert(!S64 || (SEC && NW == 1 && NPW == 1), "sector pairing: one wave per problem, 32-byte pieces");
+    constexpr bool S64S = (S64 & 1) != 0, S64L = (S64 & 2) != 0;
+    // the lower pieces of the load side stay in Z (VGPRs, written by asm loads in this variant); the upper pieces (ZU) and
+    // the parked store pieces (PK) are the new state and live in AGPRs
+    constexpr bool PK_AGPR = S64S;
+    v4u ZU[2][S64L ? NKZ : 1];
+    v4f PK[2][S64S ? NKD : 1];                // parked lower pieces of the store side
+    int lphi[2] = {0, 0};                     // phase (0 lower / 1 upper) of the piece of the stream's previous event
+    bool spark = false;                       // this window's piece is a lower one: park it
+    unsigned st_off2 = OFF_INVALID;           // where the parked lower piece goes when its upper piece leaves
+    if constexpr (S64L) {
+#pragma unroll
+        for (int wp = 0; wp < 2; ++wp)
+#pragma unroll
+            for (int j = 0; j < NKZ; ++j) {
+                ZU[wp][j] = (v4u){0u, 0u, 0u, 0u}; asm volatile("" : "+a"(ZU[wp][j]));
+            }
+    }
+    if constexpr (S64S) {
+#pragma unroll
+        for (int wp = 0; wp < 2; ++wp)
+#pragma unroll
+            for (int j = 0; j < NKD; ++j) {
+                PK[wp][j] = (v4f){0.f, 0.f, 0.f, 0.f};
+                if constexpr (PK_AGPR) asm volatile("" : "+a"(PK[wp][j]));
+            }
+    }
+    // S64 landing: `vm` = the s_waitcnt vmcnt immediate that covers the lower pieces issued two windows ago (everything
+    // older, the upper pieces of four windows ago included, is then complete as well: the counter is in order)
+    auto s64_event = [&](auto wp_c, auto vm_c) {
+        constexpr int WP = decltype(wp_c)::value;
+        constexpr int VM = decltype(vm_c)::value;
+        if constexpr (S64L) {
+            float *dst = zring + lslotS[WP] * 64 + ldst[WP];
+            float *d0 = dst + k0 * 64, *d1 = dst + k1 * 64, *d2 = dst + k2 * 64, *d3 = dst + k3 * 64;
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM) : "memory");
+            if (lphi[WP] == 0) {               // (divergent; both sides always have lanes: W % 16 == 0 keeps the rows' phases apart)
+                asm volatile("; land lower");
+#pragma unroll
+                for (int j = 0; j < NKZ; ++j) {
+                    const unsigned a0 = Z[WP][j].x, a1 = Z[WP][j].y, a2 = Z[WP][j].z, a3 = Z[WP][j].w;
+                    d0[j * C::ZSLOTS * 64] = __builtin_bit_cast(float, a0);
+                    d1[j * C::ZSLOTS * 64] = __builtin_bit_cast(float, a1);
+                    d2[j * C::ZSLOTS * 64] = __builtin_bit_cast(float, a2);
+                    d3[j * C::ZSLOTS * 64] = __builtin_bit_cast(float, a3);
+                }
+            } else {
+                asm volatile("; land upper");  // (the compiler reads the AGPR tuple element by element: 4 v_accvgpr_read per piece)
+#pragma unroll
+                for (int j = 0; j < NKZ; ++j) {
+                    const unsigned a0 = ZU[WP][j].x, a1 = ZU[WP][j].y, a2 = ZU[WP][j].z, a3 = ZU[WP][j].w;
+                    d0[j * C::ZSLOTS * 64] = __builtin_bit_cast(float, a0);
+                    d1[j * C::ZSLOTS * 64] = __builtin_bit_cast(float, a1);
+                    d2[j * C::ZSLOTS * 64] = __builtin_bit_cast(float, a2);
+                    d3[j * C::ZSLOTS * 64] = __builtin_bit_cast(float, a3);
+                }
+            }
+            lslotS[WP] = lslotS[WP] >= 4 ? lslotS[WP] - 4 : lslotS[WP] + 8;   // + 8 mod 12
+            const int phi = ((lcolS[WP] + 64) >> 3) & 1;
+            lphi[WP] = phi;
+            if (phi == 0) {                    // a lower piece: ask for the whole sector (exec-masked: the other lanes' ZU is waiting to land)
+                const bool ok = lcolS[WP] >= 0 && lrowS[WP] < H && p < P;
+                const unsigned vl = ok ? (unsigned)loffS[WP] : OFF_INVALID;
+                const unsigned vu = ok ? (unsigned)(loffS[WP] + 32 * dirw) : OFF_INVALID;
+#pragma unroll
+                for (int j = 0; j < NKZ; ++j) {
+                    const unsigned ol = j == NKZ - 1 ? vl + zlast : vl, ou = j == NKZ - 1 ? vu + zlast : vu;
+                    const int so = __builtin_amdgcn_readfirstlane(j * 16 * HW);
+                    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(Z[WP][j]) : "v"(ol), "s"(rin), "s"(so) : "memory");
+                    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=a"(ZU[WP][j]) : "v"(ou), "s"(rin), "s"(so) : "memory");
+                }
+            }
+            lcolS[WP] += 8;
+            loffS[WP] += 32 * dirw;
+            if (lcolS[WP] == W) { lcolS[WP] = 0; lrowS[WP] += P; loffS[WP] += rowstep - dirw * W * 4; }
+        }
+    };
 
     auto sec_event = [&](auto wp_c) {
         constexpr int WP = decltype(wp_c)::value;
         if constexpr (!SEC) return;
+        if constexpr (S64L) return;            // (s64_event is called in its place)
         float *dst = zring + lslotS[WP] * 64 + ldst[WP];
 #pragma unroll
         for (int j = 0; j < NKZ; ++j) {
@@ -380,7 +520,7 @@ __global__ __launch_bounds__(64 * NW * NPW) void finc_wave_kernel(const float *_
         const unsigned vb = ok ? (unsigned)loffS[WP] : OFF_INVALID;
 #pragma unroll
         for (int j = 0; j < NKZ; ++j)
-            Z[WP][j] = __builtin_amdgcn_raw_buffer_load_b128(rin, j == NKZ - 1 ? vb + zlast : vb, j * 16 * HW, 0);
+            Z[WP][j] = __builtin_amdgcn_raw_buffer_load_b128(rin, j == NKZ - 1 ? vb + zlast : vb, j * 16 * HW, FINC_LD_AUX);
         lcolS[WP] += 8;
         loffS[WP] += 32 * dirw;
         if (lcolS[WP] == W) { lcolS[WP] = 0; lrowS[WP] += P; loffS[WP] += rowstep - dirw * W * 4; }
@@ -404,6 +544,12 @@ __global__ __launch_bounds__(64 * NW * NPW) void finc_wave_kernel(const float *_
         }
         const bool ok = scolS[WP] >= 0 && srowS[WP] < H && p < P;
         st_off = ok ? (unsigned)soffS[WP] : OFF_INVALID;
+        if constexpr (S64S) {                  // lower piece: park it; upper piece: leaves with the parked lower one
+            const int phi = ((scolS[WP] + 64) >> 3) & 1;
+            spark = phi == 0;
+            st_off2 = (ok && phi == 1) ? (unsigned)(soffS[WP] - 32 * dirw) : OFF_INVALID;
+            if (phi == 0) st_off = OFF_INVALID;
+        }
         scolS[WP] += 8;
         soffS[WP] += 32 * dirw;
         if (scolS[WP] == W) { scolS[WP] = 0; srowS[WP] += P; soffS[WP] += rowstep - dirw * W * 4; }
@@ -430,7 +576,32 @@ __global__ __launch_bounds__(64 * NW * NPW) void finc_wave_kernel(const float *_
             v.y = __builtin_bit_cast(unsigned, XS[WP][j][1]);
             v.z = __builtin_bit_cast(unsigned, XS[WP][j][2]);
             v.w = __builtin_bit_cast(unsigned, XS[WP][j][3]);
-            __builtin_amdgcn_raw_buffer_store_b128(v, rout, vo, uni, 0);
+            if constexpr (S64S) {              // the parked lower piece first: two instructions, one whole sector
+                const unsigned vo2 = st_off2 == OFF_INVALID ? OFF_INVALID : vo - st_off + st_off2;
+                if constexpr (PK_AGPR) {
+                    asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen" ::"a"(PK[WP][j]), "v"(vo2), "s"(rout), "s"(uni) : "memory");
+                } else {
+                    const float e0 = PK[WP][j].x, e1 = PK[WP][j].y, e2 = PK[WP][j].z, e3 = PK[WP][j].w;
+                    v4u w;
+                    w.x = __builtin_bit_cast(unsigned, e0);
+                    w.y = __builtin_bit_cast(unsigned, e1);
+                    w.z = __builtin_bit_cast(unsigned, e2);
+                    w.w = __builtin_bit_cast(unsigned, e3);
+                    __builtin_amdgcn_raw_buffer_store_b128(w, rout, vo2, uni, FINC_ST_AUX);
+                }
+            }
+            __builtin_amdgcn_raw_buffer_store_b128(v, rout, vo, uni, FINC_ST_AUX);
+        }
+        if constexpr (S64S) {
+            if (spark) {                       // (divergent) park this window's lower piece where the upper one will find it
+                asm volatile("; park");
+#pragma unroll
+                for (int j = 0; j < NKD; ++j) {
+                    if (j < j0 || j >= j1) continue;
+                    PK[WP][j] = (v4f){XS[WP][j][0], XS[WP][j][1], XS[WP][j][2], XS[WP][j][3]};
+                    if constexpr (PK_AGPR) asm volatile("" : "+a"(PK[WP][j]));
+                }
+            }
         }
     };
 
@@ -453,7 +624,7 @@ __global__ __launch_bounds__(64 * NW * NPW) void finc_wave_kernel(const float *_
 #pragma unroll
         for (int j = 0; j < NKZ; ++j) {
             if (j < j0 || j >= j1) continue;
-            zb[j] = __builtin_amdgcn_raw_buffer_load_b128(rin, j == NKZ - 1 ? vb + zlast : vb, j * 16 * HW, 0);
+            zb[j] = __builtin_amdgcn_raw_buffer_load_b128(rin, j == NKZ - 1 ? vb + zlast : vb, j * 16 * HW, FINC_LD_AUX);
         }
         if (advance) {
             lcol += 4;
@@ -511,7 +682,7 @@ __global__ __launch_bounds__(64 * NW * NPW) void finc_wave_kernel(const float *_
             v.y = __builtin_bit_cast(unsigned, sv[j][1]);
             v.z = __builtin_bit_cast(unsigned, sv[j][2]);
             v.w = __builtin_bit_cast(unsigned, sv[j][3]);
-            __builtin_amdgcn_raw_buffer_store_b128(v, rout, vo, uni, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(v, rout, vo, uni, FINC_ST_AUX);
         }
     };
     // the window's HBM work, spread over its 4 steps: step 0 reads the x ring; steps 1-3 store a third of the registers
@@ -526,7 +697,12 @@ __global__ __launch_bounds__(64 * NW * NPW) void finc_wave_kernel(const float *_
             if constexpr (PH == 1 && !(AB & 2)) sec_swrite(wp_c, 0, S1);
             if constexpr (PH == 2 && !(AB & 2)) sec_swrite(wp_c, S1, S2);
             if constexpr (PH == 3 && !(AB & 2)) sec_swrite(wp_c, S2, NKD);
-            if constexpr (PH == 3 && !(AB & 5)) sec_event(wp_c);
+            if constexpr (PH == 3 && !(AB & 5)) {
+                sec_event(wp_c);
+                // VMEM instructions younger than the lower-piece loads of two windows ago: that event's last upper load
+                // (1) + a whole window (2*NKD stores, 2*NKZ loads) + this window's 2*NKD stores
+                s64_event(wp_c, IC<1 + (S64 & 1 ? 2 : 1) * NKD + 2 * NKZ + (S64 & 1 ? 2 : 1) * NKD>{});
+            }
         } else {
             if constexpr (PH == 0 && !(AB & 8)) io_sread();
             if constexpr (PH == 1 && !(AB & 2)) io_swrite(0, S1);
@@ -656,6 +832,9 @@ __global__ __launch_bounds__(64 * NW * NPW) void finc_wave_kernel(const float *_
         sec_event(IC<0>{});  // window -4: the first pieces of the class-0 rows leave
         sec_event(IC<1>{});  // window -3: class 1
         sec_event(IC<0>{});  // window -2: the first pieces land, the second ones leave
+        s64_event(IC<0>{}, IC<0>{});  // (S64: the same three events; before the loop they simply wait for everything)
+        s64_event(IC<1>{}, IC<0>{});
+        s64_event(IC<0>{}, IC<0>{});
     } else {
         io_issue(0, NKZ, true);
         io_land();
@@ -685,11 +864,9 @@ __global__ __launch_bounds__(64 * NW * NPW) void finc_wave_kernel(const float *_
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     if constexpr (KW > 1)
-                        finc_mma<C::MTB>(acc[mt], mt, af[FT + ((0 * KW + 1 - 1) * NK + j) * MT + mt],
-                                    ROT ? Q[0][(PHA + 3) & 3][j] : R[0][1][j]);
+                        mma(acc[mt], FT + ((0 * KW + 1 - 1) * NK + j) * MT + mt, ROT ? Q[0][(PHA + 3) & 3][j] : R[0][1][j]);
                     if constexpr (KH > 1)
-                        finc_mma<C::MTB>(acc[mt], mt, af[FT + ((1 * KW + 0 - 1) * NK + j) * MT + mt],
-                                    ROT ? Q[1][(PHA + 3) & 3][j] : R[1][0][j]);
+                        mma(acc[mt], FT + ((1 * KW + 0 - 1) * NK + j) * MT + mt, ROT ? Q[1][(PHA + 3) & 3][j] : R[1][0][j]);
                 }
         };
 
@@ -788,13 +965,13 @@ __global__ __launch_bounds__(64 * NW * NPW) void finc_wave_kernel(const float *_
                 for (int mt = 0; mt < MT; ++mt) {
                     const float b0 = bias[mt].x, b1 = bias[mt].y, b2 = bias[mt].z, b3 = bias[mt].w;
                     accn[mt] = (v4f){started ? b0 : 0.f, started ? b1 : 0.f, started ? b2 : 0.f, started ? b3 : 0.f};
-                    finc_mma<C::MTB>(accn[mt], mt, af[FZ + mt], zv[0]);
+                    mma(accn[mt], FZ + mt, zv[0]);
                 }
             } else {
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     accn[mt] = bias[mt];
-                    finc_mma<C::MTB>(accn[mt], mt, af[FZ + mt], zv[0]);
+                    mma(accn[mt], FZ + mt, zv[0]);
                 }
             }
 #pragma unroll
@@ -802,8 +979,17 @@ __global__ __launch_bounds__(64 * NW * NPW) void finc_wave_kernel(const float *_
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     if (NW == 1 && finc_zterm_is_zero(C::MTB, j, mt)) continue;   // Linv is lower triangular
-                    finc_mma<C::MTB>(accn[mt], mt, af[FZ + j * MT + mt], zv[j]);
+                    mma(accn[mt], FZ + j * MT + mt, zv[j]);
                 }
+#ifdef FINC_ZREP   // timing-only: the MFMA cost of a z-term FINC_ZREP times as wide (a folded C x C 1x1 conv
+                   // makes it G times as wide and dense); results are wrong, never shipped
+#pragma unroll
+            for (int rep = 1; rep < FINC_ZREP; ++rep)
+#pragma unroll
+                for (int j = 0; j < NKZ; ++j)
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt) mma(accn[mt], FZ + NKZ * MT + j * MT + mt, zv[j]);
+#endif
             FINC_STAMP_AT(1);                           // segment 1: z-term
             if constexpr (NW > 1) {
                 // K-split exchange: acc holds this wave's share of ALL output registers.  Ship the registers other waves
@@ -875,8 +1061,7 @@ __global__ __launch_bounds__(64 * NW * NPW) void finc_wave_kernel(const float *_
                 for (int j = 0; j < NK; ++j)
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
-                        finc_mma<C::MTB>(accn[mt], mt, af[FT + ((a * KW + b - 1) * NK + j) * MT + mt],
-                                    ROT ? Q[a][(PH + 9 - a - b) & 3][j] : R[a][b][j]);
+                        mma(accn[mt], FT + ((a * KW + b - 1) * NK + j) * MT + mt, ROT ? Q[a][(PH + 9 - a - b) & 3][j] : R[a][b][j]);
                 if constexpr (CI == 0) post1();
                 if constexpr (CI == (NCH > 1 ? 1 : 0)) io_phase(ph_c, wp_c);
                 if constexpr (CI == (NCH > 2 ? 2 : NCH - 1)) post2();
@@ -911,6 +1096,7 @@ __global__ __launch_bounds__(64 * NW * NPW) void finc_wave_kernel(const float *_
             sec_sread(IC<1>{});
             sec_swrite(IC<1>{}, 0, NKD);
             sec_event(IC<1>{});
+            s64_event(IC<1>{}, IC<0>{});
         } else {
             io_sread();
             io_swrite(0, NKD);
@@ -938,7 +1124,7 @@ __global__ __launch_bounds__(64 * NW * NPW) void finc_wave_kernel(const float *_
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     if (NW == 1 && finc_zterm_is_zero(C::MTB, j, mt)) continue;
-                    finc_mma<C::MTB>(acc[mt], mt, af[FZ + j * MT + mt], zvj);
+                    mma(acc[mt], FZ + j * MT + mt, zvj);
                 }
             }
             ++tp1; ++tm;
@@ -1057,6 +1243,7 @@ struct Inst {
     int cqp, kh, kw;
     wave_fn fn;      // 16-byte-group I/O (any W % 4 == 0)
     wave_fn fn_sec;  // 32-byte-piece I/O (W % 8 == 0)
+    wave_fn fn_s64;  // 64-byte sector pairing (W % 16 == 0); nullptr where the variant does not exist
     int nkz, nkd, nk, mt, nfrag, mtb;  // nkz/nkd/nfrag: per GROUP (packing); nk: per wave; mt = mtb tiles + 4-row blocks
     int nw, wnkz, wnkd;                // K-split: waves per problem, per-wave k-steps
     int npw;                           // problems packed into one workgroup (the launch needs B*G % npw == 0)
@@ -1068,12 +1255,32 @@ template <int CQP, int KH, int KW, int NW = 1, int NPW = 1, int MAXP = 0>
 constexpr Inst make_inst()
 {
     using C = Cfg<CQP, KH, KW, NW>;
-    return Inst{CQP, KH, KW, finc_wave_kernel<CQP, KH, KW, false, NW, NPW>, finc_wave_kernel<CQP, KH, KW, true, NW, NPW>,
+    // sector pairing parks 8 registers per k-step of z and of x in AGPRs, next to the pinned fragments
+    constexpr int zskip = [] {               // (16-row-tile fragments of the triangular z-term that are never loaded)
+        int n = 0;
+        for (int j = 0; j < C::NKZ; ++j)
+            for (int mt = 0; mt < C::MTB; ++mt) n += finc_zterm_is_zero(C::MTB, j, mt) ? 1 : 0;
+        return n;
+    }();
+    // AGPR budget next to the pinned fragments: loads paired park 16 registers per k-step of z
+    constexpr bool one = NW == 1 && NPW == 1;
+    constexpr int pinned = (C::NFRAG / C::MT) * C::MTB - zskip + ((C::NFRAG / C::MT) * C::NSM + 3) / 4;
+#ifndef FINC_S64_MODE
+#define FINC_S64_MODE 1
+#endif
+    constexpr int mode = !one ? 0 : (FINC_S64_MODE == 3 && pinned + 8 * C::NKZ + 8 * C::NKD <= 256) ? 3
+                                  : (FINC_S64_MODE >= 1 && pinned + 8 * C::NKD <= 256) ? 1 : 0;
+    wave_fn f64 = nullptr;
+    if constexpr (mode != 0) f64 = finc_wave_kernel<CQP, KH, KW, true, NW, NPW, mode>;
+    return Inst{CQP, KH, KW, finc_wave_kernel<CQP, KH, KW, false, NW, NPW>, finc_wave_kernel<CQP, KH, KW, true, NW, NPW>, f64,
                 C::NKZT, C::NKDT, C::NK, C::MT, C::NFRAGT, C::MTB, NW, C::NKZ, C::NKD, NPW, MAXP};
 }
 
 #define FINC_BOTH(cqp, kh, kw) make_inst<cqp, kh, kw>()
 
+#ifdef FINC_ONLY_C3   // experiment builds (scripts/build_variant.sh): only the c3 kernels, compiles in seconds
+const Inst g_insts[] = {make_inst<24, 3, 3, 2, 2, 512>(), FINC_BOTH(24, 3, 3)};
+#else
 const Inst g_insts[] = {
     // 3x3: every Cq % 4 == 0 up to 32, then K-split (2 / 4 waves per problem) for the banks one wave cannot hold.
     // Variants of one shape are tried in table order.  <24,3,3> first lists its small-batch variant: while the problems
@@ -1092,8 +1299,16 @@ const Inst g_insts[] = {
     make_inst<32, 5, 5, 4>(), make_inst<48, 5, 5, 4>(),
     FINC_BOTH(4, 3, 5),
 };
+#endif
 
 size_t lds_bytes(const Inst &i, int W, int P);
+
+// FINC_NO_S64=1 in the environment keeps W % 16 == 0 shapes on the 32-byte-piece kernel (A/B timing, tests of that path)
+bool finc_no_s64()
+{
+    static const bool off = [] { const char *e = getenv("FINC_NO_S64"); return e && e[0] == '1'; }();
+    return off;
+}
 
 // first variant of the shape (any: they share the packed layout); with a problem count and a width, the first variant
 // that may run them
@@ -1169,7 +1384,7 @@ int finc_mfma_variant(int B, int G, int Cq, int H, int W, int KH, int KW, int *i
     info[0] = i->cqp;
     info[1] = i->nw;
     info[2] = i->npw;
-    info[3] = W % 8 == 0 ? 1 : 0;
+    info[3] = (W % 16 == 0 && i->fn_s64 && !finc_no_s64()) ? 2 : W % 8 == 0 ? 1 : 0;
     info[4] = (int)lds_bytes(*i, W, P);
     info[5] = B * G / i->npw;
     info[6] = (int)(i - g_insts);
@@ -1196,7 +1411,7 @@ int finc_mfma_launch(const float *in, const void *packed, float *out, const Finc
     const int NB = (s.H + P - 1) / P;
     const int Tend = s.W % 8 == 0 ? (NB * s.W + P - 1 + 7) / 8 * 8 : (NB * s.W + P - 1 + 3) / 4 * 4;  // 32-byte I/O: x8 loop
     const size_t lds = lds_bytes(*i, s.W, P);
-    const wave_fn fn = (s.W % 8 == 0) ? i->fn_sec : i->fn;
+    const wave_fn fn = (s.W % 16 == 0 && i->fn_s64 && !finc_no_s64()) ? i->fn_s64 : (s.W % 8 == 0) ? i->fn_sec : i->fn;
     if (int e = finc_ensure_dynamic_lds((const void *)fn, lds)) return e;
     hipLaunchKernelGGL(fn, dim3(s.B * s.G / i->npw), dim3(64 * i->nw * i->npw), lds, st, in, (const float *)packed, out, s.G, s.Cq, s.H, s.W, P,
                        Tend, s.orient);

@@ -177,8 +177,8 @@ int finc_forward_f64(const double *x, const double *w_canon, double *z, int B, i
 /*
  * Introspection (tests, diagnostics; no reference counterpart).
  * finc_inverse_kernel_variant: which MFMA inverse kernel FINC_ALGO_AUTO / finc_inverse_packed_f32 launches for this
- *   problem.  info[8] = {Cq padded to 4, waves per problem (K-split), problems per workgroup, 1 = 32-byte I/O /
- *   0 = 16-byte I/O, LDS bytes per workgroup, workgroups, row of the instantiation table, rows in the table}.
+ *   problem.  info[8] = {Cq padded to 4, waves per problem (K-split), problems per workgroup, 2 = 64-byte sector
+ *   pairing / 1 = 32-byte pieces / 0 = 16-byte groups, LDS bytes per workgroup, workgroups, row of the instantiation table, rows in the table}.
  *   FINC_ERR_UNSUPPORTED when the shape runs on the strict kernel.
  * finc_debug_attr_table_insert: the (device, kernel) table behind the once-per-device kernel attributes; returns 1 if
  *   the pair was new.  Host-only; exists so the key logic is testable without two GPUs.

@@ -90,12 +90,13 @@ def test_variant_plan_covers_every_row_and_agrees_with_the_library():
         assert counts, (r, i)
         for n in counts:
             B, G, _ = split_problems(n)
-            for sec, (H, W) in ((1, (19, 24)), (0, (9, 20))):
+            one_wave = i["nw"] == 1 and i["npw"] == 1
+            for sec, (H, W) in ((2 if one_wave else 1, (10, 32)), (1, (19, 24)), (0, (9, 20))):
                 v = _lib.inverse_variant(B, G, i["cqp"], H, W, i["kh"], i["kw"])
                 assert v is not None and v["row"] == r and v["sec"] == sec and v["nw"] == i["nw"] and v["npw"] == i["npw"], (r, n, v)
                 assert v["workgroups"] * v["npw"] == B * G and v["lds_bytes"] <= 160 * 1024
                 hit.add((r, sec))
-    assert len(hit) == 2 * len(rows)
+    assert len(hit) == 2 * len(rows) + sum(1 for i in rows if i["nw"] == 1 and i["npw"] == 1)
     # the bench shapes: c3 at full batch is the one-wave kernel, at B <= 128 the packed 2-wave split; c5 is the 4-wave split
     assert _lib.inverse_variant(256, 4, 24, 64, 64, 3, 3)["nw"] == 1
     assert (_lib.inverse_variant(128, 4, 24, 64, 64, 3, 3)["nw"], _lib.inverse_variant(128, 4, 24, 64, 64, 3, 3)["npw"]) == (2, 2)

@@ -70,8 +70,8 @@ def run_inverse_case(dev, B, G, orient, Cq, H, W, KH, KW, seed, tag, expect_row=
 
 @pytest.mark.parametrize("row", range(28))
 def test_every_row_of_the_instantiation_table(row, dev):
-    """Walks g_insts (finc_mfma.hip): each row is launched in its 32-byte-I/O form (W % 8 == 0) and its 16-byte form
-    (W % 8 == 4), at problem counts on each side of max_problems and at odd and even counts (problems per workgroup),
+    """Walks g_insts (finc_mfma.hip): each row is launched in its 64-byte sector-pairing form (W % 16 == 0, one-wave rows),
+    its 32-byte-I/O form (W % 8 == 0) and its 16-byte form (W % 8 == 4), at problem counts on each side of max_problems and at odd and even counts (problems per workgroup),
     with the full channel count and with padded channels; the test asserts WHICH variant the library picked."""
     rows = _rows()
     if row >= len(rows):
@@ -80,10 +80,15 @@ def test_every_row_of_the_instantiation_table(row, dev):
     i = rows[row]
     counts = problem_counts_for_row(rows, row)
     assert counts, f"no problem count selects row {row}: {i}"
+    one_wave = i["nw"] == 1 and i["npw"] == 1
     for n in counts:
         B, G, orient = split_problems(n)
         big = n > 64
-        for sec, (H, W) in ((1, (7, 16) if big else (19, 24)), (0, (5, 12) if big else (9, 20))):
+        # I/O form by width: W % 16 == 0 -> 64-byte sector pairing (2) where the row has it (one wave per problem), else
+        # W % 8 == 0 -> 32-byte pieces (1), else 16-byte groups (0)
+        shapes = ((2 if one_wave else 1, (7, 16) if big else (10, 32)), (1, (5, 24) if big else (19, 24)),
+                  (0, (5, 12) if big else (9, 20)))
+        for sec, (H, W) in shapes:
             Cq = i["cqp"] if sec else max(i["cqp"] - 1, 1)          # the 16-byte form also carries padded channels
             run_inverse_case(dev, B, G, orient, Cq, H, W, i["kh"], i["kw"], seed=1000 * row + n + sec,
                              tag="variant_table", expect_row=row, expect_sec=sec)

@@ -9,7 +9,8 @@ import wave_model
 
 CASES = [(4, 8, 8, 3, 3), (3, 16, 16, 3, 3), (6, 8, 8, 3, 3), (12, 20, 20, 3, 3), (24, 19, 32, 3, 3),
          (16, 12, 12, 2, 2), (4, 10, 12, 5, 5), (2, 10, 16, 3, 5), (5, 7, 4, 3, 3), (8, 40, 8, 3, 3),
-         (1, 8, 8, 3, 3), (3, 4, 4, 3, 3), (8, 20, 48, 3, 3), (4, 33, 16, 2, 2), (8, 9, 64, 3, 3)]
+         (1, 8, 8, 3, 3), (3, 4, 4, 3, 3), (8, 20, 48, 3, 3), (4, 33, 16, 2, 2), (8, 9, 64, 3, 3),
+         (4, 18, 24, 3, 3), (8, 35, 40, 3, 3), (4, 17, 56, 2, 2), (12, 40, 32, 3, 3)]   # W % 16 == 8: a row's odd last piece
 
 
 @pytest.mark.parametrize("CQ,H,W,KH,KW", CASES)

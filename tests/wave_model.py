@@ -232,8 +232,17 @@ def run(inp, wc, fwd=False, scale=None, shift=None):
     scolS = np.stack([4 * (f0[wp] - 2 + fl4r[wp]) for wp in (0, 1)])
     srowS = svrow.copy()
     XS = np.full((2, NKD, 4, LANES), np.nan)
-    st2 = dict(ok=np.zeros(LANES, bool), row=np.zeros(LANES, int), col=np.zeros(LANES, int), par=0)
+    st2 = dict(ok=np.zeros(LANES, bool), ok2=np.zeros(LANES, bool), park=np.zeros(LANES, bool), row=np.zeros(LANES, int),
+               col=np.zeros(LANES, int), par=0)
     win = [-4]                                       # window counter of the event stream (the pre-loop runs -4, -3, -2)
+
+    # Sector pairing (W % 8 == 0): HBM is touched in whole 64-byte sectors.  Loads: a lane asks for the lower AND the upper
+    # 32-byte piece of a sector in the same event (two instructions back to back: the second is an L2 hit on the line the
+    # first one fetches); the lower piece lands one event later as before, the upper one waits in a second register set
+    # (ZU, accumulation registers) and lands two events later -- exactly when the old schedule landed it.  Nothing is
+    # requested at the event of an upper piece.  `lphi` = phase of the previous event's piece = which set lands now.
+    ZU = np.zeros((2, NKZ, 4, LANES))
+    lphi = np.zeros((2, LANES), int)
 
     def io_event():
         u = win[0]
@@ -245,16 +254,22 @@ def run(inp, wc, fwd=False, scale=None, shift=None):
             h = half[wp, lane]
             sl = (lslotS[wp, lane] + 4 * h) % 12
             dst = q[lane] * 16 + R_
+            src = Z if lphi[wp, lane] == 0 else ZU       # previous event issued a lower piece -> it lands now
             for j in range(NKZ):
                 for k in range(4):
-                    zring[j, sl + k, dst] = Z[wp, j, k, lane]
+                    zring[j, sl + k, dst] = src[wp, j, k, lane]
             lslotS[wp, lane] = (lslotS[wp, lane] + 8) % 12
             c0 = lcolS[wp, lane]
-            ok = c0 >= 0 and lrowS[wp, lane] < H
-            for j in range(NKZ):
-                ch = 4 * j + q[lane]
-                for k in range(4):
-                    Z[wp, j, k, lane] = inp[ch, lrowS[wp, lane], c0 + 4 * h + k] if (ok and ch < CQ) else 0.0
+            phi = ((c0 + 64) >> 3) & 1
+            lphi[wp, lane] = phi
+            if phi == 0:
+                ok = c0 >= 0 and lrowS[wp, lane] < H
+                oku = ok and c0 + 8 < W
+                for j in range(NKZ):
+                    ch = 4 * j + q[lane]
+                    for k in range(4):
+                        Z[wp, j, k, lane] = inp[ch, lrowS[wp, lane], c0 + 4 * h + k] if (ok and ch < CQ) else 0.0
+                        ZU[wp, j, k, lane] = inp[ch, lrowS[wp, lane], c0 + 8 + 4 * h + k] if (oku and ch < CQ) else 0.0
             lcolS[wp, lane] += 8
             if lcolS[wp, lane] == W:
                 lcolS[wp, lane] = 0
@@ -270,7 +285,7 @@ def run(inp, wc, fwd=False, scale=None, shift=None):
         c_ = u & 1                                   # the class that fires in this window
         for lane in range(LANES):
             if p[lane] >= P:
-                st2["ok"][lane] = False
+                st2["ok"][lane] = st2["ok2"][lane] = st2["park"][lane] = False
                 continue
             T = svrow[c_, lane]
             h = half[c_, lane]
@@ -281,9 +296,18 @@ def run(inp, wc, fwd=False, scale=None, shift=None):
                     for k in range(4):
                         XS[(u + 1) & 1, j, k, lane] = xring[j, (oc + k) & 7, q[lane] * 16 + p[lane]]
                         XS[u & 1, j, k, lane] = xring[j, (scolS[c_, lane] + 4 + k) & 7, q[lane] * 16 + T]
-            st2["ok"][lane] = scolS[c_, lane] >= 0 and srowS[c_, lane] < H
+            # sector pairing: a lower piece (phase 0) is parked, the upper piece (phase 1) is stored together with it --
+            # two store instructions back to back write one whole 64-byte sector; the odd last piece of a row
+            # (W % 16 == 8) has no upper half and leaves at once
+            sc0 = scolS[c_, lane]
+            ok = sc0 >= 0 and srowS[c_, lane] < H
+            phi = ((sc0 + 64) >> 3) & 1
+            last = sc0 + 8 >= W
+            st2["ok"][lane] = ok and (phi == 1 or last)
+            st2["ok2"][lane] = ok and phi == 1 and sc0 - 8 >= 0
+            st2["park"][lane] = phi == 0 and not last
             st2["row"][lane] = srowS[c_, lane]
-            st2["col"][lane] = scolS[c_, lane] + 4 * h
+            st2["col"][lane] = sc0 + 4 * h
             scolS[c_, lane] += 8
             if scolS[c_, lane] == W:
                 scolS[c_, lane] = 0
@@ -291,16 +315,23 @@ def run(inp, wc, fwd=False, scale=None, shift=None):
         st2["par"] = u & 1
         swin[0] += 1
 
+    PK = np.full((2, NKD, 4, LANES), np.nan)
+
     def io_swrite():
         if not SEC:
             return io_swrite16()
+        par = st2["par"]
         for lane in range(LANES):
-            if st2["ok"][lane]:
-                for j in range(NKD):
-                    ch = chan_d(MTB, j, q[lane])
-                    if ch < CQ:
-                        for k in range(4):
-                            out[ch, st2["row"][lane], st2["col"][lane] + k] = XS[st2["par"], j, k, lane]
+            for j in range(NKD):
+                ch = chan_d(MTB, j, q[lane])
+                if ch < CQ:
+                    for k in range(4):
+                        if st2["ok2"][lane]:
+                            out[ch, st2["row"][lane], st2["col"][lane] - 8 + k] = PK[par, j, k, lane]
+                        if st2["ok"][lane]:
+                            out[ch, st2["row"][lane], st2["col"][lane] + k] = XS[par, j, k, lane]
+            if st2["park"][lane]:
+                PK[par, :, :, lane] = XS[par, :, :, lane]
 
     sph = fl4 & 1
 
