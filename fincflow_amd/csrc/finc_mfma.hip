@@ -470,10 +470,14 @@ __global__ __launch_bounds__(64 * NW * NPW) void finc_wave_kernel(const float *_
                     d3[j * C::ZSLOTS * 64] = __builtin_bit_cast(float, a3);
                 }
             } else {
-                asm volatile("; land upper");  // (the compiler reads the AGPR tuple element by element: 4 v_accvgpr_read per piece)
+                // the upper piece comes out of its AGPR tuple as a whole (4 v_accvgpr_read) -- the asm also keeps the two
+                // sides of the branch different, or the compiler merges them over a pointer select and both register
+                // sets end up in scratch memory
 #pragma unroll
                 for (int j = 0; j < NKZ; ++j) {
-                    const unsigned a0 = ZU[WP][j].x, a1 = ZU[WP][j].y, a2 = ZU[WP][j].z, a3 = ZU[WP][j].w;
+                    v4u t = ZU[WP][j];
+                    asm volatile("; upper piece" : "+v"(t));
+                    const unsigned a0 = t.x, a1 = t.y, a2 = t.z, a3 = t.w;
                     d0[j * C::ZSLOTS * 64] = __builtin_bit_cast(float, a0);
                     d1[j * C::ZSLOTS * 64] = __builtin_bit_cast(float, a1);
                     d2[j * C::ZSLOTS * 64] = __builtin_bit_cast(float, a2);
@@ -1266,7 +1270,7 @@ constexpr Inst make_inst()
     constexpr bool one = NW == 1 && NPW == 1;
     constexpr int pinned = (C::NFRAG / C::MT) * C::MTB - zskip + ((C::NFRAG / C::MT) * C::NSM + 3) / 4;
 #ifndef FINC_S64_MODE
-#define FINC_S64_MODE 1
+#define FINC_S64_MODE 3
 #endif
     constexpr int mode = !one ? 0 : (FINC_S64_MODE == 3 && pinned + 8 * C::NKZ + 8 * C::NKD <= 256) ? 3
                                   : (FINC_S64_MODE >= 1 && pinned + 8 * C::NKD <= 256) ? 1 : 0;
