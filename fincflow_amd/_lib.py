@@ -21,6 +21,7 @@ SYMBOLS = [
     "finc_inverse_workspace_bytes", "finc_pack_inverse_weights_affine_f32",
     "finc_canonicalize_weights_f64", "finc_inverse_f64", "finc_forward_f64",
     "finc_inverse_kernel_variant", "finc_debug_attr_table_insert", "finc_debug_inverse_table_row",
+    "finc_mix_supported_f32", "finc_mix_f32",
 ]
 
 _lib = None
@@ -71,6 +72,8 @@ def lib():
     L.finc_inverse_kernel_variant.argtypes = [i, i, i, i, i, i, i, ctypes.POINTER(ctypes.c_int)]
     L.finc_debug_attr_table_insert.argtypes = [i, sz]
     L.finc_debug_inverse_table_row.argtypes = [i, ctypes.POINTER(ctypes.c_int)]
+    L.finc_mix_supported_f32.argtypes = [i]
+    L.finc_mix_f32.argtypes = [vp, vp, vp, vp, i, i, i, vp]
     for name in SYMBOLS:
         getattr(L, name)  # AttributeError here = header and library out of sync
     _lib = L

@@ -355,6 +355,17 @@ int finc_inverse_kernel_variant(int B, int G, int Cq, int H, int W, int KH, int 
     return finc_mfma_variant(B, G, Cq, H, W, KH, KW, info);
 }
 
+int finc_mix_supported_f32(int C) { return (C > 0 && finc_mix_supported(C)) ? 1 : 0; }
+
+int finc_mix_f32(const float *in, const float *mat, const float *bias, float *out, int B, int C, int HW, finc_stream_t stream)
+{
+    if (!in || !mat || !out) return FINC_ERR_NULL_POINTER;
+    if (B <= 0 || C <= 0 || HW <= 0 || C > FINC_MAX_CQ * FINC_MAX_GROUPS) return FINC_ERR_BAD_DIMS;
+    if (misaligned(in) || misaligned(mat) || misaligned(out) || (bias && misaligned(bias))) return FINC_ERR_ALIGNMENT;
+    if ((size_t)B * C * HW >= ((size_t)1 << 40)) return FINC_ERR_BAD_DIMS;
+    return finc_mix_launch(in, mat, bias, out, B, C, HW, (hipStream_t)stream);
+}
+
 int finc_debug_inverse_table_row(int row, int *info)
 {
     if (!info) return FINC_ERR_NULL_POINTER;

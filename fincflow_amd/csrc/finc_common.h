@@ -72,3 +72,7 @@ int finc_conv_pack(const float *wc, void *packed, int G, int Cq, int KH, int KW,
 int finc_conv_launch(const float *in, const void *packed, float *out, const FincShape &s, hipStream_t st);
 size_t finc_gradw_workspace_bytes(const FincShape &s); // 0: no MFMA grad-weight kernel for this shape
 int finc_gradw_launch(const float *gz, const float *x, float *gw, void *workspace, const FincShape &s, hipStream_t st);
+
+// ---- per-pixel channel mixing (1x1 conv + folded affine): finc_mix.hip ----
+bool finc_mix_supported(int C);
+int finc_mix_launch(const float *in, const float *mat, const float *bias, float *out, int B, int C, int HW, hipStream_t st);

@@ -304,7 +304,8 @@ __global__ __launch_bounds__(64 * NW * NPW) void finc_wave_kernel(const float *_
 #pragma unroll
             for (int a = 3; a >= 0; --a) {
                 const int sfr = 4 * r + a < NSMALL ? 4 * r + a : NSMALL - 1;
-                const int f = (sfr / C::NSM) * MT + C::MTB + sfr % C::NSM;
+                constexpr int NSMD = C::NSM > 0 ? C::NSM : 1;      // (NSR == 0 when there are no 4-row blocks: loop is empty)
+                const int f = (sfr / NSMD) * MT + C::MTB + sfr % NSMD;
                 const int ga = gindex(f);
                 gi = (a == 3 || quad == a) ? ga : gi;
             }

@@ -76,28 +76,64 @@ class ActNorm(FlowLayer):
 
 
 class Conv1x1(FlowLayer):
+    """layers/conv1x1.py:8-49.  Inference / sampling (no autograd graph, device tensors, a channel count the library
+    instantiates) runs on the HIP mixing kernel (`ops.finc_mix`, one streaming launch); training keeps F.conv2d."""
+
     def __init__(self, n_channels):
         super().__init__()
         self.n_channels = n_channels
         q = np.linalg.qr(np.random.randn(n_channels, n_channels))[0]
         self.W = nn.Parameter(torch.from_numpy(q.astype('float32')))
 
+    def _hip(self, x):
+        from . import ops
+        return (not (torch.is_grad_enabled() and (self.W.requires_grad or x.requires_grad)) and x.is_cuda
+                and x.dtype == torch.float32 and x.dim() == 4 and ops.mix_supported(self.n_channels))
+
     def forward(self, x, context=None):
         h, w = x.shape[2:]
         ldj = h * w * torch.slogdet(self.W)[1]
+        if self._hip(x):
+            from . import ops
+            return ops.finc_mix(x.contiguous(), self.W.detach().contiguous()), ldj
         return F.conv2d(x, self.W.view(self.n_channels, self.n_channels, 1, 1)), ldj
 
-    def reverse(self, z, context=None):
+    def _inverse_matrix(self):
         # the reference inverts W on every call (layers/conv1x1.py:37-39); cache it per weight version so that a
         # sampling pass has no LU factorisation (and no host sync) in it and can be captured in a HIP graph
         key = (self.W.data_ptr(), self.W._version, self.W.device)
         if getattr(self, "_inv_key", None) != key:
             with torch.no_grad():
-                self._w_inv = torch.inverse(self.W.detach()).view(self.n_channels, self.n_channels, 1, 1).contiguous()
+                self._w_inv = torch.inverse(self.W.detach()).contiguous()
             self._inv_key = key
-        w_inv = self._w_inv if not (torch.is_grad_enabled() and self.W.requires_grad) else \
-            torch.inverse(self.W).view(self.n_channels, self.n_channels, 1, 1)
-        return F.conv2d(z, w_inv)
+            self._aff_key = None
+        return self._w_inv
+
+    def reverse(self, z, context=None):
+        if self._hip(z):
+            from . import ops
+            return ops.finc_mix(z.contiguous(), self._inverse_matrix())
+        if torch.is_grad_enabled() and self.W.requires_grad:
+            w_inv = torch.inverse(self.W)
+        else:
+            w_inv = self._inverse_matrix()
+        return F.conv2d(z, w_inv.view(self.n_channels, self.n_channels, 1, 1))
+
+    def reverse_then_affine(self, z, log_scale, translation):
+        """exp(log_scale) * reverse(z) + translation in ONE launch: the ActNorm that precedes this layer in
+        the model follows it in the reverse chain (layers/actnorm.py:47-52), and a per-channel affine map after a channel
+        mix is a row scaling of the matrix plus a bias.  None when this call cannot take the HIP path."""
+        if not self._hip(z):
+            return None
+        from . import ops
+        w_inv = self._inverse_matrix()
+        key = (log_scale.data_ptr(), log_scale._version, translation.data_ptr(), translation._version)
+        if getattr(self, "_aff_key", None) != key:
+            with torch.no_grad():
+                self._m_aff = (torch.exp(log_scale.detach().float()).view(-1, 1) * w_inv).contiguous()
+                self._b_aff = translation.detach().float().contiguous()
+            self._aff_key = key
+        return ops.finc_mix(z.contiguous(), self._m_aff, self._b_aff)
 
     def logdet(self, input, context=None):
         raise NotImplementedError

@@ -297,6 +297,14 @@ class FlowSequential(nn.Module):
                     input = fused
                     i += 2
                     continue
+            # a channel mix followed by a per-channel affine layer that no FastFlowUnit takes: one mixing launch
+            if (fuse and i + 1 < len(mods) and hasattr(m, "reverse_then_affine") and hasattr(mods[i + 1], "reverse_affine_params")
+                    and not (i + 2 < len(mods) and isinstance(mods[i + 2], FastFlowUnit)) and not torch.is_grad_enabled()):
+                fused = m.reverse_then_affine(input, *mods[i + 1].reverse_affine_params())
+                if fused is not None:
+                    input = fused
+                    i += 2
+                    continue
             output = m.reverse(input, context)
             input = output[0] if isinstance(output, tuple) else output
             i += 1

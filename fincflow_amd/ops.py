@@ -158,6 +158,38 @@ def finc_backward(grad_z, x, w_canon, G, orient, need_gx=True, need_gw=True):
     return gx, gw
 
 
+def mix_supported(C):
+    return bool(_lib.lib().finc_mix_supported_f32(int(C)))
+
+
+def finc_mix(x, mat, bias=None, out=None):
+    """out[b, :, h, w] = mat @ x[b, :, h, w] + bias: the 1x1 convolution of a flow step (layers/conv1x1.py:29-43) with
+    whatever per-channel affine neighbour the caller folded into `mat` / `bias`, as one streaming HIP launch.
+    x [B,C,H,W] fp32 contiguous on the device, mat [C,C] (out, in), bias [C] or None.  `out` may be `x`."""
+    _require_device(x, "input")
+    _require_device(mat, "matrix")
+    if x.dim() != 4 or mat.shape != (x.shape[1], x.shape[1]) or mat.device != x.device:
+        raise ValueError("expected activations [B,C,H,W] and a [C,C] matrix on the same device")
+    if bias is not None:
+        _require_device(bias, "bias")
+        if bias.numel() != x.shape[1]:
+            raise ValueError("bias must have one entry per channel")
+    if out is None:
+        out = torch.empty_like(x)
+    else:
+        _require_device(out, "output")
+        if out.shape != x.shape or out.device != x.device:
+            raise ValueError("output must match input in shape and device")
+    if x.numel() == 0:
+        return out
+    B, C, H, W = x.shape
+    with torch.cuda.device(x.device):
+        st = _lib.lib().finc_mix_f32(x.data_ptr(), mat.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                     out.data_ptr(), B, C, H * W, _stream_ptr(x))
+    _lib.check(st, "finc_mix_f32")
+    return out
+
+
 def inverse(input, kernel, output):
     """Drop-in for the reference extension's `inverse` (cinc_cuda_level2.cpp:19-32).
 

@@ -175,6 +175,20 @@ int finc_forward_f64(const double *x, const double *w_canon, double *z, int B, i
                      int KW, unsigned orient, finc_stream_t stream);
 
 /*
+ * SURVEY 8 f3, second half -- the 1x1 convolution next to the unit (layers/conv1x1.py:29-43: forward
+ * F.conv2d(x, W), reverse F.conv2d(z, inverse(W)); one per flow step, fastflow_cifar_multi_gpu.py:224-256) as one
+ * streaming pass:      out[b, :, p] = mat * in[b, :, p] + bias      for every pixel p of every image,
+ * mat [C][C] row-major (out channel, in channel), bias [C] or NULL, activations fp32 NCHW with HW = H*W.
+ * The per-channel affine neighbour folds into the operands on the host: Conv1x1.reverse followed by ActNorm.reverse
+ * (layers/actnorm.py:47-52) is mat = diag(exp(log_scale)) * inverse(W), bias = translation.
+ * `in == out` is allowed.  FINC_ERR_UNSUPPORTED for channel counts without an instantiation
+ * (finc_mix_supported_f32(C) == 0): the caller keeps its own 1x1 convolution for those.
+ */
+int finc_mix_supported_f32(int C);
+int finc_mix_f32(const float *in, const float *mat, const float *bias, float *out, int B, int C, int HW,
+                 finc_stream_t stream);
+
+/*
  * Introspection (tests, diagnostics; no reference counterpart).
  * finc_inverse_kernel_variant: which MFMA inverse kernel FINC_ALGO_AUTO / finc_inverse_packed_f32 launches for this
  *   problem.  info[8] = {Cq padded to 4, waves per problem (K-split), problems per workgroup, 2 = 64-byte sector

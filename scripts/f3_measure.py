@@ -37,12 +37,16 @@ for name, B, C, H, W in (("c3", 256, 96, 64, 64), ("c2", 64, 48, 32, 32), ("c4_L
     y = torch.randn(B, C, H, W, device=dev)
     with torch.no_grad():
         c11.reverse(y); unit.reverse(y); an.reverse(y)
-        t11 = timeit(lambda: c11.reverse(y))
+        t11 = timeit(lambda: c11.reverse(y))                       # the HIP mixing kernel (ops.finc_mix)
+        w4 = c11._inverse_matrix().view(C, C, 1, 1)
+        tmi = timeit(lambda: torch.nn.functional.conv2d(y, w4))   # what it replaces: F.conv2d through MIOpen
+        tfa = timeit(lambda: c11.reverse_then_affine(y, an.log_scale, an.translation))
         tan = timeit(lambda: an.reverse(y))
         tun = timeit(lambda: unit.reverse(y))
         tfu = timeit(lambda: unit.reverse_affine(y, an.log_scale, an.translation))
     E = B * C * H * W
-    out[name] = {"shape": [B, C, H, W], "conv1x1_reverse_us": t11, "actnorm_reverse_us": tan, "unit_reverse_us": tun,
+    out[name] = {"shape": [B, C, H, W], "conv1x1_reverse_us": t11, "conv1x1_reverse_miopen_us": tmi,
+                 "conv1x1_reverse_then_actnorm_one_launch_us": tfa, "actnorm_reverse_us": tan, "unit_reverse_us": tun,
                  "unit_reverse_with_actnorm_folded_us": tfu, "conv1x1_GBps": 8 * E / t11 / 1e3,
                  "bytes_moved_by_conv1x1": 8 * E}
 print(json.dumps(out, indent=1))

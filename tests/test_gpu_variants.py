@@ -258,3 +258,61 @@ def test_unaligned_view_through_fastflowunit_reverse(dev):
         assert unit.reverse_affine(zv, an.log_scale, an.translation) is None     # caller runs the two layers separately
         y, _ = unit.conv_tl.reverse(zv[:, :4].contiguous())
         assert y.shape == (B, 4, H, W)
+
+
+# ------------------------------------------------------------------ the 1x1 conv next to the unit
+@pytest.mark.parametrize("shape", [(3, 96, 20, 24), (2, 12, 16, 16), (5, 24, 8, 8), (4, 48, 4, 4), (2, 192, 9, 8), (1, 4, 7, 7),
+                                   (2, 16, 5, 3), (3, 64, 6, 10), (1, 128, 3, 5), (2, 8, 1, 1)])
+def test_mix_kernel_is_the_1x1_conv(shape, dev):
+    """finc_mix_f32 against F.conv2d on the CPU in fp64 (layers/conv1x1.py:29-43), with and without bias, in place and
+    out of place, even and odd pixel counts (two pixels per lane / one)."""
+    import torch.nn.functional as F
+    from fincflow_amd import ops
+    B, C, H, W = shape
+    assert ops.mix_supported(C)
+    torch.manual_seed(sum(shape))
+    x = torch.randn(B, C, H, W)
+    M = torch.randn(C, C) / C ** 0.5
+    b = torch.randn(C)
+    ref = F.conv2d(x.double(), M.double().view(C, C, 1, 1), b.double()).numpy()
+    ref0 = F.conv2d(x.double(), M.double().view(C, C, 1, 1)).numpy()
+    xd, Md, bd = x.to(dev), M.to(dev), b.to(dev)
+    out = ops.finc_mix(xd, Md, bd)
+    e = rel_err(out.cpu().numpy(), ref)
+    report("mix", shape=list(shape), err_max_norm=e, err_elementwise=elem_rel_err(out.cpu().numpy(), ref))
+    assert e <= TOL
+    assert rel_err(ops.finc_mix(xd, Md).cpu().numpy(), ref0) <= TOL
+    y = xd.clone()
+    assert ops.finc_mix(y, Md, bd, out=y).data_ptr() == y.data_ptr() and torch.equal(y, out)      # in place
+    assert not ops.mix_supported(20) and not ops.mix_supported(7)
+    from fincflow_amd import _lib
+    with pytest.raises(_lib.FincError):
+        ops.finc_mix(torch.randn(1, 20, 4, 4, device=dev), torch.eye(20, device=dev))
+
+
+def test_conv1x1_module_runs_on_the_mix_kernel(dev):
+    """glow.Conv1x1 (layers/conv1x1.py:8-49): under no_grad both directions are one finc_mix_f32 launch; reverse(forward(x))
+    == x; the autograd path (training) still matches; and [Conv1x1, ActNorm] in a reverse chain is the affine-folded call."""
+    from fincflow_amd import glow
+    torch.manual_seed(3)
+    np.random.seed(3)
+    c = glow.Conv1x1(48).to(dev)
+    x = torch.randn(4, 48, 8, 8, device=dev)
+    with torch.no_grad():
+        z, ldj = c(x)
+        z_ref = torch.nn.functional.conv2d(x, c.W.view(48, 48, 1, 1))
+        assert rel_err(z.cpu().numpy(), z_ref.cpu().numpy()) <= TOL
+        assert abs(float(ldj) - 64 * float(torch.slogdet(c.W)[1])) < 1e-3
+        assert rel_err(c.reverse(z).cpu().numpy(), x.cpu().numpy()) <= TOL
+        an = glow.ActNorm(48).to(dev)
+        an.log_scale.copy_(0.2 * torch.randn(48, device=dev))
+        an.translation.copy_(torch.randn(48, device=dev))
+        an.initialized.fill_(1)
+        fused = c.reverse_then_affine(z, an.log_scale, an.translation)
+        assert rel_err(fused.cpu().numpy(), an.reverse(c.reverse(z)).cpu().numpy()) <= TOL
+        c.W.mul_(1.01)                                      # in-place update: the cached inverse must follow
+        assert rel_err(c.reverse(c(x)[0]).cpu().numpy(), x.cpu().numpy()) <= TOL
+    xg = x.clone().requires_grad_(True)
+    zg, _ = c(xg)
+    zg.sum().backward()
+    assert xg.grad is not None and c.W.grad is not None
