@@ -21,7 +21,7 @@ SYMBOLS = [
     "finc_inverse_workspace_bytes", "finc_pack_inverse_weights_affine_f32",
     "finc_canonicalize_weights_f64", "finc_inverse_f64", "finc_forward_f64",
     "finc_inverse_kernel_variant", "finc_debug_attr_table_insert", "finc_debug_inverse_table_row",
-    "finc_mix_supported_f32", "finc_mix_f32",
+    "finc_mix_supported_f32", "finc_mix_f32", "finc_pack_forward_weights_affine_f32",
 ]
 
 _lib = None
@@ -57,6 +57,7 @@ def lib():
     L.finc_pack_inverse_weights_f32.argtypes = [vp, vp, i, i, i, i, vp]
     L.finc_pack_inverse_weights_affine_f32.argtypes = [vp, vp, vp, vp, i, i, i, i, vp]
     L.finc_pack_forward_weights_f32.argtypes = [vp, vp, i, i, i, i, vp]
+    L.finc_pack_forward_weights_affine_f32.argtypes = [vp, vp, vp, vp, i, i, i, i, vp]
     runp = [vp, vp, vp, i, i, i, i, i, i, i, u, vp]
     L.finc_inverse_packed_f32.argtypes = runp
     L.finc_forward_packed_f32.argtypes = runp

@@ -296,6 +296,15 @@ int finc_pack_forward_weights_f32(const float *w_canon, void *packed, int G, int
     return pack(w_canon, packed, G, Cq, KH, KW, stream, true);
 }
 
+int finc_pack_forward_weights_affine_f32(const float *w_canon, const float *scale, const float *shift, void *packed,
+                                         int G, int Cq, int KH, int KW, finc_stream_t stream)
+{
+    if (!w_canon || !packed) return FINC_ERR_NULL_POINTER;
+    if (int e = check_shape(1, G, Cq, 1, 1, KH, KW)) return e;
+    if (finc_conv_packed_bytes(G, Cq, KH, KW) == 0) return FINC_ERR_UNSUPPORTED;
+    return finc_conv_pack(w_canon, packed, G, Cq, KH, KW, false, (hipStream_t)stream, scale, shift);
+}
+
 static int run_packed(const float *in, const void *packed, float *out, int B, int G, int Cq, int H, int W, int KH,
                       int KW, unsigned orient, finc_stream_t stream, bool forward)
 {

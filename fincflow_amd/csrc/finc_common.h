@@ -68,7 +68,9 @@ int finc_mfma_table_row(int row, int *info);
 // ---- forward / grad-input, MFMA strip kernel: finc_conv.hip ----
 bool finc_conv_supported(int Cq, int H, int W, int KH, int KW);
 size_t finc_conv_packed_bytes(int G, int Cq, int KH, int KW);
-int finc_conv_pack(const float *wc, void *packed, int G, int Cq, int KH, int KW, bool transpose, hipStream_t st);
+// scale / shift [G*Cq] or nullptr: z' = scale * conv(x) + shift folded into the bank (the affine layer BEHIND the conv)
+int finc_conv_pack(const float *wc, void *packed, int G, int Cq, int KH, int KW, bool transpose, hipStream_t st,
+                   const float *scale = nullptr, const float *shift = nullptr);
 int finc_conv_launch(const float *in, const void *packed, float *out, const FincShape &s, hipStream_t st);
 size_t finc_gradw_workspace_bytes(const FincShape &s); // 0: no MFMA grad-weight kernel for this shape
 int finc_gradw_launch(const float *gz, const float *x, float *gw, void *workspace, const FincShape &s, hipStream_t st);

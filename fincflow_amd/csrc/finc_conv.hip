@@ -54,13 +54,19 @@ __device__ inline float row_shl(float src)
 // fragments one wave of the strip kernel keeps in registers
 template <int CQP, int KH, int KW, int NW>
 constexpr int conv_nfrag() { return KH * KW * (CQP / 4 / NW) * (CQP / 16 + (CQP % 16) / 4); }
+// registers the bank occupies: 16-row-tile fragments one each, 4-row-block fragments four to a register (finc_tile.h)
+template <int CQP, int KH, int KW, int NW>
+constexpr int conv_nreg()
+{
+    return KH * KW * (CQP / 4 / NW) * (CQP / 16) + (KH * KW * (CQP / 4 / NW) * ((CQP % 16) / 4) + 3) / 4;
+}
 
 // Two waves per SIMD (256 registers each) is what hides one wave's loads, stores and VALU behind the other's MFMAs:
 // single-wave workgroups ask for that register budget when the bank leaves room for the working set (a 252-fragment
 // bank squeezed into 256 registers spills: 10x slower); the K-split variants keep theirs (their waves are many).
 template <int CQP, int KH, int KW, int NW>
 __global__ __launch_bounds__(64 * NW)
-    __attribute__((amdgpu_waves_per_eu(NW == 1 && conv_nfrag<CQP, KH, KW, NW>() <= 176 ? 2 : 1))) void finc_conv_kernel(const float *__restrict__ in,
+    __attribute__((amdgpu_waves_per_eu(NW == 1 && conv_nreg<CQP, KH, KW, NW>() <= 128 ? 2 : 1))) void finc_conv_kernel(const float *__restrict__ in,
                                                             const float *__restrict__ packed, float *__restrict__ out,
                                                             int G, int CQ, int H, int W, int NS, int RC,
                                                             unsigned orient)
@@ -75,8 +81,22 @@ __global__ __launch_bounds__(64 * NW)
     const int wv = NW > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
     const int lane = threadIdx.x & 63;
     const int q = lane >> 4, p = lane & 15;
-    const int strip = blockIdx.x % NS;
-    const int bg = blockIdx.x / NS;
+    // XCD-aware mapping: workgroups are dealt round-robin over the 8 XCDs, each with its own L2, and the strips of a slab
+    // share the sectors at their seams (the two halo columns left of a strip are the last columns of its neighbour's
+    // sector).  So the NS strips of a slab are placed 8 workgroups apart -- on ONE XCD -- and the seam sector is an L2 hit
+    // for whichever strip asks second (plain order: FETCH_SIZE 1.25x the image).  Speed only: nothing depends on it.
+    const int BGN = (int)gridDim.x / NS;                  // slabs in this launch
+    const int full = (BGN / 8) * 8 * NS;                  // workgroups in whole tiles of 8 slabs
+    int strip, bg;
+    if ((int)blockIdx.x < full) {
+        const int tile = blockIdx.x / (8 * NS), within = blockIdx.x % (8 * NS);
+        strip = within / 8;
+        bg = tile * 8 + within % 8;
+    } else {
+        const int idx = blockIdx.x - full;
+        strip = idx % NS;
+        bg = (BGN / 8) * 8 + idx / NS;
+    }
     const int g = bg % G;
     const unsigned o = finc_group_orient(orient, g);
     const bool fh = (o & FINC_FLIP_H) != 0, fw = (o & FINC_FLIP_W) != 0;
@@ -87,21 +107,70 @@ __global__ __launch_bounds__(64 * NW)
     const __amdgpu_buffer_rsrc_t rout =
         __builtin_amdgcn_make_buffer_rsrc((void *)(out + (size_t)bg * CQ * HW), 0, (int)slab_bytes, 0x00020000);
 
+    // 16-row-tile fragments: one register each; 4-row-block fragments: four to a register, selected by the MFMA's ABID
+    // (finc_tile.h).  The packed bank in memory keeps one 64-lane fragment per (tap, k-step, tile): a lane of a packed
+    // register reads the fragment its pixel quad stands for.
+    constexpr int NSMALL = (NFRAG / MT) * NSM, NSR = (NSMALL + 3) / 4;
     float af[NFRAG];
+    float afs[NSR > 0 ? NSR : 1];
     {
         // global fragment index ((tap*NKZT + j)*MT + mt); this wave's j = wv*NKZ + jl
-        const float *pk = packed + (size_t)g * (NTAP * NKZT * MT) * 64 + lane;
+        const float *pk = packed + (size_t)g * (NTAP * NKZT * MT + 4 * MT) * 64 + lane;
+        auto gindex = [&](int f) {
+            const int mt = f % MT, jl = (f / MT) % NKZ, tap = f / (MT * NKZ);
+            return (tap * NKZT + wv * NKZ + jl) * MT + mt;
+        };
 #pragma unroll
         for (int f = 0; f < NFRAG; ++f) {
-            const int mt = f % MT, jl = (f / MT) % NKZ, tap = f / (MT * NKZ);
-            af[f] = pk[((tap * NKZT + wv * NKZ + jl) * MT + mt) * 64];
+            if (f % MT >= MTB) continue;
+            af[f] = pk[gindex(f) * 64];
         }
-        // MFMA A operands: keep them out of the VGPRs.  With the 256-register budget the files are split 128 : 128, so
-        // a bank larger than that pins what fits and leaves the rest to the allocator.
-        constexpr int NPIN = (NW == 1 && NFRAG > 124 && NFRAG <= 176) ? 124 : NFRAG;
+        const int quad = (lane & 15) >> 2;
 #pragma unroll
-        for (int f = 0; f < NPIN; ++f) asm volatile("" : "+a"(af[f]));
+        for (int r = 0; r < NSR; ++r) {
+            int gi = 0;
+#pragma unroll
+            for (int a = 3; a >= 0; --a) {
+                constexpr int NSMD = NSM > 0 ? NSM : 1;
+                const int sfr = 4 * r + a < NSMALL ? 4 * r + a : NSMALL - 1;
+                const int ga = gindex((sfr / NSMD) * MT + MTB + sfr % NSMD);
+                gi = (a == 3 || quad == a) ? ga : gi;
+            }
+            afs[r] = pk[gi * 64];
+        }
+        // MFMA A operands: keep them out of the VGPRs.  With the 256-register budget of two waves per SIMD the files are
+        // split 128 : 128, so a bank larger than that pins what fits and leaves the rest to the allocator.
+        constexpr int NBIG = (NFRAG / MT) * MTB;
+        constexpr int NPIN = (NW == 1 && NBIG + NSR > 124 && NBIG + NSR <= 176) ? 124 - NSR : NBIG;
+        int pinned = 0;
+#pragma unroll
+        for (int f = 0; f < NFRAG; ++f) {
+            if (f % MT >= MTB) continue;
+            if (pinned++ < NPIN) asm volatile("" : "+a"(af[f]));
+        }
+#pragma unroll
+        for (int r = 0; r < NSR; ++r) asm volatile("" : "+a"(afs[r]));
     }
+    // Output-side affine map folded into the bank (z' = scale * conv(x) + shift: the ActNorm that follows the unit in the
+    // model, layers/actnorm.py:39-46): the rows of the filters carry the scale, and a row's accumulators start from its
+    // shift -- 4*MT registers in accumulator layout behind the fragments (zeros for a plain bank; a K-split adds them once)
+    v4f bias[MT];
+    {
+        const float *pb = packed + ((size_t)g * (NTAP * NKZT * MT + 4 * MT) + NTAP * NKZT * MT) * 64 + lane;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            bias[mt] = (v4f){pb[(4 * mt + 0) * 64], pb[(4 * mt + 1) * 64], pb[(4 * mt + 2) * 64], pb[(4 * mt + 3) * 64]};
+            if (NW > 1 && wv != 0) bias[mt] = (v4f){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    auto mma = [&](v4f &acc_, int f, float b) {
+        const int mt = f % MT;
+        if (mt < MTB) acc_ = __builtin_amdgcn_mfma_f32_16x16x4f32(af[f], b, acc_, 0, 0, 0);
+        else {
+            const int sfr = (f / MT) * NSM + (mt - MTB);
+            finc_mma_small(acc_, afs[sfr >> 2], b, sfr & 3);
+        }
+    };
 
     // Addressing is branch-free and select-free: a buffer offset = (row part, scalar) + (lane part, constant).
     // An off-image row contributes OFF_INVALID (2^31), an off-image column or padded channel OFF_BAD_CHANNEL
@@ -257,7 +326,7 @@ __global__ __launch_bounds__(64 * NW)
         store_row(acc[(S + KH - 1) % KH], h - 1);
         v4f ac[MT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) ac[mt] = (v4f){0.f, 0.f, 0.f, 0.f};
+        for (int mt = 0; mt < MT; ++mt) ac[mt] = bias[mt];
         // rows h-a live in slot (S - a) mod KH; older rows first (their operands are long ready)
 #pragma unroll
         for (int a = KH - 1; a >= 0; --a)
@@ -267,7 +336,7 @@ __global__ __launch_bounds__(64 * NW)
                 for (int j = 0; j < NKZ; ++j)
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
-                        finc_mma<MTB>(ac[mt], mt, af[((a * KW + b) * NKZ + j) * MT + mt], X[(S + KH - a) % KH][b][j]);
+                        mma(ac[mt], ((a * KW + b) * NKZ + j) * MT + mt, X[(S + KH - a) % KH][b][j]);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[S][mt] = ac[mt];
     };
@@ -424,12 +493,23 @@ __global__ void gradw_reduce_kernel(const float *__restrict__ part, float *__res
 }
 
 // fragment (tap (a,b), j, mt), lane (q,i): W[row finc_tile_row(mt,i)][col 4j+q][KH-1-a][KW-1-b]; `transpose` swaps row/col
-__global__ void conv_pack_kernel(const float *__restrict__ wc, float *__restrict__ packed, int Cq, int KH, int KW, int MT,
-                                 int MTB, int NKZ, int transpose, int nfrag)
+// `scale` / `shift` ([G*Cq] or nullptr): the per-output-channel affine map folded behind the conv (rows scaled; shift in
+// the 4*MT bias registers behind the fragments: 16-row tile: lane (q,p), register r = row 16mt+4q+r; 4-row block: register
+// i = row base+i in lane row 0 only, because the block's 4 lane rows are summed)
+__global__ void conv_pack_kernel(const float *__restrict__ wc, const float *__restrict__ scale, const float *__restrict__ shift,
+                                 float *__restrict__ packed, int Cq, int KH, int KW, int MT, int MTB, int NKZ, int transpose,
+                                 int nfrag)
 {
     const int g = blockIdx.y;
     const float *wg = wc + (size_t)g * Cq * Cq * KH * KW;
     const int KK = KH * KW;
+    const int npack = nfrag + 4 * MT;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < 4 * MT * 64; e += gridDim.x * blockDim.x) {
+        const int lane = e & 63, f = e >> 6;
+        const int q = lane >> 4, mt = f >> 2, r = f & 3;
+        const int row = mt < MTB ? 16 * mt + 4 * q + r : (q == 0 ? 16 * MTB + 4 * (mt - MTB) + r : Cq);
+        packed[((size_t)g * npack + nfrag + f) * 64 + lane] = (shift && row < Cq) ? shift[g * Cq + row] : 0.f;
+    }
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < nfrag * 64; e += gridDim.x * blockDim.x) {
         const int lane = e & 63, f = e >> 6;
         const int q = lane >> 4, i = lane & 15;
@@ -440,8 +520,9 @@ __global__ void conv_pack_kernel(const float *__restrict__ wc, float *__restrict
         if (row < Cq && col < Cq) {
             const int oc = transpose ? col : row, ic = transpose ? row : col;
             v = wg[((size_t)oc * Cq + ic) * KK + (KH - 1 - a) * KW + (KW - 1 - b)];
+            if (scale) v *= scale[g * Cq + row];
         }
-        packed[((size_t)g * nfrag + f) * 64 + lane] = v;
+        packed[((size_t)g * npack + f) * 64 + lane] = v;
     }
 }
 
@@ -493,18 +574,19 @@ bool finc_conv_supported(int Cq, int H, int W, int KH, int KW)
 size_t finc_conv_packed_bytes(int G, int Cq, int KH, int KW)
 {
     const ConvInst *i = find_conv(Cq, KH, KW);
-    return i ? (size_t)i->nfrag * 64 * sizeof(float) * (size_t)G : 0;
+    return i ? (size_t)(i->nfrag + 4 * i->mt) * 64 * sizeof(float) * (size_t)G : 0;
 }
 
-int finc_conv_pack(const float *wc, void *packed, int G, int Cq, int KH, int KW, bool transpose, hipStream_t st)
+int finc_conv_pack(const float *wc, void *packed, int G, int Cq, int KH, int KW, bool transpose, hipStream_t st,
+                   const float *scale, const float *shift)
 {
     const ConvInst *i = find_conv(Cq, KH, KW);
     if (!i) return FINC_ERR_UNSUPPORTED;
     const int total = i->nfrag * 64;
     int blocks = (total + 255) / 256;
     if (blocks > 64) blocks = 64;
-    hipLaunchKernelGGL(conv_pack_kernel, dim3(blocks, G), dim3(256), 0, st, wc, (float *)packed, Cq, KH, KW, i->mt,
-                       i->mtb, i->nkz, transpose ? 1 : 0, i->nfrag);
+    hipLaunchKernelGGL(conv_pack_kernel, dim3(blocks, G), dim3(256), 0, st, wc, scale, shift, (float *)packed, Cq, KH, KW,
+                       i->mt, i->mtb, i->nkz, transpose ? 1 : 0, i->nfrag);
     FINC_CHECK_LAUNCH();
     return FINC_OK;
 }

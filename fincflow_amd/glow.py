@@ -65,6 +65,13 @@ class ActNorm(FlowLayer):
         t, ls = self._shaped(input)
         return input * torch.exp(ls) + t
 
+    def forward_affine_params(self):
+        """forward(x) = (x - translation) * exp(-log_scale): what FlowSequential folds into the FastFlowUnit in front of
+        this layer (only once the data-dependent initialisation has happened)."""
+        if not bool(self.initialized):
+            return None
+        return self.log_scale, self.translation
+
     def reverse_affine_params(self):
         """reverse(y) = exp(log_scale) * y + translation, per channel: what FlowSequential folds into the FastFlowUnit
         that comes next in the reverse chain."""

@@ -167,6 +167,15 @@ class FastFlowUnit(nn.Module):
             return self._cache.inverse_affine(y.contiguous(), self._weights(), 4, ops.ORIENT_FASTFLOW, log_scale,
                                               translation)
 
+    def forward_affine(self, x, log_scale, translation):
+        """(forward(x) - translation) * exp(-log_scale): the ActNorm behind the unit rides in the forward bank (SURVEY 8
+        f3, forward direction).  Inference only; None if this call cannot take the fused path."""
+        if torch.is_grad_enabled() and (x.requires_grad or any(w.requires_grad for w in self._weights())):
+            return None
+        with torch.no_grad():
+            return self._cache.forward_affine(x.contiguous(), self._weights(), 4, ops.ORIENT_FASTFLOW, log_scale,
+                                              translation)
+
     def reverse_level1(self, x):
         """fastflow.py:57-76: one solve per group."""
         chunks = torch.chunk(x, 4, dim=1)
@@ -270,10 +279,24 @@ class FlowSequential(nn.Module):
 
     def forward(self, input, context=None, compute_expensive=False):
         logdet = 0
-        for module in self:
+        mods = list(self.sequence_modules)
+        i = 0
+        while i < len(mods):
+            module = mods[i]
+            # density evaluation: a FastFlowUnit followed by an (initialised) per-channel affine layer is one launch
+            if (self.fuse_affine and i + 1 < len(mods) and isinstance(module, FastFlowUnit)
+                    and hasattr(mods[i + 1], "forward_affine_params") and not torch.is_grad_enabled()):
+                params = mods[i + 1].forward_affine_params()
+                fused = module.forward_affine(input, *params) if params is not None else None
+                if fused is not None:
+                    logdet += mods[i + 1].logdet(input, context)      # (the unit's own logdet is 0)
+                    input = output = fused
+                    i += 2
+                    continue
             output, layer_logdet = module(input, context)
             logdet += layer_logdet
             input = output
+            i += 1
         logprob = self.base_distribution.log_prob(input)
         return output, logprob + logdet
 

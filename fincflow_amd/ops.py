@@ -207,7 +207,7 @@ def inverse(input, kernel, output):
 
 class _DeviceBank:
     """What PackedWeights holds for ONE device."""
-    __slots__ = ("key", "w_canon", "packed_inv", "packed_fwd", "packed_aff", "aff_key")
+    __slots__ = ("key", "w_canon", "packed_inv", "packed_fwd", "packed_aff", "aff_key", "packed_faff", "faff_key")
 
     def __init__(self):
         self.key = None
@@ -216,6 +216,8 @@ class _DeviceBank:
         self.packed_fwd = None
         self.packed_aff = None
         self.aff_key = None
+        self.packed_faff = None
+        self.faff_key = None
 
 
 class PackedWeights:
@@ -263,6 +265,7 @@ class PackedWeights:
             bank.packed_inv = None
             bank.packed_fwd = None
             bank.packed_aff = None
+            bank.packed_faff = None
             bank.key = key
         return bank
 
@@ -283,6 +286,35 @@ class PackedWeights:
             if out is None:
                 out = torch.empty_like(x)
             _lib.check(L.finc_forward_packed_f32(x.data_ptr(), bank.packed_fwd.data_ptr(), out.data_ptr(), B, G, Cq, H, W,
+                                                 KH, KW, orient, _stream_ptr(x)), "finc_forward_packed_f32")
+        return out
+
+    def forward_affine(self, x, weights, G, orient, log_scale, translation, out=None):
+        """(forward(x) - translation) * exp(-log_scale) in ONE launch: the per-channel affine layer BEHIND the unit in the
+        model (ActNorm.forward, layers/actnorm.py:39-46) folded into the forward bank -- filter rows scaled, accumulators
+        started from the shift.  Returns None when the shape has no MFMA strip kernel (the caller runs the two layers)."""
+        bank = self._get(weights, G, orient)
+        w_canon = bank.w_canon
+        _require_device(x, "input")
+        B, Cq, H, W, KH, KW = _dims(x, w_canon, G)
+        L = _lib.lib()
+        if x.numel() == 0 or L.finc_forward_algo_for(Cq, H, W, KH, KW) != _lib.ALGO["mfma"]:
+            return None
+        key = (log_scale.data_ptr(), log_scale._version, translation.data_ptr(), translation._version)
+        with torch.cuda.device(x.device):
+            if bank.packed_faff is None or bank.faff_key != key:
+                scale = torch.exp(-log_scale.detach().float()).contiguous()
+                shift = (-translation.detach().float() * scale).contiguous()
+                if scale.numel() != G * Cq:
+                    raise ValueError("affine parameters must have one entry per channel")
+                bank.packed_faff = torch.empty(L.finc_workspace_bytes(G, Cq, KH, KW), dtype=torch.uint8, device=x.device)
+                _lib.check(L.finc_pack_forward_weights_affine_f32(w_canon.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                                                  bank.packed_faff.data_ptr(), G, Cq, KH, KW, _stream_ptr(x)),
+                           "finc_pack_forward_weights_affine_f32")
+                bank.faff_key = key
+            if out is None:
+                out = torch.empty_like(x)
+            _lib.check(L.finc_forward_packed_f32(x.data_ptr(), bank.packed_faff.data_ptr(), out.data_ptr(), B, G, Cq, H, W,
                                                  KH, KW, orient, _stream_ptr(x)), "finc_forward_packed_f32")
         return out
 

@@ -139,6 +139,15 @@ int finc_pack_forward_weights_f32(const float *w_canon, void *packed, int G, int
  */
 int finc_pack_inverse_weights_affine_f32(const float *w_canon, const float *scale, const float *shift, void *packed,
                                          int G, int Cq, int KH, int KW, finc_stream_t stream);
+/*
+ * The same fold for the forward direction: with fragments packed by this call, finc_forward_packed_f32(x, ...) returns
+ * scale * forward(x) + shift per output channel, i.e. ActNorm.forward(FastFlowUnit.forward(x)) (layers/actnorm.py:39-46:
+ * scale = exp(-log_scale), shift = -translation * exp(-log_scale); FlowSequential.forward calls them back to back,
+ * layers/flowsequential.py:21-44) in the one launch: the filter rows carry the scale, the accumulators start from the
+ * shift.  The layer's log-determinant is the caller's business (it does not depend on the data).
+ */
+int finc_pack_forward_weights_affine_f32(const float *w_canon, const float *scale, const float *shift, void *packed,
+                                         int G, int Cq, int KH, int KW, finc_stream_t stream);
 int finc_inverse_packed_f32(const float *z, const void *packed, float *x, int B, int G, int Cq, int H, int W,
                             int KH, int KW, unsigned orient, finc_stream_t stream);
 int finc_forward_packed_f32(const float *x, const void *packed, float *z, int B, int G, int Cq, int H, int W,

@@ -316,3 +316,43 @@ def test_conv1x1_module_runs_on_the_mix_kernel(dev):
     zg, _ = c(xg)
     zg.sum().backward()
     assert xg.grad is not None and c.W.grad is not None
+
+
+@pytest.mark.parametrize("shape", [(3, 96, 20, 24, 3), (2, 48, 16, 16, 3), (2, 12, 9, 8, 3), (2, 192, 12, 16, 3), (1, 64, 10, 12, 5)])
+def test_affine_fold_behind_the_forward(shape, dev):
+    """SURVEY 8 f3, forward direction: ActNorm.forward(FastFlowUnit.forward(x)) in one launch (filter rows scaled, accumulators
+    started from the shift; K-split banks add the shift once).  Against the two layers one after the other and the oracle;
+    FlowSequential.forward takes the fused path by itself and returns the same log-probabilities."""
+    from fincflow_amd import FastFlowUnit, FlowSequential, glow
+    from fincflow_amd.layers import StandardNormal
+    B, C, H, W, K = shape
+    torch.manual_seed(sum(shape))
+    unit = FastFlowUnit(C, C, K).to(dev)
+    an = glow.ActNorm(C).to(dev)
+    with torch.no_grad():
+        an.log_scale.copy_(0.3 * torch.randn(C, device=dev))
+        an.translation.copy_(torch.randn(C, device=dev))
+        an.initialized.fill_(1)
+        x = torch.randn(B, C, H, W, device=dev)
+        two = an(unit(x)[0])[0]
+        fused = unit.forward_affine(x, an.log_scale, an.translation)
+    assert fused is not None
+    assert rel_err(fused.cpu().numpy(), two.cpu().numpy()) <= TOL
+    ws = torch.cat(unit._weights()).detach().cpu().numpy()
+    wco = oracle.canonicalize(ws, 4, ORIENT_FASTFLOW)
+    z = oracle.forward_f32(x.cpu().numpy(), wco)
+    ref = (z - an.translation.detach().cpu().numpy()[None, :, None, None]) * np.exp(-an.log_scale.detach().cpu().numpy())[None, :, None, None]
+    assert rel_err(fused.cpu().numpy(), ref) <= TOL
+    seq = FlowSequential(StandardNormal((C, H, W)), unit, an)
+    with torch.no_grad():
+        seq.fuse_affine = True
+        za, lpa = seq(x)
+        seq.fuse_affine = False
+        zb, lpb = seq(x)
+        assert rel_err(za.cpu().numpy(), zb.cpu().numpy()) <= TOL and torch.allclose(lpa, lpb, rtol=1e-5, atol=1e-3)
+        an.translation.add_(0.5)                        # in-place update: the cached bank must follow
+        seq.fuse_affine = True
+        zc, _ = seq(x)
+        assert rel_err(zc.cpu().numpy(), an(unit(x)[0])[0].cpu().numpy()) <= TOL
+        an.initialized.fill_(0)                          # not initialised: no fold (ActNorm.forward must see the data)
+        assert an.forward_affine_params() is None
