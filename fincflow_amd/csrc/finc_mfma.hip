@@ -272,6 +272,18 @@ __global__ __launch_bounds__(64 * NW * NPW) void finc_wave_kernel(const float *_
     float *xch = lds_p;
     float *zring = lds_p + C::XCH + wv * wave_lds;
     float *xring = zring + C::ZRING;
+    // z ring: per k-step j, 12 column slots as 3 groups of 4; a group is [cell 0..63][4 columns], one 16-byte cell per
+    // (lane row q, image row r) -- so a landing is ONE ds_write_b128 of the piece as it came from memory (a W-flipped
+    // group reads its elements in reverse instead), and it can be written straight from an AGPR tuple.  The cell of (q, r)
+    // is swizzled for both sides: the per-step reads (lane (q,p) takes element (t-p)&3 of its own cell) hit 32 different
+    // banks, and the 8 lanes that ds_write_b128 serves together -- they land the rows {0,5,6,7}, {8,13,14,15}, {1,2,3,4} or
+    // {9,10,11,12}, each row twice (its two groups) -- spread over 4 bank sets (2-way, the minimum; unswizzled: 6-way, and
+    // the landings of a window cost 5 % of the kernel).  Low bits of the cell = (r >> 2) ^ T[r & 3], T = {0, 0, 2, 3}:
+    // found by search over the Latin squares that separate both families.
+    auto zcell = [](int qq, int rr) {
+        const int lo = ((rr >> 2) ^ ((0x3200 >> (4 * (rr & 3))) & 3)) | ((qq & 1) << 2);
+        return lo | (((rr & 3) | ((qq >> 1) << 2)) << 3);
+    };
     float *fifo = xring + C::XRING;
     const int trash = fifo_n + lane;          // per-lane scratch word(s): lanes that neither push nor pop point here
 
@@ -396,7 +408,7 @@ __global__ __launch_bounds__(64 * NW * NPW) void finc_wave_kernel(const float *_
         lcolS[wp] = 4 * ((wp ? -3 : -4) + 4 + f);
         lrowS[wp] = R;
         lslotS[wp] = ((4 * (((wp ? -3 : -4) + 2 + f + h) % 3 + 3)) % 12);
-        ldst[wp] = q * 16 + R;
+        ldst[wp] = 4 * zcell(q, R);
         const int c = lcolS[wp] + 4 * h;
         loffS[wp] = ((fh ? H - 1 - R : R) * W + (fw ? W - 4 - c : c)) * 4 + (4 * wv * NKZ + q) * HW * 4;
         scolS[wp] = 4 * ((wp ? -1 : 0) - 2 + f);
@@ -458,37 +470,24 @@ __global__ __launch_bounds__(64 * NW * NPW) void finc_wave_kernel(const float *_
         constexpr int VM = decltype(vm_c)::value;
         if constexpr (S64L) {
             float *dst = zring + lslotS[WP] * 64 + ldst[WP];
-            float *d0 = dst + k0 * 64, *d1 = dst + k1 * 64, *d2 = dst + k2 * 64, *d3 = dst + k3 * 64;
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM) : "memory");
-            if (lphi[WP] == 0) {               // (divergent; both sides always have lanes: W % 16 == 0 keeps the rows' phases apart)
-                asm volatile("; land lower");
+#ifndef FINC_S64_ABLATE   // timing-only bits: 1 no vmcnt wait, 2 no landing writes, 4 no load issue
+#define FINC_S64_ABLATE 0
+#endif
+            if constexpr (!(FINC_S64_ABLATE & 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM) : "memory");
+            if constexpr (FINC_S64_ABLATE & 2) {
+            } else if (lphi[WP] == 0) {        // (divergent; both sides always have lanes: W % 16 == 0 keeps the rows' phases apart)
 #pragma unroll
-                for (int j = 0; j < NKZ; ++j) {
-                    const unsigned a0 = Z[WP][j].x, a1 = Z[WP][j].y, a2 = Z[WP][j].z, a3 = Z[WP][j].w;
-                    d0[j * C::ZSLOTS * 64] = __builtin_bit_cast(float, a0);
-                    d1[j * C::ZSLOTS * 64] = __builtin_bit_cast(float, a1);
-                    d2[j * C::ZSLOTS * 64] = __builtin_bit_cast(float, a2);
-                    d3[j * C::ZSLOTS * 64] = __builtin_bit_cast(float, a3);
-                }
-            } else {
-                // the upper piece comes out of its AGPR tuple as a whole (4 v_accvgpr_read) -- the asm also keeps the two
-                // sides of the branch different, or the compiler merges them over a pointer select and both register
-                // sets end up in scratch memory
+                for (int j = 0; j < NKZ; ++j) *reinterpret_cast<v4u *>(dst + j * C::ZSLOTS * 64) = Z[WP][j];
+            } else {                           // the upper piece goes from its AGPR tuple to the ring as it is
+                const unsigned ba = (unsigned)(uintptr_t)dst;
 #pragma unroll
-                for (int j = 0; j < NKZ; ++j) {
-                    v4u t = ZU[WP][j];
-                    asm volatile("; upper piece" : "+v"(t));
-                    const unsigned a0 = t.x, a1 = t.y, a2 = t.z, a3 = t.w;
-                    d0[j * C::ZSLOTS * 64] = __builtin_bit_cast(float, a0);
-                    d1[j * C::ZSLOTS * 64] = __builtin_bit_cast(float, a1);
-                    d2[j * C::ZSLOTS * 64] = __builtin_bit_cast(float, a2);
-                    d3[j * C::ZSLOTS * 64] = __builtin_bit_cast(float, a3);
-                }
+                for (int j = 0; j < NKZ; ++j)
+                    asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(ba), "a"(ZU[WP][j]), "n"(j * C::ZSLOTS * 256) : "memory");
             }
             lslotS[WP] = lslotS[WP] >= 4 ? lslotS[WP] - 4 : lslotS[WP] + 8;   // + 8 mod 12
             const int phi = ((lcolS[WP] + 64) >> 3) & 1;
             lphi[WP] = phi;
-            if (phi == 0) {                    // a lower piece: ask for the whole sector (exec-masked: the other lanes' ZU is waiting to land)
+            if ((FINC_S64_ABLATE & 4) == 0 && phi == 0) {   // a lower piece: ask for the whole sector (exec-masked: the other lanes' ZU is waiting to land)
                 const bool ok = lcolS[WP] >= 0 && lrowS[WP] < H && p < P;
                 const unsigned vl = ok ? (unsigned)loffS[WP] : OFF_INVALID;
                 const unsigned vu = ok ? (unsigned)(loffS[WP] + 32 * dirw) : OFF_INVALID;
@@ -512,14 +511,7 @@ __global__ __launch_bounds__(64 * NW * NPW) void finc_wave_kernel(const float *_
         if constexpr (S64L) return;            // (s64_event is called in its place)
         float *dst = zring + lslotS[WP] * 64 + ldst[WP];
 #pragma unroll
-        for (int j = 0; j < NKZ; ++j) {
-            const unsigned a0 = Z[WP][j].x, a1 = Z[WP][j].y, a2 = Z[WP][j].z, a3 = Z[WP][j].w;
-            float *d = dst + j * C::ZSLOTS * 64;
-            d[k0 * 64] = __builtin_bit_cast(float, a0);
-            d[k1 * 64] = __builtin_bit_cast(float, a1);
-            d[k2 * 64] = __builtin_bit_cast(float, a2);
-            d[k3 * 64] = __builtin_bit_cast(float, a3);
-        }
+        for (int j = 0; j < NKZ; ++j) *reinterpret_cast<v4u *>(dst + j * C::ZSLOTS * 64) = Z[WP][j];
         lslotS[WP] = lslotS[WP] >= 4 ? lslotS[WP] - 4 : lslotS[WP] + 8;   // + 8 mod 12
         const bool ok = lcolS[WP] >= 0 && lrowS[WP] < H && p < P;
         const unsigned vb = ok ? (unsigned)loffS[WP] : OFF_INVALID;
@@ -638,16 +630,9 @@ __global__ __launch_bounds__(64 * NW * NPW) void finc_wave_kernel(const float *_
         }
     };
     auto io_land = [&]() {
-        float *b0 = zring + (lslot + k0) * 64 + lane, *b1 = zring + (lslot + k1) * 64 + lane;
-        float *b2 = zring + (lslot + k2) * 64 + lane, *b3 = zring + (lslot + k3) * 64 + lane;
+        float *dst = zring + lslot * 64 + 4 * zcell(q, p);
 #pragma unroll
-        for (int j = 0; j < NKZ; ++j) {
-            const unsigned v0 = zb[j].x, v1 = zb[j].y, v2 = zb[j].z, v3 = zb[j].w;
-            b0[j * C::ZSLOTS * 64] = __builtin_bit_cast(float, v0);
-            b1[j * C::ZSLOTS * 64] = __builtin_bit_cast(float, v1);
-            b2[j * C::ZSLOTS * 64] = __builtin_bit_cast(float, v2);
-            b3[j * C::ZSLOTS * 64] = __builtin_bit_cast(float, v3);
-        }
+        for (int j = 0; j < NKZ; ++j) *reinterpret_cast<v4u *>(dst + j * C::ZSLOTS * 64) = zb[j];
         lslot = lslot == 8 ? 0 : lslot + 4;
     };
     auto io_sread = [&]() {
@@ -847,7 +832,13 @@ __global__ __launch_bounds__(64 * NW * NPW) void finc_wave_kernel(const float *_
     }
 
     int nslot = ((-3 - p) % 12 + 12) % 12;    // z-ring slot of the position of step t+1 ...
-    const float *zrd = zring + nslot * 64 + lane; // ... and its address
+    // ... and its address: group (slot >> 2), own cell, element (slot & 3) -- counted from the other end in a W-flipped group
+    const float *zrd = zring + (nslot >> 2) * 256 + 4 * zcell(q, p) + (fw ? 3 - (nslot & 3) : (nslot & 3));
+    // per-step advance of zrd: +-1 inside a group, a jump to the next group when the new slot starts one.  After the advance
+    // of step t the slot is (t + 2 - p) mod 12, so which lanes jump is a function of t & 3: four per-lane constants.
+    int zstep[4];
+#pragma unroll
+    for (int ph = 0; ph < 4; ++ph) zstep[ph] = (((ph + 2 - p) & 3) == 0) ? 256 - 3 * dirw : dirw;
     int tp1 = -3;                             // t+1 (scalar).  Lane p has started its chain iff p <= t+1 ...
     int tm = -3;                              // ... and its NEXT position starts a row iff p == (t+1) mod W =: tm
     int xwin = 256 + lane;                    // x-ring write index of this window: 256*((t>>2)&1) + lane, t = -4
@@ -1088,7 +1079,7 @@ __global__ __launch_bounds__(64 * NW * NPW) void finc_wave_kernel(const float *_
             if constexpr (NW > 1) __syncthreads();     // every wave has read its shares: the buffer may be rewritten
             ++tp1;
             ++tm; if (tm == W) tm = 0;
-            ++nslot; zrd += 64;
+            ++nslot; zrd += zstep[PH];
             if (nslot == 12) { nslot = 0; zrd -= 12 * 64; }
             if constexpr (PH == 3) xwin ^= 256;
             fifo_advance();
@@ -1111,7 +1102,7 @@ __global__ __launch_bounds__(64 * NW * NPW) void finc_wave_kernel(const float *_
 #pragma unroll
         for (int k = 0; k < 3; ++k) {                  // steps -4, -3, -2: bookkeeping only (the FIFO ring is zero)
             ++tp1; ++tm;
-            ++nslot; zrd += 64;
+            ++nslot; zrd += zstep[k];                  // (t = -4 + k: t & 3 == k)
             if (nslot == 12) { nslot = 0; zrd -= 12 * 64; }
             fifo_advance();
         }
@@ -1133,7 +1124,7 @@ __global__ __launch_bounds__(64 * NW * NPW) void finc_wave_kernel(const float *_
                 }
             }
             ++tp1; ++tm;
-            ++nslot; zrd += 64;
+            ++nslot; zrd += zstep[3];
             if (nslot == 12) { nslot = 0; zrd -= 12 * 64; }
             xwin ^= 256;
             fifo_advance();
