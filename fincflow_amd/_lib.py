@@ -21,7 +21,7 @@ SYMBOLS = [
     "finc_inverse_workspace_bytes", "finc_pack_inverse_weights_affine_f32",
     "finc_canonicalize_weights_f64", "finc_inverse_f64", "finc_forward_f64",
     "finc_inverse_kernel_variant", "finc_debug_attr_table_insert", "finc_debug_inverse_table_row",
-    "finc_mix_supported_f32", "finc_mix_f32", "finc_pack_forward_weights_affine_f32",
+    "finc_mix_supported_f32", "finc_mix_f32", "finc_pack_forward_weights_affine_f32", "finc_debug_hlp_timeouts",
 ]
 
 _lib = None
@@ -73,6 +73,7 @@ def lib():
     L.finc_inverse_kernel_variant.argtypes = [i, i, i, i, i, i, i, ctypes.POINTER(ctypes.c_int)]
     L.finc_debug_attr_table_insert.argtypes = [i, sz]
     L.finc_debug_inverse_table_row.argtypes = [i, ctypes.POINTER(ctypes.c_int)]
+    L.finc_debug_hlp_timeouts.argtypes = [ctypes.POINTER(ctypes.c_uint)]
     L.finc_mix_supported_f32.argtypes = [i]
     L.finc_mix_f32.argtypes = [vp, vp, vp, vp, i, i, i, vp]
     for name in SYMBOLS:
@@ -90,6 +91,13 @@ def inverse_variant(B, G, Cq, H, W, KH, KW):
     check(st, "finc_inverse_kernel_variant")
     keys = ("cqp", "nw", "npw", "sec", "lds_bytes", "workgroups", "row", "rows")
     return dict(zip(keys, list(info)))
+
+
+def hlp_timeouts():
+    """Waits of the helper-wave inverse that gave up (must be 0)."""
+    n = ctypes.c_uint(0)
+    check(lib().finc_debug_hlp_timeouts(ctypes.byref(n)), "finc_debug_hlp_timeouts")
+    return int(n.value)
 
 
 def inverse_table():

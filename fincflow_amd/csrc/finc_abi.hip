@@ -375,6 +375,12 @@ int finc_mix_f32(const float *in, const float *mat, const float *bias, float *ou
     return finc_mix_launch(in, mat, bias, out, B, C, HW, (hipStream_t)stream);
 }
 
+int finc_debug_hlp_timeouts(unsigned *h_count)
+{
+    if (!h_count) return FINC_ERR_NULL_POINTER;
+    return finc_mfma_hlp_timeouts(h_count);
+}
+
 int finc_debug_inverse_table_row(int row, int *info)
 {
     if (!info) return FINC_ERR_NULL_POINTER;

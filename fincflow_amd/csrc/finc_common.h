@@ -64,6 +64,8 @@ int finc_mfma_launch(const float *in, const void *packed, float *out, const Finc
 int finc_mfma_variant(int B, int G, int Cq, int H, int W, int KH, int KW, int *info);
 // info[0..5] = {Cq padded, KH, KW, waves per problem, problems per workgroup, max_problems (0 = no limit)}
 int finc_mfma_table_row(int row, int *info);
+// waits of the helper-wave protocol that ran out of their spin budget since the library was loaded (synchronous copy)
+int finc_mfma_hlp_timeouts(unsigned *count);
 
 // ---- forward / grad-input, MFMA strip kernel: finc_conv.hip ----
 bool finc_conv_supported(int Cq, int H, int W, int KH, int KW);

@@ -201,6 +201,15 @@ __device__ unsigned long long finc_stamp_buf[64];
 #define FINC_STAMP_AT(k) do { } while (0)
 #endif
 
+__device__ unsigned finc_hlp_timeouts = 0;       // helper-wave protocol: waits that gave up (must stay 0)
+#ifdef FINC_HLP_COUNT    // diagnostic build: how often the compute wave finds its partner late (word 0: landing, 1: x-ring reads)
+__device__ unsigned finc_hlp_late[2] = {0, 0};
+#define FINC_HLP_LATE(k) do { if ((threadIdx.x & 63) == 0) atomicAdd(&finc_hlp_late[k], 1u); } while (0)
+extern "C" int finc_debug_hlp_late(unsigned *h) { return (int)hipMemcpyFromSymbol(h, HIP_SYMBOL(finc_hlp_late), 8); }
+#else
+#define FINC_HLP_LATE(k) do { } while (0)
+#endif
+
 constexpr unsigned OFF_INVALID = 0x80000000u;    // voffset beyond any slab: buffer loads return 0, stores are dropped
 constexpr unsigned OFF_BAD_CHANNEL = 0x40000000u; // added to a valid offset it still lands beyond the slab (< 1 GiB)
 
@@ -234,8 +243,21 @@ constexpr unsigned OFF_BAD_CHANNEL = 0x40000000u; // added to a valid offset it 
 // hipcc does not count: the kernel waits for them itself (one s_waitcnt vmcnt per event; the instruction order of a
 // window is fixed, so the count is a constant) and ALL z loads of this variant are asm so that hipcc has no VMEM load of
 // its own to mis-count around them.
-template <int CQP, int KH, int KW, bool SEC, int NW = 1, int NPW = 1, int S64 = 0>
-__global__ __launch_bounds__(64 * NW * NPW) void finc_wave_kernel(const float *__restrict__ in,
+// HLP ("helper waves"; with S64 = 3): the workgroup is 8 waves = 4 problems.  Waves 0-3 only COMPUTE (z-ring reads, MFMAs,
+// post-processing, x-ring / FIFO writes: no HBM instruction at all); waves 4-7 -- by the dispatch order of a workgroup's
+// waves the SIMD partners of waves 0-3 -- run the whole HBM side of "their" problem (loads, landings, x-ring reads, parking,
+// stores) in the original order.  A second wave's VALU / LDS / VMEM work does not slow an fp32 MFMA stream on the same
+// SIMD (scripts/micro/mfma_helper.hip: 0.0 %), whereas the same instructions issued by the MFMA wave itself cost their
+// full issue time: the I/O side was 63 us of the 438 us kernel (profiles/r02/notes/ab12).  The two
+// waves of a problem meet through four monotonic words in LDS (no workgroup barrier: the four problems stay independent):
+//   A1  compute -> helper   A1 >= w: the z read of step 4w-1 is in the LDS queue: the landing of window w-1 may go ahead
+//   A   compute -> helper   A >= w: the compute wave is past the x-ring write of step 4w-1: window w's x-ring reads may
+//   B   helper -> compute   B >= w: the landing of window w-1 is done -- checked before the z read of step 4w
+//   B2  helper -> compute   B2 >= w+1: the x-ring reads of window w are done -- checked before the x-ring write of step 4w+1
+// LDS executes a wave's operations in order and has no cache, so a flag written after the data is seen after the data.
+// Every spin is bounded.
+template <int CQP, int KH, int KW, bool SEC, int NW = 1, int NPW = 1, int S64 = 0, int HLP = 0>
+__global__ __launch_bounds__(HLP ? 512 : 64 * NW * NPW) void finc_wave_kernel(const float *__restrict__ in,
                                                             const float *__restrict__ packed, float *__restrict__ out,
                                                             int G, int CQ, int H, int W, int P, int Tend,
                                                             unsigned orient)
@@ -245,12 +267,14 @@ __global__ __launch_bounds__(64 * NW * NPW) void finc_wave_kernel(const float *_
     constexpr int JS = 4 * (KH - 1);          // FIFO: floats per k-step (4 k-slots x (KH-1) source lanes)
     constexpr int SS = NK * JS;               // FIFO: floats per step slot
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int wvt = NW * NPW > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;  // wave of the workgroup
-    const int wv = wvt % NW;                  // wave of the problem (K-split)
-    const int prob = wvt / NW;                // problem of the workgroup
+    static_assert(!HLP || (S64 == 3 && NW == 1 && NPW == 1), "helper waves: the sector-pairing kernel, one compute wave per problem");
+    const int wvt = (HLP || NW * NPW > 1) ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;  // wave of the workgroup
+    const bool helper = HLP && wvt >= 4;      // waves 4-7: the HBM side of problems 0-3
+    const int wv = HLP ? 0 : wvt % NW;        // wave of the problem (K-split)
+    const int prob = HLP ? (wvt & 3) : wvt / NW;   // problem of the workgroup
     const int lane = threadIdx.x & 63;
     const int q = lane >> 4, p = lane & 15;
-    const int bg = blockIdx.x * NPW + prob;
+    const int bg = blockIdx.x * (HLP ? 4 : NPW) + prob;
     const int g = bg % G;
     const unsigned o = finc_group_orient(orient, g);
     const bool fh = (o & FINC_FLIP_H) != 0, fw = (o & FINC_FLIP_W) != 0;
@@ -286,6 +310,36 @@ __global__ __launch_bounds__(64 * NW * NPW) void finc_wave_kernel(const float *_
     };
     float *fifo = xring + C::XRING;
     const int trash = fifo_n + lane;          // per-lane scratch word(s): lanes that neither push nor pop point here
+    // HLP: the three progress words of this problem, behind the four problems' rings
+    const unsigned flag_a = (unsigned)(uintptr_t)(lds + 4 * wave_lds + 4 * prob);   // +0: A, +4: B, +8: B2, +12: A1 (bytes)
+    auto flag_set = [flag_a](auto word_c, int v) {
+        constexpr int WORD = decltype(word_c)::value;
+        if constexpr (HLP) asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(flag_a), "v"(v), "n"(4 * WORD) : "memory");
+    };
+    // two-stage wait for the compute role: `peek` only issues the read (no wait); `check` -- a few hundred cycles later, when
+    // the value has long arrived -- tests it and falls back to the polling loop only if the partner really is late.  A wait
+    // that reads and tests in one go stalls the MFMA wave for a whole LDS round trip twice per window (2 % of the kernel).
+    auto flag_peek = [flag_a](auto word_c, int &reg) {
+        constexpr int WORD = decltype(word_c)::value;
+        if constexpr (HLP) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(reg) : "v"(flag_a), "n"(4 * WORD) : "memory");
+    };
+    auto flag_wait = [flag_a](auto word_c, int target) {
+        constexpr int WORD = decltype(word_c)::value;
+#ifndef FINC_HLP_NOWAIT     // timing-only bit mask of flag words whose waits are skipped (0 A, 1 B, 2 B2); results wrong
+#define FINC_HLP_NOWAIT 0
+#endif
+        if constexpr (HLP && !((FINC_HLP_NOWAIT >> WORD) & 1)) {
+            int budget = 1 << 20;              // bounded (~0.1 s): a protocol bug must not hang the GPU ...
+            for (; budget > 0; --budget) {
+                int v;
+                asm volatile("ds_read_b32 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(flag_a), "n"(4 * WORD) : "memory");
+                if (__builtin_amdgcn_readfirstlane(v) >= target) break;
+                __builtin_amdgcn_s_sleep(2);
+            }
+            // ... and must not pass unnoticed: finc_debug_hlp_timeouts() reads this counter (tests assert it stays 0)
+            if (budget == 0 && (threadIdx.x & 63) == 0) atomicAdd(&finc_hlp_timeouts, 1u);
+        }
+    };
 
     // ---- filter fragments -> registers -------------------------------------------------------
     // 16-row-tile fragments: one register each (af[f], f = the fragment's index); 4-row-block fragments: four to a
@@ -295,7 +349,7 @@ __global__ __launch_bounds__(64 * NW * NPW) void finc_wave_kernel(const float *_
     constexpr int NSMALL = (NFRAG / MT) * C::NSM, NSR = (NSMALL + 3) / 4;
     float af[NFRAG];
     float afs[NSR > 0 ? NSR : 1];
-    {
+    if (!helper) {
         // packed index: z-term (j*MT + mt), then taps ((tap-1)*NKDT + j)*MT + mt, j global; this wave's j = wv*N + jl
         const float *pk = packed + (size_t)g * C::NPACK * 64 + lane;
         auto gindex = [&](int f) {
@@ -441,34 +495,46 @@ __global__ __launch_bounds__(64 * NW * NPW) void finc_wave_kernel(const float *_
     // the lower pieces of the load side stay in Z (VGPRs, written by asm loads in this variant); the upper pieces (ZU) and
     // the parked store pieces (PK) are the new state and live in AGPRs
     constexpr bool PK_AGPR = S64S;
-    v4u ZU[2][S64L ? NKZ : 1];
+    // HLP: two waves per SIMD share the register file, and hipcc splits a wave's 256 registers 128 : 128 between VGPRs and
+    // AGPRs.  The helper role fits only if the lower pieces (ZA) wait in AGPRs too and one parked set stays in VGPRs; it
+    // MUST fit: a spilled in-flight load destination is saved before the data has arrived (hipcc takes an asm output for
+    // complete).
+    constexpr bool ZA_AGPR = HLP != 0;
+    v4u ZU[2][S64L ? NKZ : 1], ZA[2][ZA_AGPR ? NKZ : 1];
     v4f PK[2][S64S ? NKD : 1];                // parked lower pieces of the store side
     int lphi[2] = {0, 0};                     // phase (0 lower / 1 upper) of the piece of the stream's previous event
     bool spark = false;                       // this window's piece is a lower one: park it
     unsigned st_off2 = OFF_INVALID;           // where the parked lower piece goes when its upper piece leaves
-    if constexpr (S64L) {
+    auto s64_init = [&]() {                    // zeros in the waiting sets (what lands before anything was requested)
+        if constexpr (S64L) {
 #pragma unroll
-        for (int wp = 0; wp < 2; ++wp)
+            for (int wp = 0; wp < 2; ++wp)
 #pragma unroll
-            for (int j = 0; j < NKZ; ++j) {
-                ZU[wp][j] = (v4u){0u, 0u, 0u, 0u}; asm volatile("" : "+a"(ZU[wp][j]));
-            }
-    }
-    if constexpr (S64S) {
+                for (int j = 0; j < NKZ; ++j) {
+                    ZU[wp][j] = (v4u){0u, 0u, 0u, 0u}; asm volatile("" : "+a"(ZU[wp][j]));
+                    if constexpr (ZA_AGPR) { ZA[wp][j] = (v4u){0u, 0u, 0u, 0u}; asm volatile("" : "+a"(ZA[wp][j])); }
+                }
+        }
+        if constexpr (S64S) {
 #pragma unroll
-        for (int wp = 0; wp < 2; ++wp)
+            for (int wp = 0; wp < 2; ++wp)
 #pragma unroll
-            for (int j = 0; j < NKD; ++j) {
-                PK[wp][j] = (v4f){0.f, 0.f, 0.f, 0.f};
-                if constexpr (PK_AGPR) asm volatile("" : "+a"(PK[wp][j]));
-            }
-    }
+                for (int j = 0; j < NKD; ++j) {
+                    PK[wp][j] = (v4f){0.f, 0.f, 0.f, 0.f};
+                    if constexpr (PK_AGPR) { if (!HLP || wp == 0) asm volatile("" : "+a"(PK[wp][j])); }
+                }
+        }
+    };
+    if constexpr (!HLP) s64_init();            // (HLP: at the entry of the helper role -- the compute role never touches these)
     // S64 landing: `vm` = the s_waitcnt vmcnt immediate that covers the lower pieces issued two windows ago (everything
     // older, the upper pieces of four windows ago included, is then complete as well: the counter is in order)
-    auto s64_event = [&](auto wp_c, auto vm_c) {
+    // (part_c: 0 = the whole event; 1 = only the landing, 2 = only the requests -- the helper role does its urgent x-ring
+    // reads between the two)
+    auto s64_part = [&](auto wp_c, auto vm_c, int pub_b, auto part_c) {
         constexpr int WP = decltype(wp_c)::value;
         constexpr int VM = decltype(vm_c)::value;
-        if constexpr (S64L) {
+        constexpr int PART = decltype(part_c)::value;
+        if constexpr (S64L && PART != 2) {
             float *dst = zring + lslotS[WP] * 64 + ldst[WP];
 #ifndef FINC_S64_ABLATE   // timing-only bits: 1 no vmcnt wait, 2 no landing writes, 4 no load issue
 #define FINC_S64_ABLATE 0
@@ -476,15 +542,27 @@ __global__ __launch_bounds__(64 * NW * NPW) void finc_wave_kernel(const float *_
             if constexpr (!(FINC_S64_ABLATE & 1)) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(VM) : "memory");
             if constexpr (FINC_S64_ABLATE & 2) {
             } else if (lphi[WP] == 0) {        // (divergent; both sides always have lanes: W % 16 == 0 keeps the rows' phases apart)
+                if constexpr (ZA_AGPR) {
+                    const unsigned ba = (unsigned)(uintptr_t)dst;
 #pragma unroll
-                for (int j = 0; j < NKZ; ++j) *reinterpret_cast<v4u *>(dst + j * C::ZSLOTS * 64) = Z[WP][j];
+                    for (int j = 0; j < NKZ; ++j)      // (the comment keeps the two sides' asm different: identical asm is merged over a select of the tuples)
+                        asm volatile("ds_write_b128 %0, %1 offset:%2 ; lower piece" ::"v"(ba), "a"(ZA[WP][j]), "n"(j * C::ZSLOTS * 256) : "memory");
+                } else {
+#pragma unroll
+                    for (int j = 0; j < NKZ; ++j) *reinterpret_cast<v4u *>(dst + j * C::ZSLOTS * 64) = Z[WP][j];
+                }
             } else {                           // the upper piece goes from its AGPR tuple to the ring as it is
                 const unsigned ba = (unsigned)(uintptr_t)dst;
 #pragma unroll
                 for (int j = 0; j < NKZ; ++j)
                     asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(ba), "a"(ZU[WP][j]), "n"(j * C::ZSLOTS * 256) : "memory");
             }
+            if constexpr (HLP) {               // the landing is in the LDS queue: tell the compute wave (HLP)
+                if (pub_b != -0x7fffffff) flag_set(IC<1>{}, pub_b);
+            }
             lslotS[WP] = lslotS[WP] >= 4 ? lslotS[WP] - 4 : lslotS[WP] + 8;   // + 8 mod 12
+        }
+        if constexpr (S64L && PART != 1) {
             const int phi = ((lcolS[WP] + 64) >> 3) & 1;
             lphi[WP] = phi;
             if ((FINC_S64_ABLATE & 4) == 0 && phi == 0) {   // a lower piece: ask for the whole sector (exec-masked: the other lanes' ZU is waiting to land)
@@ -495,7 +573,10 @@ __global__ __launch_bounds__(64 * NW * NPW) void finc_wave_kernel(const float *_
                 for (int j = 0; j < NKZ; ++j) {
                     const unsigned ol = j == NKZ - 1 ? vl + zlast : vl, ou = j == NKZ - 1 ? vu + zlast : vu;
                     const int so = __builtin_amdgcn_readfirstlane(j * 16 * HW);
-                    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(Z[WP][j]) : "v"(ol), "s"(rin), "s"(so) : "memory");
+                    if constexpr (ZA_AGPR)
+                        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=a"(ZA[WP][j]) : "v"(ol), "s"(rin), "s"(so) : "memory");
+                    else
+                        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(Z[WP][j]) : "v"(ol), "s"(rin), "s"(so) : "memory");
                     asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=a"(ZU[WP][j]) : "v"(ou), "s"(rin), "s"(so) : "memory");
                 }
             }
@@ -504,6 +585,8 @@ __global__ __launch_bounds__(64 * NW * NPW) void finc_wave_kernel(const float *_
             if (lcolS[WP] == W) { lcolS[WP] = 0; lrowS[WP] += P; loffS[WP] += rowstep - dirw * W * 4; }
         }
     };
+
+    auto s64_event = [&](auto wp_c, auto vm_c, int pub_b = -0x7fffffff) { s64_part(wp_c, vm_c, pub_b, IC<0>{}); };
 
     auto sec_event = [&](auto wp_c) {
         constexpr int WP = decltype(wp_c)::value;
@@ -522,7 +605,7 @@ __global__ __launch_bounds__(64 * NW * NPW) void finc_wave_kernel(const float *_
         loffS[WP] += 32 * dirw;
         if (lcolS[WP] == W) { lcolS[WP] = 0; lrowS[WP] += P; loffS[WP] += rowstep - dirw * W * 4; }
     };
-    auto sec_sread = [&](auto wp_c) {          // window of parity WP: class WP fires
+    auto sec_sread = [&](auto wp_c, int pub_b2 = -0x7fffffff) {   // window of parity WP: class WP fires
         constexpr int WP = decltype(wp_c)::value;
         if constexpr (!SEC) return;
         if (cls != WP && p < P) {              // (divergent) own row: first group of its next pair; partner: second group, due now
@@ -537,6 +620,12 @@ __global__ __launch_bounds__(64 * NW * NPW) void finc_wave_kernel(const float *_
                 XS[WP][j][1] = xp[xprt[1]];
                 XS[WP][j][2] = xp[xprt[2]];
                 XS[WP][j][3] = xp[xprt[3]];
+            }
+        }
+        if constexpr (HLP) {                   // the reads are in the LDS queue: once they are back, tell the compute wave
+            if (pub_b2 != -0x7fffffff) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                flag_set(IC<2>{}, pub_b2);
             }
         }
         const bool ok = scolS[WP] >= 0 && srowS[WP] < H && p < P;
@@ -575,7 +664,7 @@ __global__ __launch_bounds__(64 * NW * NPW) void finc_wave_kernel(const float *_
             v.w = __builtin_bit_cast(unsigned, XS[WP][j][3]);
             if constexpr (S64S) {              // the parked lower piece first: two instructions, one whole sector
                 const unsigned vo2 = st_off2 == OFF_INVALID ? OFF_INVALID : vo - st_off + st_off2;
-                if constexpr (PK_AGPR) {
+                if constexpr (PK_AGPR && (!HLP || WP == 0)) {
                     asm volatile("buffer_store_dwordx4 %0, %1, %2, %3 offen" ::"a"(PK[WP][j]), "v"(vo2), "s"(rout), "s"(uni) : "memory");
                 } else {
                     const float e0 = PK[WP][j].x, e1 = PK[WP][j].y, e2 = PK[WP][j].z, e3 = PK[WP][j].w;
@@ -596,7 +685,7 @@ __global__ __launch_bounds__(64 * NW * NPW) void finc_wave_kernel(const float *_
                 for (int j = 0; j < NKD; ++j) {
                     if (j < j0 || j >= j1) continue;
                     PK[WP][j] = (v4f){XS[WP][j][0], XS[WP][j][1], XS[WP][j][2], XS[WP][j][3]};
-                    if constexpr (PK_AGPR) asm volatile("" : "+a"(PK[WP][j]));
+                    if constexpr (PK_AGPR && (!HLP || WP == 0)) asm volatile("" : "+a"(PK[WP][j]));
                 }
             }
         }
@@ -815,10 +904,58 @@ __global__ __launch_bounds__(64 * NW * NPW) void finc_wave_kernel(const float *_
         }
     };
 
-    __syncthreads(); // single wave: orders the FIFO zero-fill before use
+    if constexpr (HLP) {                      // A = 0, B = -1, B2 = 0
+        if (!helper) { flag_set(IC<0>{}, 0); flag_set(IC<1>{}, -1); flag_set(IC<2>{}, 0); flag_set(IC<3>{}, 0); }
+    }
+    __syncthreads(); // single wave: orders the FIFO zero-fill before use (HLP: and the flags' initial values)
+
+    if constexpr (HLP) {
+        if (helper) {
+            // ===== the HBM side of one problem, in the order the single-wave kernel issues it =====
+#ifndef FINC_HLP_PRIO
+#define FINC_HLP_PRIO 0
+#endif
+            // (Priority: at equal priority the helper gets only the bubbles of its partner's MFMA stream -- ~60 cycles per VALU
+            // instruction, scripts/micro/mfma_helper.hip -- and its landing is late for two checks out of three; raised, it is
+            // late for one in seven, but every instruction it then issues first delays the MFMA wave and the kernel is 2 %
+            // SLOWER (profiles/r02/notes/ab18): the partner's slack is the pole wave's cover.  It stays at 0.)
+            if constexpr (FINC_HLP_PRIO != 0) __builtin_amdgcn_s_setprio(FINC_HLP_PRIO);
+            s64_init();
+            const int wlast = Tend >> 2;       // the window after the last computed one (even: Tend % 8 == 0)
+            s64_event(IC<0>{}, IC<0>{});       // window -4: the first pieces of the class-0 rows leave
+            s64_event(IC<1>{}, IC<0>{});       // window -3: class 1
+            s64_event(IC<0>{}, IC<0>{});       // window -2: the first pieces land, the second ones leave
+            sec_sread(IC<1>{});                // window -1
+            sec_swrite(IC<1>{}, 0, NKD);
+            s64_event(IC<1>{}, IC<0>{}, 0);    // its landing is what the compute wave's first z read waits for: B = 0
+            sec_sread(IC<0>{});                // window 0 (nothing has been written to the x ring yet: no wait)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            flag_set(IC<2>{}, 1);
+            sec_swrite(IC<0>{}, 0, NKD);
+            constexpr int VMS = 1 + 2 * NKD + 2 * NKZ + 2 * NKD;
+            for (int w = 1; w < wlast; w += 2) {
+                // odd window w: the event of window w-1 (parity 0) and window w's stores (parity 1).  What the compute wave
+                // waits for goes first -- the landing, then the x-ring reads; the requests and the stores have all the time
+                flag_wait(IC<3>{}, w);
+                s64_part(IC<0>{}, IC<VMS>{}, w, IC<1>{});
+                flag_wait(IC<0>{}, w);
+                sec_sread(IC<1>{}, w + 1);
+                s64_part(IC<0>{}, IC<VMS>{}, 0, IC<2>{});
+                sec_swrite(IC<1>{}, 0, NKD);
+                flag_wait(IC<3>{}, w + 1);     // even window w+1
+                s64_part(IC<1>{}, IC<VMS>{}, w + 1, IC<1>{});
+                flag_wait(IC<0>{}, w + 1);
+                sec_sread(IC<0>{}, w + 2);
+                s64_part(IC<1>{}, IC<VMS>{}, 0, IC<2>{});
+                sec_swrite(IC<0>{}, 0, NKD);
+            }
+            return;
+        }
+    }
 
     // pre-loop = the HBM side of the two windows before the first computed one
-    if constexpr (SEC) {
+    if constexpr (HLP) {
+    } else if constexpr (SEC) {
         sec_event(IC<0>{});  // window -4: the first pieces of the class-0 rows leave
         sec_event(IC<1>{});  // window -3: class 1
         sec_event(IC<0>{});  // window -2: the first pieces land, the second ones leave
@@ -842,6 +979,8 @@ __global__ __launch_bounds__(64 * NW * NPW) void finc_wave_kernel(const float *_
     int tp1 = -3;                             // t+1 (scalar).  Lane p has started its chain iff p <= t+1 ...
     int tm = -3;                              // ... and its NEXT position starts a row iff p == (t+1) mod W =: tm
     int xwin = 256 + lane;                    // x-ring write index of this window: 256*((t>>2)&1) + lane, t = -4
+    int win = 0;                              // HLP: index of the window being computed (main loop)
+    int peek_b = -1, peek_b2 = 0;             // HLP: flag values read ahead of their checks
 
     {
         // =========================== inverse ===========================
@@ -883,6 +1022,11 @@ __global__ __launch_bounds__(64 * NW * NPW) void finc_wave_kernel(const float *_
             float zraw[NKZ], zv[NKZ], xpk[NKD];
             float xown[NKD];                          // K-split: this wave's own share of the registers it finalises
             v4f accn[MT];
+            if constexpr (HLP && PH == 0) {            // the landing of the previous window must be in the ring (peeked in step 3)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (__builtin_expect(__builtin_amdgcn_readfirstlane(peek_b) < win, 0)) { FINC_COLD(); FINC_HLP_LATE(0); flag_wait(IC<1>{}, win); }
+            }
+            if constexpr (HLP && PH == 1) flag_peek(IC<2>{}, peek_b2);     // (for the check before this step's x-ring write)
 
             // ---- RA1: z of the next position is requested; operands that do not depend on this step age
 #pragma unroll
@@ -917,6 +1061,9 @@ __global__ __launch_bounds__(64 * NW * NPW) void finc_wave_kernel(const float *_
                 }
             }
             phase_a(ph_c, 0, NK / 2);
+            // HLP: this step's z read is in the LDS queue -- the last one before the slots of this window's landing are
+            // free -- so the helper may land (A1), a whole step before the next read
+            if constexpr (HLP && PH == 3) flag_set(IC<3>{}, win + 1);
             FINC_SB();
             // ---- RA2
 #pragma unroll
@@ -1058,9 +1205,19 @@ __global__ __launch_bounds__(64 * NW * NPW) void finc_wave_kernel(const float *_
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt)
                         mma(accn[mt], FT + ((a * KW + b - 1) * NK + j) * MT + mt, ROT ? Q[a][(PH + 9 - a - b) & 3][j] : R[a][b][j]);
-                if constexpr (CI == 0) post1();
-                if constexpr (CI == (NCH > 1 ? 1 : 0)) io_phase(ph_c, wp_c);
-                if constexpr (CI == (NCH > 2 ? 2 : NCH - 1)) post2();
+                if constexpr (CI == 0) {
+                    if constexpr (HLP && PH == 1) {    // the helper must have read what this write replaces (peeked in step 0)
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        if (__builtin_expect(__builtin_amdgcn_readfirstlane(peek_b2) < win + 1, 0)) { FINC_COLD(); FINC_HLP_LATE(1); flag_wait(IC<2>{}, win + 1); }
+                    }
+                    post1();
+                    if constexpr (HLP && PH == 3) flag_set(IC<0>{}, win + 1);    // window done as far as the helper cares
+                }
+                if constexpr (!HLP && CI == (NCH > 1 ? 1 : 0)) io_phase(ph_c, wp_c);
+                if constexpr (CI == (NCH > 2 ? 2 : NCH - 1)) {
+                    post2();
+                    if constexpr (HLP && PH == 3) flag_peek(IC<1>{}, peek_b);   // (for the check at the top of the next step)
+                }
                 FINC_SB();
                 if constexpr (CI < 6) FINC_STAMP_AT(2 + CI); // segments 2.. : phase-B chunks (0: post1, 1: HBM I/O, 2: post2)
             };
@@ -1081,14 +1238,15 @@ __global__ __launch_bounds__(64 * NW * NPW) void finc_wave_kernel(const float *_
             ++tm; if (tm == W) tm = 0;
             ++nslot; zrd += zstep[PH];
             if (nslot == 12) { nslot = 0; zrd -= 12 * 64; }
-            if constexpr (PH == 3) xwin ^= 256;
+            if constexpr (PH == 3) { xwin ^= 256; ++win; }
             fifo_advance();
             FINC_STAMP_AT(8);                           // segment 8: advance
         };
 
         // Window -4 (steps -4..-1) solves nothing: every lane is still before its first pixel.  Only its HBM side
         // and the z-term of lane 0's first pixel (phase B of step -1) matter, so it runs without the other 3.9 steps.
-        if constexpr (SEC) {                           // window -1 has parity 1
+        if constexpr (HLP) {
+        } else if constexpr (SEC) {                    // window -1 has parity 1
             sec_sread(IC<1>{});
             sec_swrite(IC<1>{}, 0, NKD);
             sec_event(IC<1>{});
@@ -1108,6 +1266,8 @@ __global__ __launch_bounds__(64 * NW * NPW) void finc_wave_kernel(const float *_
         }
         {                                              // step -1: acc = Linv * z of the position lanes with p == 0 start at
             const bool started = p <= tp1;             // tp1 == 0 here
+            flag_wait(IC<1>{}, 0);                     // (HLP) the first landings
+            peek_b = 0;
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) {
                 const float b0 = bias[mt].x, b1 = bias[mt].y, b2 = bias[mt].z, b3 = bias[mt].w;
@@ -1145,7 +1305,8 @@ __global__ __launch_bounds__(64 * NW * NPW) void finc_wave_kernel(const float *_
                 step(IC<3>{}, IC<1>{});
             }
         }
-        if constexpr (SEC) {                           // window Tend/4 (parity 0): the last pieces leave
+        if constexpr (HLP) {
+        } else if constexpr (SEC) {                    // window Tend/4 (parity 0): the last pieces leave
             sec_sread(IC<0>{});
             sec_swrite(IC<0>{}, 0, NKD);
         } else {
@@ -1240,6 +1401,7 @@ struct Inst {
     wave_fn fn;      // 16-byte-group I/O (any W % 4 == 0)
     wave_fn fn_sec;  // 32-byte-piece I/O (W % 8 == 0)
     wave_fn fn_s64;  // 64-byte sector pairing (W % 16 == 0); nullptr where the variant does not exist
+    wave_fn fn_hlp;  // sector pairing + helper waves: 8-wave workgroups of 4 problems (problem count % 4 == 0); or nullptr
     int nkz, nkd, nk, mt, nfrag, mtb;  // nkz/nkd/nfrag: per GROUP (packing); nk: per wave; mt = mtb tiles + 4-row blocks
     int nw, wnkz, wnkd;                // K-split: waves per problem, per-wave k-steps
     int npw;                           // problems packed into one workgroup (the launch needs B*G % npw == 0)
@@ -1266,9 +1428,18 @@ constexpr Inst make_inst()
 #endif
     constexpr int mode = !one ? 0 : (FINC_S64_MODE == 3 && pinned + 8 * C::NKZ + 8 * C::NKD <= 256) ? 3
                                   : (FINC_S64_MODE >= 1 && pinned + 8 * C::NKD <= 256) ? 1 : 0;
-    wave_fn f64 = nullptr;
+    wave_fn f64 = nullptr, fhl = nullptr;
     if constexpr (mode != 0) f64 = finc_wave_kernel<CQP, KH, KW, true, NW, NPW, mode>;
-    return Inst{CQP, KH, KW, finc_wave_kernel<CQP, KH, KW, false, NW, NPW>, finc_wave_kernel<CQP, KH, KW, true, NW, NPW>, f64,
+#ifndef FINC_HLP_MODE
+#define FINC_HLP_MODE 1
+#endif
+    // helper waves: both roles must fit hipcc's 128 : 128 split of a 256-register wave WITHOUT spilling (an in-flight load
+    // destination that is spilled is saved before its data has arrived): helper AGPRs = lower + upper pieces + one parked
+    // set, helper VGPRs = two store sets + the other parked set + bookkeeping, compute AGPRs = the pinned fragments
+    // (filters whose operands do not rotate in place -- 5x5 -- keep explicit ageing copies: too many VGPRs in the compute role)
+    constexpr bool hlp_fits = 16 * C::NKZ + 4 * C::NKD <= 124 && 12 * C::NKD + 48 <= 124 && pinned <= 124 && (KH - 1 + KW) < 6;
+    if constexpr (mode == 3 && FINC_HLP_MODE && hlp_fits) fhl = finc_wave_kernel<CQP, KH, KW, true, NW, NPW, 3, 1>;
+    return Inst{CQP, KH, KW, finc_wave_kernel<CQP, KH, KW, false, NW, NPW>, finc_wave_kernel<CQP, KH, KW, true, NW, NPW>, f64, fhl,
                 C::NKZT, C::NKDT, C::NK, C::MT, C::NFRAGT, C::MTB, NW, C::NKZ, C::NKD, NPW, MAXP};
 }
 
@@ -1298,6 +1469,13 @@ const Inst g_insts[] = {
 #endif
 
 size_t lds_bytes(const Inst &i, int W, int P);
+
+// FINC_NO_HLP=1 keeps the helper-wave variant off (A/B timing, tests of the single-wave sector-pairing path)
+bool finc_no_hlp()
+{
+    static const bool off = [] { const char *e = getenv("FINC_NO_HLP"); return e && e[0] == '1'; }();
+    return off;
+}
 
 // FINC_NO_S64=1 in the environment keeps W % 16 == 0 shapes on the 32-byte-piece kernel (A/B timing, tests of that path)
 bool finc_no_s64()
@@ -1342,6 +1520,12 @@ extern "C" int finc_debug_stamps(unsigned long long *host_out, int n)
 }
 #endif
 
+int finc_mfma_hlp_timeouts(unsigned *count)
+{
+    FINC_HIP_TRY(hipMemcpyFromSymbol(count, HIP_SYMBOL(finc_hlp_timeouts), sizeof(unsigned)));
+    return FINC_OK;
+}
+
 bool finc_mfma_supported(int Cq, int H, int W, int KH, int KW)
 {
     if (W % 4 != 0 || W < 4 || H < 1) return false;
@@ -1380,9 +1564,11 @@ int finc_mfma_variant(int B, int G, int Cq, int H, int W, int KH, int KW, int *i
     info[0] = i->cqp;
     info[1] = i->nw;
     info[2] = i->npw;
-    info[3] = (W % 16 == 0 && i->fn_s64 && !finc_no_s64()) ? 2 : W % 8 == 0 ? 1 : 0;
-    info[4] = (int)lds_bytes(*i, W, P);
-    info[5] = B * G / i->npw;
+    const bool s64 = W % 16 == 0 && i->fn_s64 && !finc_no_s64();
+    const bool hlp = s64 && i->fn_hlp && ((long long)B * G) % 4 == 0 && 4 * lds_bytes(*i, W, P) + 64 <= 160 * 1024 && !finc_no_hlp();
+    info[3] = hlp ? 3 : s64 ? 2 : W % 8 == 0 ? 1 : 0;
+    info[4] = hlp ? (int)(4 * lds_bytes(*i, W, P) + 64) : (int)lds_bytes(*i, W, P);
+    info[5] = hlp ? B * G / 4 : B * G / i->npw;
     info[6] = (int)(i - g_insts);
     info[7] = (int)(sizeof(g_insts) / sizeof(g_insts[0]));
     return FINC_OK;
@@ -1407,10 +1593,18 @@ int finc_mfma_launch(const float *in, const void *packed, float *out, const Finc
     const int NB = (s.H + P - 1) / P;
     const int Tend = s.W % 8 == 0 ? (NB * s.W + P - 1 + 7) / 8 * 8 : (NB * s.W + P - 1 + 3) / 4 * 4;  // 32-byte I/O: x8 loop
     const size_t lds = lds_bytes(*i, s.W, P);
-    const wave_fn fn = (s.W % 16 == 0 && i->fn_s64 && !finc_no_s64()) ? i->fn_s64 : (s.W % 8 == 0) ? i->fn_sec : i->fn;
-    if (int e = finc_ensure_dynamic_lds((const void *)fn, lds)) return e;
-    hipLaunchKernelGGL(fn, dim3(s.B * s.G / i->npw), dim3(64 * i->nw * i->npw), lds, st, in, (const float *)packed, out, s.G, s.Cq, s.H, s.W, P,
-                       Tend, s.orient);
+    const bool s64 = s.W % 16 == 0 && i->fn_s64 && !finc_no_s64();
+    // helper waves: 4 problems per 8-wave workgroup; their rings + 3 progress words each must fit one CU's LDS
+    const size_t lds_hlp = 4 * lds + 64;
+    const bool hlp = s64 && i->fn_hlp && ((long long)s.B * s.G) % 4 == 0 && lds_hlp <= 160 * 1024 && !finc_no_hlp();
+    const wave_fn fn = hlp ? i->fn_hlp : s64 ? i->fn_s64 : (s.W % 8 == 0) ? i->fn_sec : i->fn;
+    if (int e = finc_ensure_dynamic_lds((const void *)fn, hlp ? lds_hlp : lds)) return e;
+    if (hlp)
+        hipLaunchKernelGGL(fn, dim3(s.B * s.G / 4), dim3(512), lds_hlp, st, in, (const float *)packed, out, s.G, s.Cq, s.H, s.W, P,
+                           Tend, s.orient);
+    else
+        hipLaunchKernelGGL(fn, dim3(s.B * s.G / i->npw), dim3(64 * i->nw * i->npw), lds, st, in, (const float *)packed, out, s.G, s.Cq, s.H, s.W, P,
+                           Tend, s.orient);
     FINC_CHECK_LAUNCH();
     return FINC_OK;
 }

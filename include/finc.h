@@ -200,8 +200,9 @@ int finc_mix_f32(const float *in, const float *mat, const float *bias, float *ou
 /*
  * Introspection (tests, diagnostics; no reference counterpart).
  * finc_inverse_kernel_variant: which MFMA inverse kernel FINC_ALGO_AUTO / finc_inverse_packed_f32 launches for this
- *   problem.  info[8] = {Cq padded to 4, waves per problem (K-split), problems per workgroup, 2 = 64-byte sector
- *   pairing / 1 = 32-byte pieces / 0 = 16-byte groups, LDS bytes per workgroup, workgroups, row of the instantiation table, rows in the table}.
+ *   problem.  info[8] = {Cq padded to 4, waves per problem (K-split), problems per workgroup, 3 = sector pairing with
+ *   helper waves (8-wave workgroups of 4 problems) / 2 = 64-byte sector pairing / 1 = 32-byte pieces / 0 = 16-byte
+ *   groups, LDS bytes per workgroup, workgroups, row of the instantiation table, rows in the table}.
  *   FINC_ERR_UNSUPPORTED when the shape runs on the strict kernel.
  * finc_debug_attr_table_insert: the (device, kernel) table behind the once-per-device kernel attributes; returns 1 if
  *   the pair was new.  Host-only; exists so the key logic is testable without two GPUs.
@@ -212,6 +213,10 @@ int finc_mix_f32(const float *in, const float *mat, const float *bias, float *ou
 int finc_inverse_kernel_variant(int B, int G, int Cq, int H, int W, int KH, int KW, int *info);
 int finc_debug_inverse_table_row(int row, int *info);
 int finc_debug_attr_table_insert(int device, size_t kernel_token);
+/* SYNCHRONOUS.  The helper-wave form of the inverse (form 3 of finc_inverse_kernel_variant) pairs each compute wave with a
+ * wave that does its HBM traffic; the two meet through progress words in LDS, and every wait is bounded.  *h_count = waits
+ * that gave up since the library was loaded on the current device: anything but 0 is a bug. */
+int finc_debug_hlp_timeouts(unsigned *h_count);
 
 #ifdef __cplusplus
 }

@@ -93,12 +93,16 @@ def test_variant_plan_covers_every_row_and_agrees_with_the_library():
             one_wave = i["nw"] == 1 and i["npw"] == 1
             for sec, (H, W) in ((2 if one_wave else 1, (10, 32)), (1, (19, 24)), (0, (9, 20))):
                 v = _lib.inverse_variant(B, G, i["cqp"], H, W, i["kh"], i["kw"])
+                if sec == 2 and v is not None and v["sec"] == 3:      # sector pairing with helper waves: problems in fours, banks that fit
+                    assert n % 4 == 0 and i["cqp"] <= 24
+                    v = dict(v, sec=2)
                 assert v is not None and v["row"] == r and v["sec"] == sec and v["nw"] == i["nw"] and v["npw"] == i["npw"], (r, n, v)
-                assert v["workgroups"] * v["npw"] == B * G and v["lds_bytes"] <= 160 * 1024
+                per_wg = B * G // v["workgroups"]                      # helper-wave form: 4 problems per 8-wave workgroup
+                assert per_wg in (v["npw"], 4) and v["workgroups"] * per_wg == B * G and v["lds_bytes"] <= 160 * 1024
                 hit.add((r, sec))
     assert len(hit) == 2 * len(rows) + sum(1 for i in rows if i["nw"] == 1 and i["npw"] == 1)
     # the bench shapes: c3 at full batch is the one-wave kernel, at B <= 128 the packed 2-wave split; c5 is the 4-wave split
-    assert _lib.inverse_variant(256, 4, 24, 64, 64, 3, 3)["nw"] == 1
+    assert _lib.inverse_variant(256, 4, 24, 64, 64, 3, 3)["nw"] == 1 and _lib.inverse_variant(256, 4, 24, 64, 64, 3, 3)["sec"] == 3
     assert (_lib.inverse_variant(128, 4, 24, 64, 64, 3, 3)["nw"], _lib.inverse_variant(128, 4, 24, 64, 64, 3, 3)["npw"]) == (2, 2)
     assert _lib.inverse_variant(64, 4, 48, 128, 128, 5, 5)["nw"] == 4
     assert _lib.inverse_variant(2, 4, 24, 16, 15, 3, 3) is None          # W % 4 != 0: strict kernel
