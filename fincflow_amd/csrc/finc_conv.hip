@@ -78,6 +78,17 @@ __global__ __launch_bounds__(64 * NW)
     constexpr int NFRAG = NTAP * NKZ * MT;                // fragments this wave holds
     constexpr int DREG = (4 * (CQP / 16) + (CQP % 16) / 4) / NW; // output registers this wave finalises and stores
     __shared__ float xch[NW > 1 ? 2 * NW * NW * DREG * 64 : 1]; // [parity][dst wave][src wave][reg][lane]
+    // Output staging (one wave per strip, W % 16 == 0).  Straight from the accumulators a store instruction covers 4 channel
+    // rows x 64 bytes, and six of those per step cost the MFMA wave 47 us of the 400 us c3 forward (timing-only builds,
+    // profiles/r02/notes/ab21).  Through LDS the row leaves as [channel][16 pixels]: a lane writes its values with
+    // ds_write_b32 (cheap beside MFMAs), reads back 16 bytes of one channel, and ceil(Cq/16) buffer_store_dwordx4 -- 16
+    // whole 64-byte sectors each -- go out after the step's MFMAs, when the read-back has long arrived.
+    constexpr int OPITCH = 20;                            // floats per channel row in the staging buffer (16 + pad: bank spread)
+    constexpr int NOI = (CQP + 15) / 16;                  // 16-channel store instructions per row
+    __shared__ __attribute__((aligned(16))) float ostg[NW == 1 ? NOI * 16 * OPITCH : 4];
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    v4u ostv[NOI];                                        // the row read back, waiting for the end of the step
+    unsigned ost_row = OFF_INVALID;                       // its (scalar) row offset
     const int wv = NW > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
     const int lane = threadIdx.x & 63;
     const int q = lane >> 4, p = lane & 15;
@@ -204,6 +215,12 @@ __global__ __launch_bounds__(64 * NW)
             lout[d] = (colok && c < CQ) ? coloff + (unsigned)c * HW * 4u : OFF_BAD_CHANNEL;
         }
     }
+    // staged stores: lane (c16, k) = channel 16i + c16, 16-byte piece k of the strip's sector (memory order)
+    const bool wide = NW == 1 && (W & 15) == 0;
+    const int oc16 = lane >> 2;
+    const unsigned ost_col = (unsigned)((fw ? W - 16 - strip * 16 : strip * 16) + 4 * (lane & 3)) * 4u;
+    const unsigned ost_lane = ost_col + (unsigned)oc16 * HW * 4u;
+    const unsigned ost_lane_last = (16 * (NOI - 1) + oc16 < CQ) ? ost_lane : OFF_BAD_CHANNEL;   // only the last instruction can hold padded channels
     auto rowoff = [&](int h) {                            // scalar
         return (h >= 0 && h < H) ? (unsigned)((fh ? H - 1 - h : h) * W) * 4u : OFF_INVALID;
     };
@@ -223,7 +240,15 @@ __global__ __launch_bounds__(64 * NW)
 #pragma unroll
             for (int j = 0; j < NKZ; ++j) X[s][b][j] = 0.f;
     float nxt[NKZ], nxh[NKZ];                             // the row loaded one step ahead (+ its halo)
+#ifndef FINC_CONV_ABLATE   // timing-only experiment bits (results wrong): 1 = no loads, 2 = no stores
+#define FINC_CONV_ABLATE 0
+#endif
     auto issue = [&](int h) {
+        if constexpr (FINC_CONV_ABLATE & 1) {
+#pragma unroll
+            for (int j = 0; j < NKZ; ++j) { nxt[j] = (float)(h + j) * 1e-3f; nxh[j] = nxt[j]; }
+            return;
+        }
         const unsigned ro = rowoff(h);
         const unsigned v0 = ro + lin0, v1 = ro + lin1, h0 = ro + lhal0, h1 = ro + lhal1;
 #pragma unroll
@@ -245,8 +270,29 @@ __global__ __launch_bounds__(64 * NW)
 
     int parity = 0;
     auto store_row = [&](const v4f (&ac)[MT], int h) {   // h = the row those accumulators belong to
+        if constexpr (FINC_CONV_ABLATE & 2) {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) asm volatile("" ::"v"(ac[mt]));
+            return;
+        }
         const unsigned ro = rowoff_st(h);
         if constexpr (NW == 1) {
+            if (wide) {                                   // (uniform) staged: LDS now, HBM at the end of the step
+                const int pp = fw ? 15 - p : p;           // memory order inside the strip's sector
+#pragma unroll
+                for (int mt = 0; mt < MTB; ++mt) {
+                    const float v[4] = {ac[mt].x, ac[mt].y, ac[mt].z, ac[mt].w};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ostg[(16 * mt + 4 * q + r) * OPITCH + pp] = v[r];
+                }
+#pragma unroll
+                for (int sb = 0; sb < NSM; ++sb) ostg[(16 * MTB + 4 * sb + q) * OPITCH + pp] = finc_block_reduce(ac[MTB + sb]);
+#pragma unroll
+                for (int i = 0; i < NOI; ++i)
+                    ostv[i] = *reinterpret_cast<const v4u *>(&ostg[(16 * i + (lane >> 2)) * OPITCH + 4 * (lane & 3)]);
+                ost_row = ro;
+                return;
+            }
             const unsigned vb = ro + lo_base;
 #pragma unroll
             for (int mt = 0; mt < MTB; ++mt) {
@@ -339,6 +385,13 @@ __global__ __launch_bounds__(64 * NW)
                         mma(ac[mt], ((a * KW + b) * NKZ + j) * MT + mt, X[(S + KH - a) % KH][b][j]);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[S][mt] = ac[mt];
+        if constexpr (NW == 1) {
+            if (wide) {                                   // the previous row leaves: ceil(Cq/16) x 16 whole sectors
+#pragma unroll
+                for (int i = 0; i < NOI; ++i)
+                    __builtin_amdgcn_raw_buffer_store_b128(ostv[i], rout, ost_row + (i == NOI - 1 ? ost_lane_last : ost_lane), 16 * i * HW * 4, 0);
+            }
+        }
     };
 
     int hs = r0 - (KH - 1);
