@@ -332,6 +332,18 @@ def bench_stub(args):
 # ----------------------------------------------------------------------------------------------------------------
 # the hot path
 # ----------------------------------------------------------------------------------------------------------------
+def inverse_kernel_name(B, Cq, H, W, K):
+    """The inverse kernel this process launches for the workload, as the library itself reports it (not a constant)."""
+    from fincflow_amd import _lib
+    v = _lib.inverse_variant(B, 4, Cq, H, W, K, K)
+    if v is None:
+        return "inverse_strict_kernel<float> (inverse, scalar)"
+    io = {0: "32-byte I/O", 1: "32-byte I/O, lane pairs", 2: "64-byte sector pairing",
+          3: "64-byte sector pairing, helper waves do the I/O (512-thread workgroups of 4 problems)"}.get(v["sec"], str(v["sec"]))
+    return (f"finc_wave_kernel<CQP={v['cqp']},{K},{K},NW={v['nw']},NPW={v['npw']}> (inverse; {io}; "
+            f"{v['workgroups']} workgroups, {v['lds_bytes']} B LDS)")
+
+
 def bench_unit(args):
     h = Harness(args, stub=False)
     torch = h.torch
@@ -420,7 +432,7 @@ def bench_unit(args):
                         "note": f"fp32-compute-bound shape: at 100 % of the fp32 peak this call reaches {hbm_ceiling:.0%} of "
                                 f"HBM peak" + ("; the north_star's 40 % of HBM on the forward is unreachable at fp32 here"
                                                if hbm_ceiling < 0.4 else "")},
-            "roofline": {"kernel": f"finc_wave_kernel<{(Cq + 3) // 4 * 4},{K},{K},SEC> (inverse)", "bound": "hbm", "achieved": inv_gbs,
+            "roofline": {"kernel": inverse_kernel_name(B, Cq, H, W, K), "bound": "hbm", "achieved": inv_gbs,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": inv_gbs / HBM_PEAK_GBS,
                          "traffic": (traffic or {}).get("inverse_hbm_bytes_per_launch"),
                          "traffic_source": (traffic or {}).get("source"),

@@ -112,3 +112,41 @@ def test_full_config4_model_samples_and_reconstructs():
         torch.manual_seed(5)
         a, a_true = model.sample(16, also_true_inverse=True)
         assert a_true is not a and rel_err(a.cpu().numpy(), a_true.cpu().numpy()) <= 1e-4
+
+
+@pytest.mark.gpu
+def test_config4_exactly_as_benched():
+    """The topology `bench.py --workload c4` times, unchanged: create_model(num_blocks=3, block_size=32, actnorm=True,
+    split_prior=True), default preprocess and coupling width, 128 samples.  A split prior draws fresh noise at every
+    level, so there is no reconstruct identity here; what is checked is the sample contract, that the fused chain
+    (ActNorm folded into the inverses' loads/stores) and the layer-by-layer chain produce the same images from the same
+    noise, that every FastFlowUnit in the stack inverts its own forward at the shape it sees, and a density pass."""
+    from fincflow_amd import FastFlowUnit, glow
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    np.random.seed(0)
+    model = glow.create_model(num_blocks=3, block_size=32, actnorm=True, split_prior=True).to(dev).eval()
+    units = [m for m in model if isinstance(m, FastFlowUnit)]
+    assert len(units) == 96
+    with torch.no_grad():
+        for m in model:
+            if isinstance(m, glow.ActNorm):
+                m.initialized.fill_(1)             # as bench.py does: sampling never runs the data-dependent init
+        s, s_true = model.sample(128)
+        assert s_true is s and s.shape == (128, 3, 32, 32) and torch.isfinite(s).all()
+        torch.manual_seed(11)
+        a, a_true = model.sample(128, also_true_inverse=True)
+        assert a_true is not a and torch.isfinite(a_true).all()
+        assert rel_err(a.cpu().numpy(), a_true.cpu().numpy()) <= 1e-4
+        shapes = {}
+        for u in units:                            # one unit per distinct shape: 12x16x16, 24x8x8, 48x4x4
+            shapes.setdefault(u.conv_tl.conv.weight.shape[0] * 4, u)
+        assert sorted(shapes) == [12, 24, 48]
+        for C, u in shapes.items():
+            hw = {12: 16, 24: 8, 48: 4}[C]
+            x = torch.randn(128, C, hw, hw, device=dev)
+            z, _ = u(x)
+            xr = u.reverse(z)
+            assert rel_err(xr.cpu().numpy(), x.cpu().numpy()) <= 1e-5
+        z, logp = model(torch.rand(16, 3, 32, 32, device=dev))
+        assert torch.isfinite(logp).all() and logp.shape == (16,)
