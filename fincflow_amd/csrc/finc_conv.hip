@@ -64,7 +64,7 @@ constexpr int conv_nreg()
 // Two waves per SIMD (256 registers each) is what hides one wave's loads, stores and VALU behind the other's MFMAs:
 // single-wave workgroups ask for that register budget when the bank leaves room for the working set (a 252-fragment
 // bank squeezed into 256 registers spills: 10x slower); the K-split variants keep theirs (their waves are many).
-template <int CQP, int KH, int KW, int NW>
+template <int CQP, int KH, int KW, int NW, bool WIDE>
 __global__ __launch_bounds__(64 * NW)
     __attribute__((amdgpu_waves_per_eu(NW == 1 && conv_nreg<CQP, KH, KW, NW>() <= 128 ? 2 : 1))) void finc_conv_kernel(const float *__restrict__ in,
                                                             const float *__restrict__ packed, float *__restrict__ out,
@@ -85,10 +85,18 @@ __global__ __launch_bounds__(64 * NW)
     // whole 64-byte sectors each -- go out after the step's MFMAs, when the read-back has long arrived.
     constexpr int OPITCH = 20;                            // floats per channel row in the staging buffer (16 + pad: bank spread)
     constexpr int NOI = (CQP + 15) / 16;                  // 16-channel store instructions per row
-    __shared__ __attribute__((aligned(16))) float ostg[NW == 1 ? NOI * 16 * OPITCH : 4];
+    __shared__ __attribute__((aligned(16))) float ostg[WIDE ? NOI * 16 * OPITCH : 4];
+    // Input staging (WIDE): the row arrives as whole 16-byte pieces -- lane = (channel, piece), ceil(5*Cq/64) dwordx4 loads
+    // instead of 2*Cq/4 dword loads -- and is turned into MFMA B operands by ds_read_b32: [channel][4 halo + 16 columns]
+    // in MEMORY order, so a column shift is a read address (no DPP) and the columns left of the strip are the last piece
+    // of the neighbouring sector, one more lane group of the same loads (no halo loads).
+    constexpr int IPITCH = 24;                            // floats per channel row: two 16-wide windows 24 apart never share a bank
+    constexpr int NII = (5 * CQP + 63) / 64;              // dwordx4 load instructions per row
+    __shared__ __attribute__((aligned(16))) float istg[WIDE ? CQP * IPITCH + 4 : 4];
     typedef unsigned v4u __attribute__((ext_vector_type(4)));
     v4u ostv[NOI];                                        // the row read back, waiting for the end of the step
     unsigned ost_row = OFF_INVALID;                       // its (scalar) row offset
+    bool ost_ok = false;                                  // WIDE: whether that row exists in this chunk (else its stores are dropped)
     const int wv = NW > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
     const int lane = threadIdx.x & 63;
     const int q = lane >> 4, p = lane & 15;
@@ -183,6 +191,139 @@ __global__ __launch_bounds__(64 * NW)
         }
     };
 
+    if constexpr (WIDE) {
+        // ------------------------------------------------------------------------------------------------------------
+        // W % 16 == 0, one wave per strip.  What the MFMA pipe of a SIMD loses to this kernel is, above all, its VMEM
+        // instructions -- ~25 cycles each whatever their width (scripts/micro/fwd_path.hip: the dword scheme below costs
+        // 3,380 cycles per row step on a saturated SIMD, this one 3,000, the MFMAs alone 2,290) -- so the row moves in as
+        // few as possible: ceil(5 Cq / 64) dwordx4 loads and ceil(Cq / 16) dwordx4 stores, both transposed through LDS.
+        // Pipeline of step h (everything ahead of the MFMAs, nothing waits in front of them):
+        //   stores of row h-2 | row h+1 (registers) -> input tile | loads of row h+2 | operand reads of row h+1 (land
+        //   during this step's MFMAs) | result of row h-1 -> output tile -> registers | MFMAs of row h.
+        // ------------------------------------------------------------------------------------------------------------
+        static_assert(NW == 1 && KW <= 5, "one wave per strip; the halo is one 16-byte piece");
+        constexpr int U = KH + 1;                         // row slots: slot (S+1)%U fills while slots S..S-KH+1 are read
+        const float *const in_slab = in + (size_t)bg * CQ * HW;
+        float *const out_slab = out + (size_t)bg * CQ * HW;
+        // a row's buffer resource: the slab, or EMPTY when the row does not exist (loads give 0, stores are dropped);
+        // row validity is wave-uniform: one scalar select, and the row's byte offset rides in the scalar offset
+        auto rsrc_in = [&](bool ok) { return __builtin_amdgcn_make_buffer_rsrc((void *)in_slab, 0, ok ? (int)slab_bytes : 0, 0x00020000); };
+        auto rsrc_out = [&](bool ok) { return __builtin_amdgcn_make_buffer_rsrc((void *)out_slab, 0, ok ? (int)slab_bytes : 0, 0x00020000); };
+        auto rowbytes = [&](int h) { return (unsigned)((fh ? H - 1 - h : h) * W) * 4u; };
+        const int r0 = blockIdx.y * RC, r1 = r0 + RC < H ? r0 + RC : H;
+        const int ms = fw ? W - 16 - strip * 16 : strip * 16;       // memory column where the strip's sector starts
+        const int hm = fw ? ms + 16 : ms - 4;                       // ... and the piece holding the KW-1 columns left of it
+        unsigned lvo[NII];                                          // load slot 64i+lane: byte offset in the slab
+        int lwr[NII];                                               // ... and where its 16 bytes go in the tile (floats)
+#pragma unroll
+        for (int i = 0; i < NII; ++i) {
+            const int t = 64 * i + lane;
+            lvo[i] = OFF_BAD_CHANNEL;
+            lwr[i] = CQP * IPITCH;                                  // scratch piece behind the tile
+            if (t < 4 * CQP) {
+                const int c = t >> 2, k = t & 3;
+                if (c < CQ) lvo[i] = (unsigned)c * HW * 4u + (unsigned)(ms + 4 * k) * 4u;
+                lwr[i] = c * IPITCH + (fw ? 0 : 4) + 4 * k;
+            } else if (t < 5 * CQP) {
+                const int c = t - 4 * CQP;
+                if (c < CQ && hm >= 0 && hm < W) lvo[i] = (unsigned)c * HW * 4u + (unsigned)hm * 4u;
+                lwr[i] = c * IPITCH + (fw ? 16 : 0);
+            }
+        }
+        int ird[KW];                                                // lane (q,p), shift b: canonical column p-b of channel q
+#pragma unroll
+        for (int b = 0; b < KW; ++b) ird[b] = q * IPITCH + (fw ? 15 - (p - b) : 4 + (p - b));
+        const int pp = fw ? 15 - p : p;                             // memory order inside the strip's sector
+        const unsigned ost_col = (unsigned)(ms + 4 * (lane & 3)) * 4u;
+        const unsigned ost_lane = ost_col + (unsigned)(lane >> 2) * HW * 4u;
+        const unsigned ost_lane_last = (16 * (NOI - 1) + (lane >> 2) < CQ) ? ost_lane : OFF_BAD_CHANNEL;
+        v4u L[NII];
+#pragma unroll
+        for (int i = 0; i < NII; ++i) L[i] = (v4u){0u, 0u, 0u, 0u};
+        float X[U][KW][NKZ];
+#pragma unroll
+        for (int sl = 0; sl < U; ++sl)
+#pragma unroll
+            for (int b = 0; b < KW; ++b)
+#pragma unroll
+                for (int j = 0; j < NKZ; ++j) X[sl][b][j] = 0.f;
+        v4f prev[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) prev[mt] = (v4f){0.f, 0.f, 0.f, 0.f};
+        auto issue = [&](int h) {
+            const bool ok = h >= 0 && h < H;
+            const __amdgpu_buffer_rsrc_t r = rsrc_in(ok);
+            const unsigned ro = ok ? rowbytes(h) : 0u;
+#pragma unroll
+            for (int i = 0; i < NII; ++i) L[i] = __builtin_amdgcn_raw_buffer_load_b128(r, lvo[i], ro, 0);
+        };
+        auto flush_staged = [&]() {
+            const __amdgpu_buffer_rsrc_t r = rsrc_out(ost_ok);
+#pragma unroll
+            for (int i = 0; i < NOI; ++i)
+                __builtin_amdgcn_raw_buffer_store_b128(ostv[i], r, i == NOI - 1 ? ost_lane_last : ost_lane,
+                                                       (unsigned)(16 * i) * HW * 4u + ost_row, 0);
+            ost_ok = false;
+        };
+        auto step = [&](auto s_c, int h) {
+            constexpr int S = decltype(s_c)::value, SN = (S + 1) % U;
+            flush_staged();
+#pragma unroll
+            for (int i = 0; i < NII; ++i) *reinterpret_cast<v4u *>(&istg[lwr[i]]) = L[i];
+            issue(h + 2);
+#pragma unroll
+            for (int b = 0; b < KW; ++b)
+#pragma unroll
+                for (int j = 0; j < NKZ; ++j) X[SN][b][j] = istg[ird[b] + 4 * j * IPITCH];
+            {                                                       // the result of row h-1: accumulators -> [channel][16] -> pieces
+#pragma unroll
+                for (int mt = 0; mt < MTB; ++mt) {
+                    const float v[4] = {prev[mt].x, prev[mt].y, prev[mt].z, prev[mt].w};
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) ostg[(16 * mt + 4 * q + r) * OPITCH + pp] = v[r];
+                }
+#pragma unroll
+                for (int sb = 0; sb < NSM; ++sb) ostg[(16 * MTB + 4 * sb + q) * OPITCH + pp] = finc_block_reduce(prev[MTB + sb]);
+#pragma unroll
+                for (int i = 0; i < NOI; ++i)
+                    ostv[i] = *reinterpret_cast<const v4u *>(&ostg[(16 * i + (lane >> 2)) * OPITCH + 4 * (lane & 3)]);
+                const int hp = h - 1;
+                ost_ok = hp >= r0 && hp < r1;
+                ost_row = ost_ok ? rowbytes(hp) : 0u;
+            }
+            __builtin_amdgcn_sched_barrier(0);                      // all of the above stays ahead of the MFMAs ...
+            // rows outside [r0, r1) are walked only to fill the operand slots (and to drain the pipeline): no MFMAs for them
+            if (h >= r0 && h < r1) {
+                v4f ac[MT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) ac[mt] = bias[mt];
+#pragma unroll
+                for (int a = KH - 1; a >= 0; --a)
+#pragma unroll
+                    for (int b = 0; b < KW; ++b)
+#pragma unroll
+                        for (int j = 0; j < NKZ; ++j)
+#pragma unroll
+                            for (int mt = 0; mt < MT; ++mt)
+                                mma(ac[mt], ((a * KW + b) * NKZ + j) * MT + mt, X[(S + U - a) % U][b][j]);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) prev[mt] = ac[mt];
+            }
+            __builtin_amdgcn_sched_barrier(0);                      // ... and the next step's memory work behind them
+        };
+        // Row hs itself is never loaded (its operands are the zeros above): it must not reach a stored row, so the walk
+        // starts KH rows early; the rows before r0 only fill the slots (a slot is a position in the unrolled group, so any
+        // start row will do).
+        const int hs = r0 - KH;
+        issue(hs + 1);
+        for (int h0 = hs; h0 < r1 + 1; h0 += U) {
+            [&]<int... I>(std::integer_sequence<int, I...>) { (step(IC<I>{}, h0 + I), ...); }
+            (std::make_integer_sequence<int, U>{});
+        }
+        flush_staged();                                             // the last row, if no step followed it
+        return;
+    }
+
     // Addressing is branch-free and select-free: a buffer offset = (row part, scalar) + (lane part, constant).
     // An off-image row contributes OFF_INVALID (2^31), an off-image column or padded channel OFF_BAD_CHANNEL
     // (2^30); any such sum lands beyond the slab (< 2^30 bytes), where loads return 0 and stores are dropped.
@@ -216,7 +357,7 @@ __global__ __launch_bounds__(64 * NW)
         }
     }
     // staged stores: lane (c16, k) = channel 16i + c16, 16-byte piece k of the strip's sector (memory order)
-    const bool wide = NW == 1 && (W & 15) == 0;
+    constexpr bool wide = false;                          // the staged form is the WIDE pipeline above
     const int oc16 = lane >> 2;
     const unsigned ost_col = (unsigned)((fw ? W - 16 - strip * 16 : strip * 16) + 4 * (lane & 3)) * 4u;
     const unsigned ost_lane = ost_col + (unsigned)oc16 * HW * 4u;
@@ -277,7 +418,7 @@ __global__ __launch_bounds__(64 * NW)
         }
         const unsigned ro = rowoff_st(h);
         if constexpr (NW == 1) {
-            if (wide) {                                   // (uniform) staged: LDS now, HBM at the end of the step
+            if constexpr (wide) {                         // (kept for reference: the first staged form, stores only)
                 const int pp = fw ? 15 - p : p;           // memory order inside the strip's sector
 #pragma unroll
                 for (int mt = 0; mt < MTB; ++mt) {
@@ -370,23 +511,26 @@ __global__ __launch_bounds__(64 * NW)
         issue(h + 1);                                     // next row: a whole step of MFMAs to arrive
         // the previous row's result leaves while this row's MFMAs run
         store_row(acc[(S + KH - 1) % KH], h - 1);
-        v4f ac[MT];
+        // rows outside [r0, r1) are walked only to fill the operand slots: no MFMAs for them (their results are never stored)
+        if (h >= r0 && h < r1) {
+            v4f ac[MT];
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) ac[mt] = bias[mt];
-        // rows h-a live in slot (S - a) mod KH; older rows first (their operands are long ready)
+            for (int mt = 0; mt < MT; ++mt) ac[mt] = bias[mt];
+            // rows h-a live in slot (S - a) mod KH; older rows first (their operands are long ready)
 #pragma unroll
-        for (int a = KH - 1; a >= 0; --a)
+            for (int a = KH - 1; a >= 0; --a)
 #pragma unroll
-            for (int b = 0; b < KW; ++b)
+                for (int b = 0; b < KW; ++b)
 #pragma unroll
-                for (int j = 0; j < NKZ; ++j)
+                    for (int j = 0; j < NKZ; ++j)
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-                        mma(ac[mt], ((a * KW + b) * NKZ + j) * MT + mt, X[(S + KH - a) % KH][b][j]);
+                        for (int mt = 0; mt < MT; ++mt)
+                            mma(ac[mt], ((a * KW + b) * NKZ + j) * MT + mt, X[(S + KH - a) % KH][b][j]);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[S][mt] = ac[mt];
+            for (int mt = 0; mt < MT; ++mt) acc[S][mt] = ac[mt];
+        }
         if constexpr (NW == 1) {
-            if (wide) {                                   // the previous row leaves: ceil(Cq/16) x 16 whole sectors
+            if constexpr (wide) {                         // the previous row leaves: ceil(Cq/16) x 16 whole sectors
 #pragma unroll
                 for (int i = 0; i < NOI; ++i)
                     __builtin_amdgcn_raw_buffer_store_b128(ostv[i], rout, ost_row + (i == NOI - 1 ? ost_lane_last : ost_lane), 16 * i * HW * 4, 0);
@@ -584,20 +728,31 @@ typedef void (*gradw_fn)(const float *, const float *, float *, int, int, int, i
 struct ConvInst {
     int cqp, kh, kw;
     conv_fn fn;
+    conv_fn fn_wide;             // W % 16 == 0, one wave per strip: rows move as 16-byte pieces through LDS (nullptr: none)
     int mt, mtb, nkz, nfrag, nw; // mt = mtb 16-row tiles + 4-row blocks: fragments per (tap, k-step)
     int mtg;                     // grad-weight kernel: ceil(Cq/16) tiles in both dimensions
     gradw_fn gw; // MFMA grad-weight kernel (nullptr: NTAP*MT*MT accumulators would not fit)
 };
+template <int CQP, int KH, int KW, int NW>
+constexpr conv_fn wide_fn()
+{
+    // the staged form holds KH+1 row slots of operands and its pieces in flight: only where that fits beside the bank
+    // (<28,3,3> and <16,5,5> would spill inside the 256 registers of two waves per SIMD)
+    constexpr int NREG = conv_nreg<CQP, KH, KW, NW>();
+    if constexpr (NW == 1 && KW <= 5 && NREG + (KH + 1) * KW * (CQP / 4) + 64 <= (NREG <= 128 ? 256 : 512))
+        return finc_conv_kernel<CQP, KH, KW, NW, true>;
+    else return nullptr;
+}
 template <int CQP, int KH, int KW, int NW = 1>
 constexpr ConvInst make_conv()
 {
     constexpr int MTG = (CQP + 15) / 16, MTB = CQP / 16, MT = MTB + (CQP % 16) / 4;
     if constexpr (KH * KW * MTG * MTG * 4 <= 200)
-        return ConvInst{CQP, KH, KW, finc_conv_kernel<CQP, KH, KW, NW>, MT, MTB, CQP / 4, KH * KW * (CQP / 4) * MT, NW, MTG,
-                        finc_gradw_kernel<CQP, KH, KW>};
+        return ConvInst{CQP, KH, KW, finc_conv_kernel<CQP, KH, KW, NW, false>, wide_fn<CQP, KH, KW, NW>(), MT, MTB, CQP / 4,
+                        KH * KW * (CQP / 4) * MT, NW, MTG, finc_gradw_kernel<CQP, KH, KW>};
     else
-        return ConvInst{CQP, KH, KW, finc_conv_kernel<CQP, KH, KW, NW>, MT, MTB, CQP / 4, KH * KW * (CQP / 4) * MT, NW, MTG,
-                        nullptr};
+        return ConvInst{CQP, KH, KW, finc_conv_kernel<CQP, KH, KW, NW, false>, wide_fn<CQP, KH, KW, NW>(), MT, MTB, CQP / 4,
+                        KH * KW * (CQP / 4) * MT, NW, MTG, nullptr};
 }
 const ConvInst g_conv[] = {
     make_conv<4, 3, 3>(),  make_conv<8, 3, 3>(),  make_conv<12, 3, 3>(), make_conv<16, 3, 3>(), make_conv<20, 3, 3>(),
@@ -685,7 +840,9 @@ int finc_conv_launch(const float *in, const void *packed, float *out, const Finc
     if (nrc > s.H / 4) nrc = s.H / 4 > 0 ? s.H / 4 : 1;
     const int RC = (s.H + nrc - 1) / nrc;
     nrc = (s.H + RC - 1) / RC;
-    hipLaunchKernelGGL(i->fn, dim3(s.B * s.G * NS, nrc), dim3(64 * i->nw), 0, st, in, (const float *)packed, out, s.G, s.Cq,
+    static const bool no_wide = getenv("FINC_CONV_NO_WIDE") != nullptr;   // experiment switch: the dword form everywhere
+    const conv_fn fn = (i->fn_wide && s.W % 16 == 0 && !no_wide) ? i->fn_wide : i->fn;
+    hipLaunchKernelGGL(fn, dim3(s.B * s.G * NS, nrc), dim3(64 * i->nw), 0, st, in, (const float *)packed, out, s.G, s.Cq,
                        s.H, s.W, NS, RC, s.orient);
     FINC_CHECK_LAUNCH();
     return FINC_OK;

@@ -165,6 +165,50 @@ def test_bounded_fuzz_sweep(seed, dev):
     assert worst < 1e-3
 
 
+# ------------------------------------------------------------------ forward: the staged (16-byte piece) form
+STAGED_FORWARD_SHAPES = [
+    # (B, G, Cq, H, W, K, orient)   W % 16 == 0 -> rows move as dwordx4 pieces through LDS
+    (2, 4, 24, 9, 16, 3, None),     # one strip: no neighbour on either side (halo piece invalid for both flips)
+    (2, 4, 24, 7, 64, 3, None),     # c3's width, all four flips in one call
+    (1, 4, 12, 32, 32, 3, None),    # c2: few strips -> the host cuts the walk into row chunks (r0 > 0)
+    (3, 1, 23, 5, 48, 3, 0), (3, 1, 23, 5, 48, 3, 1), (3, 1, 23, 5, 48, 3, 2), (3, 1, 23, 5, 48, 3, 3),  # padded channels, each flip
+    (2, 4, 3, 16, 16, 3, None), (2, 4, 6, 8, 32, 3, None), (1, 4, 20, 6, 32, 3, None),
+    (1, 4, 32, 6, 32, 3, None),     # 144 fragments: one wave per SIMD, three load instructions per row
+    (2, 4, 13, 6, 32, 2, None), (2, 1, 24, 5, 16, 2, 3),
+    (1, 4, 12, 9, 32, 5, None), (2, 1, 8, 7, 48, 5, 1), (1, 1, 4, 6, 16, 5, 2),   # 5x5: the halo is the whole piece
+    (1, 4, 28, 6, 32, 3, None), (1, 4, 16, 6, 32, 5, None),   # banks the staged form has no room for: the dword form, same answers
+    (1, 1, 4, 1, 16, 3, 0), (1, 1, 4, 2, 16, 3, 3), (4, 4, 24, 3, 16, 3, None),   # fewer rows than the filter is tall
+]
+
+
+@pytest.mark.parametrize("shape", STAGED_FORWARD_SHAPES)
+def test_staged_forward_against_the_oracle(shape, dev):
+    """finc_conv_kernel<..., WIDE>: every flip, padded channels, single strips, row chunks, each filter size -- against
+    oracle.forward_f32 (fastflow.py:31-50's four padded convs), plus the affine fold on the same shapes."""
+    from fincflow_amd import ops
+    B, G, Cq, H, W, K, orient = shape
+    orient = ORIENT_FASTFLOW if orient is None else orient
+    rng = np.random.default_rng(B * 1000 + Cq * 10 + K)
+    std = (0.05 if K < 5 else 0.02) * min(1.0, (24.0 / Cq) ** 0.5)
+    ws = oracle.make_stored_weights(G, Cq, K, K, orient=orient, seed=Cq + K, std=std)
+    wco = oracle.canonicalize(ws, G, orient)
+    x = rng.standard_normal((B, G * Cq, H, W)).astype(np.float32)
+    z = oracle.forward_f32(x, wco, G, orient)
+    wc = ops.canonicalize(t(ws, dev), G, orient)
+    got = ops.finc_forward(t(x, dev), wc, G, orient).cpu().numpy()
+    e = rel_err(got, z)
+    report("staged_forward", B=B, G=G, Cq=Cq, H=H, W=W, K=K, orient=orient, err_max_norm=e, err_elementwise=elem_rel_err(got, z))
+    assert e <= TOL, (shape, e)
+    # grad_input runs the same kernel on the flipped image with transposed fragments: adjoint identity <gz, A x'> = <A^T gz, x'>
+    gz = rng.standard_normal(z.shape).astype(np.float32)
+    x2 = rng.standard_normal(x.shape).astype(np.float32)
+    xt = t(x, dev).requires_grad_(True)
+    ops.conv_forward(xt, t(ws, dev), G, orient).backward(t(gz, dev))
+    lhs = float(np.sum(gz.astype(np.float64) * oracle.forward_f32(x2, wco, G, orient)))
+    rhs = float(np.sum(xt.grad.cpu().numpy().astype(np.float64) * x2))
+    assert abs(lhs - rhs) <= 1e-4 * max(1.0, abs(lhs)), (shape, lhs, rhs)
+
+
 # ------------------------------------------------------------------ fp64 entry points
 @pytest.mark.parametrize("shape", [(2, 1, 5, 9, 11, 3, 0), (1, 1, 3, 7, 7, 3, 1), (2, 4, 6, 8, 12, 3, None), (1, 1, 4, 6, 5, 2, 3)])
 def test_fp64_inverse_is_bit_exact_with_the_reference_solver(shape, dev):
