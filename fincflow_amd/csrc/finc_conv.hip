@@ -90,7 +90,7 @@ __global__ __launch_bounds__(64 * NW)
     // instead of 2*Cq/4 dword loads -- and is turned into MFMA B operands by ds_read_b32: [channel][4 halo + 16 columns]
     // in MEMORY order, so a column shift is a read address (no DPP) and the columns left of the strip are the last piece
     // of the neighbouring sector, one more lane group of the same loads (no halo loads).
-    constexpr int IPITCH = 24;                            // floats per channel row: two 16-wide windows 24 apart never share a bank
+    constexpr int IPITCH = 24;                            // floats per channel row (48 and 80 -- conflict-free for all 64 lanes -- time the same: ab27)
     constexpr int NII = (5 * CQP + 63) / 64;              // dwordx4 load instructions per row
     __shared__ __attribute__((aligned(16))) float istg[WIDE ? CQP * IPITCH + 4 : 4];
     typedef unsigned v4u __attribute__((ext_vector_type(4)));

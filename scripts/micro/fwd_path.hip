@@ -97,6 +97,18 @@ __global__ __launch_bounds__(256) void k(const float *ab, const float *in, float
                 nxh[j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ri, lh, 4u * j * chs + r2, 0));
             }
         }
+        if (PIECES & 256) {                                         // DIRECT: row s+2 goes HBM -> LDS (tile s&1), no registers, no ds_write
+            const unsigned r2 = (unsigned)((s + 2) % steps) * RS;
+            float *dt = itile + (S & 1) * 24 * IP;                  // 64 lanes x 16 bytes land contiguously from dt on (M0 base)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ri, (__attribute__((address_space(3))) void *)dt, 16, l4, r2, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ri, (__attribute__((address_space(3))) void *)(dt + 256), 16, l4b, 16u * chs + r2, 0, 0);
+            float *rt = itile + ((S + 1) & 1) * 24 * IP;            // the tile filled a step ago
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+#pragma unroll
+            for (int b = 0; b < 3; ++b)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) X[SN][b][j] = rt[(4 * j + q) * 16 + (p >= b ? p - b : p)];
+        }
         if (PIECES & 2) {                                           // row s+1 (loaded during step s-1) -> LDS, [channel][4 + 16]
             *reinterpret_cast<v4u *>(&it[c16 * IP + 4 + 4 * pc]) = L[0];
             if (c16 < 8) *reinterpret_cast<v4u *>(&it[(16 + c16) * IP + 4 + 4 * pc]) = L[1];
@@ -197,6 +209,8 @@ int main()
     run<128 + 76>("the shipped kernel's path, IMAGE layout", ab, in, outb, out, tm, steps);
     run<128 + 1>("2 dwordx4 row loads, IMAGE layout", ab, in, outb, out, tm, steps);
     run<128 + 12>("staging + stores, IMAGE layout", ab, in, outb, out, tm, steps);
+    run<256>("DIRECT-to-LDS row loads (2 buffer_load_dwordx4 ... lds) + 18 operand reads", ab, in, outb, out, tm, steps);
+    run<256 + 12>("DIRECT-to-LDS loads + operand reads + staging + stores", ab, in, outb, out, tm, steps);
     run<12>("only staging + stores", ab, in, outb, out, tm, steps);
     run<4>("only staging", ab, in, outb, out, tm, steps);
     return 0;
