@@ -78,11 +78,10 @@ __global__ __launch_bounds__(64 * NW)
     constexpr int NFRAG = NTAP * NKZ * MT;                // fragments this wave holds
     constexpr int DREG = (4 * (CQP / 16) + (CQP % 16) / 4) / NW; // output registers this wave finalises and stores
     __shared__ float xch[NW > 1 ? 2 * NW * NW * DREG * 64 : 1]; // [parity][dst wave][src wave][reg][lane]
-    // Output staging (one wave per strip, W % 16 == 0).  Straight from the accumulators a store instruction covers 4 channel
-    // rows x 64 bytes, and six of those per step cost the MFMA wave 47 us of the 400 us c3 forward (timing-only builds,
-    // profiles/r02/notes/ab21).  Through LDS the row leaves as [channel][16 pixels]: a lane writes its values with
-    // ds_write_b32 (cheap beside MFMAs), reads back 16 bytes of one channel, and ceil(Cq/16) buffer_store_dwordx4 -- 16
-    // whole 64-byte sectors each -- go out after the step's MFMAs, when the read-back has long arrived.
+    // Output staging (WIDE).  Straight from the accumulators a store instruction covers 4 channel rows x 64 bytes, 24 of them
+    // per row at c3.  Through LDS the row leaves as [channel][16 pixels]: a lane writes its values with ds_write_b32 (cheap
+    // beside MFMAs), reads back 16 bytes of one channel, and ceil(Cq/16) buffer_store_dwordx4 -- 16 whole 64-byte sectors
+    // each -- go out at the start of the next step, when the read-back has long arrived.
     constexpr int OPITCH = 20;                            // floats per channel row in the staging buffer (16 + pad: bank spread)
     constexpr int NOI = (CQP + 15) / 16;                  // 16-channel store instructions per row
     __shared__ __attribute__((aligned(16))) float ostg[WIDE ? NOI * 16 * OPITCH : 4];
@@ -94,9 +93,9 @@ __global__ __launch_bounds__(64 * NW)
     constexpr int NII = (5 * CQP + 63) / 64;              // dwordx4 load instructions per row
     __shared__ __attribute__((aligned(16))) float istg[WIDE ? CQP * IPITCH + 4 : 4];
     typedef unsigned v4u __attribute__((ext_vector_type(4)));
-    v4u ostv[NOI];                                        // the row read back, waiting for the end of the step
-    unsigned ost_row = OFF_INVALID;                       // its (scalar) row offset
-    bool ost_ok = false;                                  // WIDE: whether that row exists in this chunk (else its stores are dropped)
+    v4u ostv[NOI];                                        // WIDE: the result row read back, waiting for the next step
+    unsigned ost_row = 0;                                 // ... its (scalar) row offset
+    bool ost_ok = false;                                  // ... and whether that row exists in this chunk (else its stores are dropped)
     const int wv = NW > 1 ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;
     const int lane = threadIdx.x & 63;
     const int q = lane >> 4, p = lane & 15;
@@ -357,11 +356,6 @@ __global__ __launch_bounds__(64 * NW)
         }
     }
     // staged stores: lane (c16, k) = channel 16i + c16, 16-byte piece k of the strip's sector (memory order)
-    constexpr bool wide = false;                          // the staged form is the WIDE pipeline above
-    const int oc16 = lane >> 2;
-    const unsigned ost_col = (unsigned)((fw ? W - 16 - strip * 16 : strip * 16) + 4 * (lane & 3)) * 4u;
-    const unsigned ost_lane = ost_col + (unsigned)oc16 * HW * 4u;
-    const unsigned ost_lane_last = (16 * (NOI - 1) + oc16 < CQ) ? ost_lane : OFF_BAD_CHANNEL;   // only the last instruction can hold padded channels
     auto rowoff = [&](int h) {                            // scalar
         return (h >= 0 && h < H) ? (unsigned)((fh ? H - 1 - h : h) * W) * 4u : OFF_INVALID;
     };
@@ -418,22 +412,6 @@ __global__ __launch_bounds__(64 * NW)
         }
         const unsigned ro = rowoff_st(h);
         if constexpr (NW == 1) {
-            if constexpr (wide) {                         // (kept for reference: the first staged form, stores only)
-                const int pp = fw ? 15 - p : p;           // memory order inside the strip's sector
-#pragma unroll
-                for (int mt = 0; mt < MTB; ++mt) {
-                    const float v[4] = {ac[mt].x, ac[mt].y, ac[mt].z, ac[mt].w};
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) ostg[(16 * mt + 4 * q + r) * OPITCH + pp] = v[r];
-                }
-#pragma unroll
-                for (int sb = 0; sb < NSM; ++sb) ostg[(16 * MTB + 4 * sb + q) * OPITCH + pp] = finc_block_reduce(ac[MTB + sb]);
-#pragma unroll
-                for (int i = 0; i < NOI; ++i)
-                    ostv[i] = *reinterpret_cast<const v4u *>(&ostg[(16 * i + (lane >> 2)) * OPITCH + 4 * (lane & 3)]);
-                ost_row = ro;
-                return;
-            }
             const unsigned vb = ro + lo_base;
 #pragma unroll
             for (int mt = 0; mt < MTB; ++mt) {
@@ -528,13 +506,6 @@ __global__ __launch_bounds__(64 * NW)
                             mma(ac[mt], ((a * KW + b) * NKZ + j) * MT + mt, X[(S + KH - a) % KH][b][j]);
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) acc[S][mt] = ac[mt];
-        }
-        if constexpr (NW == 1) {
-            if constexpr (wide) {                         // the previous row leaves: ceil(Cq/16) x 16 whole sectors
-#pragma unroll
-                for (int i = 0; i < NOI; ++i)
-                    __builtin_amdgcn_raw_buffer_store_b128(ostv[i], rout, ost_row + (i == NOI - 1 ? ost_lane_last : ost_lane), 16 * i * HW * 4, 0);
-            }
         }
     };
 
