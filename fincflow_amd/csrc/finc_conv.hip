@@ -812,7 +812,10 @@ int finc_conv_launch(const float *in, const void *packed, float *out, const Finc
     const int RC = (s.H + nrc - 1) / nrc;
     nrc = (s.H + RC - 1) / RC;
     static const bool no_wide = getenv("FINC_CONV_NO_WIDE") != nullptr;   // experiment switch: the dword form everywhere
-    const conv_fn fn = (i->fn_wide && s.W % 16 == 0 && !no_wide) ? i->fn_wide : i->fn;
+    // the staged form moves 16-byte pieces: activations that are only float-aligned (a view into a larger tensor) take the
+    // dword form, as the inverse sends them to its strict kernel
+    const bool aligned16 = (((uintptr_t)in | (uintptr_t)out) & 15) == 0;
+    const conv_fn fn = (i->fn_wide && s.W % 16 == 0 && aligned16 && !no_wide) ? i->fn_wide : i->fn;
     hipLaunchKernelGGL(fn, dim3(s.B * s.G * NS, nrc), dim3(64 * i->nw), 0, st, in, (const float *)packed, out, s.G, s.Cq,
                        s.H, s.W, NS, RC, s.orient);
     FINC_CHECK_LAUNCH();

@@ -307,6 +307,30 @@ def test_unaligned_view_through_fastflowunit_reverse(dev):
         assert y.shape == (B, 4, H, W)
 
 
+def test_unaligned_view_through_the_forward(dev):
+    """The staged forward moves 16-byte pieces; a float-aligned view (W % 16 == 0, so the staged form would be picked)
+    must take the dword form and give the same numbers -- input view, output view, and both."""
+    from fincflow_amd import FastFlowUnit
+    torch.manual_seed(7)
+    B, C, H, W = 2, 48, 6, 32
+    unit = FastFlowUnit(C, C, 3).to(dev)
+    x = torch.randn(B, C, H, W, device=dev)
+    with torch.no_grad():
+        z, _ = unit(x)                                # aligned: the staged form
+        n = x.numel()
+        buf = torch.zeros(n + 8, device=dev)
+        buf[1:n + 1] = x.flatten()
+        xv = buf[1:n + 1].view(B, C, H, W)
+        assert xv.is_contiguous() and xv.data_ptr() % 16 == 4
+        zv, _ = unit(xv)
+        assert rel_err(zv.cpu().numpy(), z.cpu().numpy()) <= 1e-6
+        obuf = torch.zeros(n + 8, device=dev)
+        ov = obuf[3:n + 3].view(B, C, H, W)
+        unit._cache.forward(xv, unit._weights(), 4, ORIENT_FASTFLOW, out=ov)
+        assert rel_err(ov.cpu().numpy(), z.cpu().numpy()) <= 1e-6
+        assert float(obuf[:3].abs().sum()) == 0.0 and float(obuf[n + 3:].abs().sum()) == 0.0   # nothing written outside the view
+
+
 # ------------------------------------------------------------------ SURVEY 8 f3: the 1x1 conv next to the unit
 @pytest.mark.parametrize("shape", [(3, 96, 20, 24), (2, 12, 16, 16), (5, 24, 8, 8), (4, 48, 4, 4), (2, 192, 9, 8), (1, 4, 7, 7),
                                    (2, 16, 5, 3), (3, 64, 6, 10), (1, 128, 3, 5), (2, 8, 1, 1)])
