@@ -845,13 +845,18 @@ __global__ __launch_bounds__(HLP ? 512 : 64 * NW * NPW) void finc_wave_kernel(co
     float *pop_p[KH];                         // = fifo + pop_base + ((fslot+1) % D) * pop_stride
 #pragma unroll
     for (int a = 1; a < KH; ++a) pop_p[a] = fifo + pop_base[a] + (D > 1 ? pop_stride[a] : 0);
+#ifndef FINC_FIFO_EXEC   // experiment: 1 = only the lanes that really push / pop touch LDS (exec-masked), no trash words
+#define FINC_FIFO_EXEC 0
+#endif
     auto fifo_push = [&](const float (&v)[NK]) {
+        if (FINC_FIFO_EXEC && !do_push) return;
 #pragma unroll
         for (int j = 0; j < NK; ++j) push_p[j * JS] = v[j];
     };
     auto fifo_pop_all = [&]() {
 #pragma unroll
         for (int a = 1; a < KH; ++a) {
+            if (FINC_FIFO_EXEC && !(p < a)) continue;
 #pragma unroll
             for (int j = 0; j < NK; ++j) fv[a][j] = pop_p[a][j * JS];
         }
