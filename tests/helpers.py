@@ -159,7 +159,7 @@ def fuzz_case(rng, case):
     Cq = int(rng.choice(cq_opts))
     G = int(rng.choice([1, 4, 4, 4]))
     H = int(rng.integers(1, 41))
-    W = int(rng.choice([rng.integers(1, 41), 4 * rng.integers(1, 12), 8 * rng.integers(1, 9)]))
+    W = int(rng.choice([rng.integers(1, 41), 4 * rng.integers(1, 12), 8 * rng.integers(1, 9), 16 * rng.integers(1, 5)]))   # W % 16 == 0: the staged forward
     B = int(rng.integers(1, 4))
     orient = ORIENT_FASTFLOW if G == 4 else int(rng.integers(0, 4))
     std = (0.05 if K < 5 else 0.02) * min(1.0, (24.0 / Cq) ** 0.5)   # keep the operator norm of the bank roughly constant
