@@ -518,148 +518,6 @@ __global__ __launch_bounds__(64 * NW)
     }
 }
 
-// -----------------------------------------------------------------------------------------------
-// grad_w: gw[o][i][KH-1-a][KW-1-b] = sum_{image, h, w} gz[o,h,w] * x[i,h-a,w-b]  per group.
-// Same strip walk, but the PIXELS are the MFMA K dimension: A = gz (lane (q,m): channel 16mo+m, pixel 4kk+q),
-// B = x shifted by the tap (lane (q,n): channel 16mi+n, pixel 4kk+q-b), D = a 16x16 (o,i) tile per tap, kept in
-// NTAP*MT*MT accumulators for the whole kernel.  A wave walks several (image, strip) units of one group and then
-// writes its partial tiles; gradw_reduce_kernel sums the partials, un-tiles them and applies the corner-tap mask
-// (PaddedConv2d.reset_gradients, layers/conv.py:98-99).  Column shifts are just shifted load addresses here.
-// -----------------------------------------------------------------------------------------------
-template <int CQP, int KH, int KW>
-__global__ __launch_bounds__(64) void finc_gradw_kernel(const float *__restrict__ gz, const float *__restrict__ x,
-                                                        float *__restrict__ part, int G, int CQ, int H, int W, int NS,
-                                                        int B, int WPG, unsigned orient)
-{
-    constexpr int MT = (CQP + 15) / 16, NTAP = KH * KW, RS = KH + 1; // RS row slots: rows h+1 (arriving), h, .., h-KH+1
-    const int lane = threadIdx.x;
-    const int q = lane >> 4, m = lane & 15;
-    const int g = blockIdx.x / WPG, wslot = blockIdx.x % WPG;
-    const unsigned o = finc_group_orient(orient, g);
-    const bool fh = (o & FINC_FLIP_H) != 0, fw = (o & FINC_FLIP_W) != 0;
-    const int HW = H * W;
-    const unsigned slab_bytes = (unsigned)CQ * (unsigned)HW * 4u;
-
-    v4f acc[NTAP][MT][MT];
-#pragma unroll
-    for (int t = 0; t < NTAP; ++t)
-#pragma unroll
-        for (int mo = 0; mo < MT; ++mo)
-#pragma unroll
-            for (int mi = 0; mi < MT; ++mi) acc[t][mo][mi] = (v4f){0.f, 0.f, 0.f, 0.f};
-
-    unsigned choff[MT];                                   // channel 16mt+m of this lane (same for gz and x)
-#pragma unroll
-    for (int mt = 0; mt < MT; ++mt) choff[mt] = (16 * mt + m) < CQ ? (unsigned)(16 * mt + m) * HW * 4u : OFF_BAD_CHANNEL;
-
-    for (int u = wslot; u < B * NS; u += WPG) {
-        const int b = u / NS, strip = u % NS;
-        const size_t slab = ((size_t)b * G + g) * CQ * HW;
-        const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void *)(gz + slab), 0, (int)slab_bytes, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void *)(x + slab), 0, (int)slab_bytes, 0x00020000);
-        // lane offsets: pixel 4kk+q of the strip, shifted left by b columns for x (invalid columns -> beyond the slab)
-        unsigned og[MT][4], ox[KW][MT][4];
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-            const int col = strip * 16 + 4 * kk + q;
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt) {
-                og[mt][kk] = col < W ? (unsigned)(fw ? W - 1 - col : col) * 4u + choff[mt] : OFF_BAD_CHANNEL;
-#pragma unroll
-                for (int bb = 0; bb < KW; ++bb) {
-                    const int c = col - bb;
-                    ox[bb][mt][kk] = (c >= 0 && col < W) ? (unsigned)(fw ? W - 1 - c : c) * 4u + choff[mt] : OFF_BAD_CHANNEL;
-                }
-            }
-        }
-        float GA[2][MT][4];                               // gz rows: [arriving / current]
-        float XB[RS][KW][MT][4];                          // x rows by slot
-#pragma unroll
-        for (int s = 0; s < RS; ++s)
-#pragma unroll
-            for (int bb = 0; bb < KW; ++bb)
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) XB[s][bb][mt][kk] = 0.f;
-        auto rowbytes = [&](int h) { return (unsigned)((fh ? H - 1 - h : h) * W) * 4u; };
-        auto load_row = [&](int h, float (&ga)[MT][4], float (&xb)[KW][MT][4]) {
-            const bool rok = h < H;
-            const unsigned ro = rok ? rowbytes(h) : OFF_INVALID;      // scalar
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    ga[mt][kk] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rg, ro + og[mt][kk], 0, 0));
-#pragma unroll
-                    for (int bb = 0; bb < KW; ++bb)
-                        xb[bb][mt][kk] =
-                            __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, ro + ox[bb][mt][kk], 0, 0));
-                }
-        };
-        auto step = [&](auto i_c, int h) {                // row h lives in slot S, row h+1 arrives into slot S+1
-            constexpr int I = decltype(i_c)::value;       // h % UN
-            constexpr int S = I % RS, PAR = I & 1;        // x row slot, gz ping-pong buffer
-            load_row(h + 1, GA[PAR ^ 1], XB[(S + 1) % RS]);
-#pragma unroll
-            for (int a = 0; a < KH; ++a)
-#pragma unroll
-                for (int bb = 0; bb < KW; ++bb)
-#pragma unroll
-                    for (int mo = 0; mo < MT; ++mo)
-#pragma unroll
-                        for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-                            for (int kk = 0; kk < 4; ++kk)
-                                acc[a * KW + bb][mo][mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(
-                                    GA[PAR][mo][kk], XB[(S + RS - a) % RS][bb][mi][kk], acc[a * KW + bb][mo][mi], 0, 0, 0);
-        };
-        load_row(0, GA[0], XB[0]);
-        // RS and the 2-deep gz ring must rotate together: unroll by lcm(RS, 2)
-        constexpr int UN = (RS % 2 == 0) ? RS : 2 * RS;
-        for (int h0 = 0; h0 < H; h0 += UN) {
-            [&]<int... I>(std::integer_sequence<int, I...>) {
-                ((h0 + I < H ? step(IC<I>{}, h0 + I) : (void)0), ...);
-            }(std::make_integer_sequence<int, UN>{});
-        }
-    }
-    // partial tiles: part[((g*WPG + wslot)*NTAP*MT*MT + tile)*256 + r*64 + lane]
-    float *dst = part + (size_t)blockIdx.x * (NTAP * MT * MT) * 256 + lane;
-#pragma unroll
-    for (int t = 0; t < NTAP; ++t)
-#pragma unroll
-        for (int mo = 0; mo < MT; ++mo)
-#pragma unroll
-            for (int mi = 0; mi < MT; ++mi) {
-                const v4f v = acc[t][mo][mi];
-                const float v0 = v.x, v1 = v.y, v2 = v.z, v3 = v.w;
-                float *d = dst + ((t * MT + mo) * MT + mi) * 256;
-                d[0] = v0; d[64] = v1; d[128] = v2; d[192] = v3;
-            }
-}
-
-// gw[g][o][i][kh][kw] = sum over the WPG partials; D layout: lane (q,n), reg r -> o = 16mo+4q+r, i = 16mi+n.
-__global__ void gradw_reduce_kernel(const float *__restrict__ part, float *__restrict__ gw, int Cq, int KH, int KW, int MT,
-                                    int WPG)
-{
-    const int g = blockIdx.y;
-    const int ntap = KH * KW;
-    const int per = ntap * MT * MT * 256;
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < per; e += gridDim.x * blockDim.x) {
-        float s = 0.f;
-        const float *p = part + (size_t)g * WPG * per + e;
-        for (int w = 0; w < WPG; ++w) s += p[(size_t)w * per];
-        const int lane = e & 63, r = (e >> 6) & 3, tile = e >> 8;
-        const int mi = tile % MT, mo = (tile / MT) % MT, t = tile / (MT * MT);
-        const int oc = 16 * mo + 4 * (lane >> 4) + r, ic = 16 * mi + (lane & 15);
-        if (oc < Cq && ic < Cq) {
-            const int a = t / KW, b = t % KW;
-            const bool masked = (a == 0 && b == 0) && ic >= oc;
-            gw[(((size_t)(g * Cq + oc) * Cq + ic) * KH + (KH - 1 - a)) * KW + (KW - 1 - b)] = masked ? 0.f : s;
-        }
-    }
-}
-
 // fragment (tap (a,b), j, mt), lane (q,i): W[row finc_tile_row(mt,i)][col 4j+q][KH-1-a][KW-1-b]; `transpose` swaps row/col
 // `scale` / `shift` ([G*Cq] or nullptr): the per-output-channel affine map folded behind the conv (rows scaled; shift in
 // the 4*MT bias registers behind the fragments: 16-row tile: lane (q,p), register r = row 16mt+4q+r; 4-row block: register
@@ -695,14 +553,11 @@ __global__ void conv_pack_kernel(const float *__restrict__ wc, const float *__re
 }
 
 typedef void (*conv_fn)(const float *, const float *, float *, int, int, int, int, int, int, unsigned);
-typedef void (*gradw_fn)(const float *, const float *, float *, int, int, int, int, int, int, int, unsigned);
 struct ConvInst {
     int cqp, kh, kw;
     conv_fn fn;
     conv_fn fn_wide;             // W % 16 == 0, one wave per strip: rows move as 16-byte pieces through LDS (nullptr: none)
     int mt, mtb, nkz, nfrag, nw; // mt = mtb 16-row tiles + 4-row blocks: fragments per (tap, k-step)
-    int mtg;                     // grad-weight kernel: ceil(Cq/16) tiles in both dimensions
-    gradw_fn gw; // MFMA grad-weight kernel (nullptr: NTAP*MT*MT accumulators would not fit)
 };
 template <int CQP, int KH, int KW, int NW>
 constexpr conv_fn wide_fn()
@@ -717,13 +572,9 @@ constexpr conv_fn wide_fn()
 template <int CQP, int KH, int KW, int NW = 1>
 constexpr ConvInst make_conv()
 {
-    constexpr int MTG = (CQP + 15) / 16, MTB = CQP / 16, MT = MTB + (CQP % 16) / 4;
-    if constexpr (KH * KW * MTG * MTG * 4 <= 200)
-        return ConvInst{CQP, KH, KW, finc_conv_kernel<CQP, KH, KW, NW, false>, wide_fn<CQP, KH, KW, NW>(), MT, MTB, CQP / 4,
-                        KH * KW * (CQP / 4) * MT, NW, MTG, finc_gradw_kernel<CQP, KH, KW>};
-    else
-        return ConvInst{CQP, KH, KW, finc_conv_kernel<CQP, KH, KW, NW, false>, wide_fn<CQP, KH, KW, NW>(), MT, MTB, CQP / 4,
-                        KH * KW * (CQP / 4) * MT, NW, MTG, nullptr};
+    constexpr int MTB = CQP / 16, MT = MTB + (CQP % 16) / 4;
+    return ConvInst{CQP, KH, KW, finc_conv_kernel<CQP, KH, KW, NW, false>, wide_fn<CQP, KH, KW, NW>(), MT, MTB, CQP / 4,
+                    KH * KW * (CQP / 4) * MT, NW};
 }
 const ConvInst g_conv[] = {
     make_conv<4, 3, 3>(),  make_conv<8, 3, 3>(),  make_conv<12, 3, 3>(), make_conv<16, 3, 3>(), make_conv<20, 3, 3>(),
@@ -766,35 +617,6 @@ int finc_conv_pack(const float *wc, void *packed, int G, int Cq, int KH, int KW,
     if (blocks > 64) blocks = 64;
     hipLaunchKernelGGL(conv_pack_kernel, dim3(blocks, G), dim3(256), 0, st, wc, scale, shift, (float *)packed, Cq, KH, KW,
                        i->mt, i->mtb, i->nkz, transpose ? 1 : 0, i->nfrag);
-    FINC_CHECK_LAUNCH();
-    return FINC_OK;
-}
-
-static int gradw_wpg(const FincShape &s)
-{
-    const int units = s.B * ((s.W + 15) / 16);
-    return units < 256 ? units : 256;
-}
-
-size_t finc_gradw_workspace_bytes(const FincShape &s)
-{
-    const ConvInst *i = find_conv(s.Cq, s.KH, s.KW);
-    if (!i || !i->gw || !finc_conv_supported(s.Cq, s.H, s.W, s.KH, s.KW)) return 0;
-    return (size_t)s.G * gradw_wpg(s) * s.KH * s.KW * i->mtg * i->mtg * 256 * sizeof(float);
-}
-
-int finc_gradw_launch(const float *gz, const float *x, float *gw, void *workspace, const FincShape &s, hipStream_t st)
-{
-    const ConvInst *i = find_conv(s.Cq, s.KH, s.KW);
-    if (!i || !i->gw) return FINC_ERR_UNSUPPORTED;
-    const int NS = (s.W + 15) / 16, WPG = gradw_wpg(s);
-    hipLaunchKernelGGL(i->gw, dim3(s.G * WPG), dim3(64), 0, st, gz, x, (float *)workspace, s.G, s.Cq, s.H, s.W, NS, s.B,
-                       WPG, s.orient);
-    FINC_CHECK_LAUNCH();
-    const int per = s.KH * s.KW * i->mtg * i->mtg * 256;
-    int blocks = (per + 255) / 256;
-    hipLaunchKernelGGL(gradw_reduce_kernel, dim3(blocks, s.G), dim3(256), 0, st, (const float *)workspace, gw, s.Cq, s.KH,
-                       s.KW, i->mtg, WPG);
     FINC_CHECK_LAUNCH();
     return FINC_OK;
 }

@@ -294,7 +294,11 @@ def test_ksplit_forward_and_grad_input(shape, dev):
     assert abs(lhs - rhs) <= 1e-5 * max(abs(lhs), abs(rhs), 1.0)
 
 
-@pytest.mark.parametrize("shape", [(3, 96, 20, 40, 3), (2, 64, 9, 17, 5), (2, 16, 12, 12, 2), (64, 96, 64, 64, 3)])
+@pytest.mark.parametrize("shape", [(3, 96, 20, 40, 3), (2, 64, 9, 17, 5), (2, 16, 12, 12, 2), (64, 96, 64, 64, 3),
+                                   # W % 16 == 0: the staged form (16-byte pieces through LDS; 4-row blocks behind the last full 16)
+                                   (3, 96, 10, 16, 3), (2, 48, 9, 32, 3), (2, 64, 7, 48, 3), (2, 80, 6, 32, 3), (2, 16, 9, 16, 3),
+                                   (2, 32, 8, 32, 5), (2, 48, 6, 16, 5), (2, 92, 8, 32, 3), (3, 128, 5, 16, 3), (2, 96, 8, 32, 2),
+                                   (5, 96, 1, 16, 3), (1, 96, 2, 64, 3)])
 def test_grad_weight_mfma(shape, dev):
     """grad_w on the MFMA strip kernel (pixels on K) + reduce + corner-tap mask.  Pinned by linearity in the weights:
     <grad_w, dW> == <gz, forward(x; dW)> for any bank dW whose masked entries are zero, and against the direct
