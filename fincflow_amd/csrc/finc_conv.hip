@@ -268,7 +268,7 @@ __global__ __launch_bounds__(64 * NW)
             constexpr int S = decltype(s_c)::value, SN = (S + 1) % U;
             flush_staged();
 #pragma unroll
-            for (int i = 0; i < NII; ++i) *reinterpret_cast<v4u *>(&istg[lwr[i]]) = L[i];
+            for (int i = 0; i < NII; ++i) reinterpret_cast<v4u *>(istg)[lwr[i] >> 2] = L[i];   // (index in pieces: ds_write_b128)
             issue(h + 2);
 #pragma unroll
             for (int b = 0; b < KW; ++b)

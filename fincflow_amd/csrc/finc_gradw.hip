@@ -237,15 +237,18 @@ __global__ __launch_bounds__(64) void finc_gradw_staged_kernel(const float *__re
             }
         }
         auto rowbytes = [&](int h) { return (unsigned)((fh ? H - 1 - h : h) * W) * 4u; };
-        v4u LX[NXI], LG[NGI];
-        auto issue = [&](int h) {
+        // pieces in flight: TWO rows ahead (one wave per SIMD: nobody else hides a row's HBM latency), two register sets by
+        // row parity
+        v4u LX[2][NXI], LG[2][NGI];
+        auto issue = [&](auto par_c, int h) {
+            constexpr int PAR = decltype(par_c)::value;
             const bool ok = h >= 0 && h < H;
             const __amdgpu_buffer_rsrc_t rx = rsrc(x, ok), rg = rsrc(gz, ok);
             const unsigned ro = ok ? rowbytes(h) : 0u;
 #pragma unroll
-            for (int i = 0; i < NXI; ++i) LX[i] = __builtin_amdgcn_raw_buffer_load_b128(rx, lvx[i], ro, 0);
+            for (int i = 0; i < NXI; ++i) LX[PAR][i] = __builtin_amdgcn_raw_buffer_load_b128(rx, lvx[i], ro, 0);
 #pragma unroll
-            for (int i = 0; i < NGI; ++i) LG[i] = __builtin_amdgcn_raw_buffer_load_b128(rg, lvg[i], ro, 0);
+            for (int i = 0; i < NGI; ++i) LG[PAR][i] = __builtin_amdgcn_raw_buffer_load_b128(rg, lvg[i], ro, 0);
         };
         float GA[2][MTBD][4], GS[2][NSMD][4];                           // gz operands: [arriving / current]
         float XB[RS][KW][MT][4];                                        // x operands by row slot
@@ -257,15 +260,15 @@ __global__ __launch_bounds__(64) void finc_gradw_staged_kernel(const float *__re
                 for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int kk = 0; kk < 4; ++kk) XB[sl][bb][mt][kk] = 0.f;
-        // stage(row): its pieces (loaded during the previous step) go registers -> tiles -> operand registers of the row's
-        // slot, and the row after it is asked for
+        // stage(row): its pieces (asked for two steps ago) go registers -> tiles -> operand registers of the row's slot, and
+        // row + 2 is asked for
         auto stage = [&](auto sn_c, auto pn_c, int row) {
             constexpr int SN = decltype(sn_c)::value, PN = decltype(pn_c)::value;
 #pragma unroll
-            for (int i = 0; i < NXI; ++i) *reinterpret_cast<v4u *>(&xt[lwx[i]]) = LX[i];
+            for (int i = 0; i < NXI; ++i) reinterpret_cast<v4u *>(xt)[lwx[i] >> 2] = LX[PN][i];   // (index in pieces: ds_write_b128)
 #pragma unroll
-            for (int i = 0; i < NGI; ++i) *reinterpret_cast<v4u *>(&gt[lwg[i]]) = LG[i];
-            issue(row + 1);
+            for (int i = 0; i < NGI; ++i) reinterpret_cast<v4u *>(gt)[lwg[i] >> 2] = LG[PN][i];
+            issue(IC<PN>{}, row + 2);                                   // into the set just emptied
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
 #pragma unroll
@@ -302,8 +305,9 @@ __global__ __launch_bounds__(64) void finc_gradw_staged_kernel(const float *__re
                         }
             __builtin_amdgcn_sched_barrier(0);
         };
-        issue(0);
-        stage(IC<0>{}, IC<0>{}, 0);                                     // row 0 into slot 0 (asks for row 1)
+        issue(IC<0>{}, 0);
+        issue(IC<1>{}, 1);
+        stage(IC<0>{}, IC<0>{}, 0);                                     // row 0 into slot 0 (asks for row 2)
         constexpr int UN = (RS % 2 == 0) ? RS : 2 * RS;                 // row slots and the 2-deep gz ring rotate together
         for (int h0 = 0; h0 < H; h0 += UN) {
             [&]<int... I>(std::integer_sequence<int, I...>) {
