@@ -339,24 +339,32 @@ __global__ __launch_bounds__(64) void finc_gradw_staged_kernel(const float *__re
 }
 
 // gw[g][o][i][kh][kw] = sum over the WPG partials; D layout: lane (q,n), reg r -> o = 16mo+4q+r, i = 16mi+n.
-__global__ void gradw_reduce_kernel(const float *__restrict__ part, float *__restrict__ gw, int Cq, int KH, int KW, int MT,
-                                    int WPG)
+// A block of 256 threads owns 32 consecutive entries; its 8 thread groups sum 8 interleaved slices of the partials
+// (w = j, j+8, ...) and the slices meet in LDS in a FIXED order: 8x the loads in flight of one thread per entry, and
+// the same bits on every run.
+__global__ __launch_bounds__(256) void gradw_reduce_kernel(const float *__restrict__ part, float *__restrict__ gw, int Cq, int KH,
+                                                           int KW, int MT, int WPG)
 {
+    __shared__ float slice[8][32];
     const int g = blockIdx.y;
     const int ntap = KH * KW;
     const int per = ntap * MT * MT * 256;
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < per; e += gridDim.x * blockDim.x) {
-        float s = 0.f;
-        const float *p = part + (size_t)g * WPG * per + e;
-        for (int w = 0; w < WPG; ++w) s += p[(size_t)w * per];
-        const int lane = e & 63, r = (e >> 6) & 3, tile = e >> 8;
-        const int mi = tile % MT, mo = (tile / MT) % MT, t = tile / (MT * MT);
-        const int oc = 16 * mo + 4 * (lane >> 4) + r, ic = 16 * mi + (lane & 15);
-        if (oc < Cq && ic < Cq) {
-            const int a = t / KW, b = t % KW;
-            const bool masked = (a == 0 && b == 0) && ic >= oc;
-            gw[(((size_t)(g * Cq + oc) * Cq + ic) * KH + (KH - 1 - a)) * KW + (KW - 1 - b)] = masked ? 0.f : s;
-        }
+    const int el = threadIdx.x & 31, j = threadIdx.x >> 5;
+    const int e = blockIdx.x * 32 + el;                    // per is a multiple of 256: every block is full
+    float s = 0.f;
+    const float *p = part + (size_t)g * WPG * per + e;
+    for (int w = j; w < WPG; w += 8) s += p[(size_t)w * per];
+    slice[j][el] = s;
+    __syncthreads();
+    if (j != 0) return;
+    s = ((slice[0][el] + slice[1][el]) + (slice[2][el] + slice[3][el])) + ((slice[4][el] + slice[5][el]) + (slice[6][el] + slice[7][el]));
+    const int lane = e & 63, r = (e >> 6) & 3, tile = e >> 8;
+    const int mi = tile % MT, mo = (tile / MT) % MT, t = tile / (MT * MT);
+    const int oc = 16 * mo + 4 * (lane >> 4) + r, ic = 16 * mi + (lane & 15);
+    if (oc < Cq && ic < Cq) {
+        const int a = t / KW, b = t % KW;
+        const bool masked = (a == 0 && b == 0) && ic >= oc;
+        gw[(((size_t)(g * Cq + oc) * Cq + ic) * KH + (KH - 1 - a)) * KW + (KW - 1 - b)] = masked ? 0.f : s;
     }
 }
 
@@ -428,7 +436,7 @@ int finc_gradw_launch(const float *gz, const float *x, float *gw, void *workspac
                        WPG, s.orient);
     FINC_CHECK_LAUNCH();
     const int per = s.KH * s.KW * i->mtg * i->mtg * 256;
-    int blocks = (per + 255) / 256;
+    const int blocks = per / 32;
     hipLaunchKernelGGL(gradw_reduce_kernel, dim3(blocks, s.G), dim3(256), 0, st, (const float *)workspace, gw, s.Cq, s.KH,
                        s.KW, i->mtg, WPG);
     FINC_CHECK_LAUNCH();

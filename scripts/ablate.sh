@@ -8,6 +8,6 @@ for v in 0 1 2 3; do
 done
 wait
 for v in 0 1 2 3; do
-  hipcc --offload-arch=gfx950 -shared -fPIC -o ../../ablate_build/libfinc_v$v.so finc_abi.o finc_generic.o finc_conv.o ../../ablate_build/mfma_$v.o
+  hipcc --offload-arch=gfx950 -shared -fPIC -o ../../ablate_build/libfinc_v$v.so finc_abi.o finc_generic.o finc_conv.o finc_gradw.o finc_mix.o ../../ablate_build/mfma_$v.o
 done
 ls -la ../../ablate_build/*.so

@@ -320,7 +320,10 @@ def test_grad_weight_mfma(shape, dev):
     dW = torch.randn_like(wc) * mask
     lhs = float((gw.double() * dW.double()).sum())
     rhs = float((gz.double() * ops.finc_forward(x, dW.contiguous()).double()).sum())
-    assert abs(lhs - rhs) <= 2e-5 * max(abs(lhs), abs(rhs), 1.0)
+    # both sides are sums of many terms of either sign: the yardstick is the sum of their magnitudes, not the (cancelled)
+    # total -- 2e-7 of it is fp32 rounding of a few hundred accumulations per entry, whatever order they ran in
+    scale = float((gw.double() * dW.double()).abs().sum())
+    assert abs(lhs - rhs) <= 2e-7 * scale + 1e-6, (lhs, rhs, scale)
     if B * C * H * W <= 1 << 20:
         gw_direct = torch.empty_like(wc)
         st = L.finc_backward_f32(gz.data_ptr(), x.data_ptr(), wc.data_ptr(), None, gw_direct.data_ptr(), B, 4, Cq, H, W, K, K,
