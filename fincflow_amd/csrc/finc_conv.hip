@@ -630,6 +630,8 @@ int finc_conv_launch(const float *in, const void *packed, float *out, const Finc
     // still pay up to 2 waves per SIMD), in chunks of at least 4 rows (every chunk recomputes KH-1 rows of operands)
     const long long waves = (long long)s.B * s.G * NS * i->nw;
     int nrc = waves >= 2048 ? 1 : waves >= 1024 ? 2 : (int)((1024 + waves - 1) / waves);
+    static const int force_chunks = getenv("FINC_CONV_CHUNKS") ? atoi(getenv("FINC_CONV_CHUNKS")) : 0;   // experiment switch
+    if (force_chunks > 0) nrc = force_chunks;
     if (nrc > s.H / 4) nrc = s.H / 4 > 0 ? s.H / 4 : 1;
     const int RC = (s.H + nrc - 1) / nrc;
     nrc = (s.H + RC - 1) / RC;
