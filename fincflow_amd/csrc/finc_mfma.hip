@@ -1451,17 +1451,20 @@ constexpr Inst make_inst()
 #define FINC_BOTH(cqp, kh, kw) make_inst<cqp, kh, kw>()
 
 #ifdef FINC_ONLY_C3   // experiment builds (scripts/build_variant.sh): only the c3 kernels, compiles in seconds
-const Inst g_insts[] = {make_inst<24, 3, 3, 2, 2, 512>(), FINC_BOTH(24, 3, 3)};
+const Inst g_insts[] = {make_inst<24, 3, 3, 3, 1, 256>(), make_inst<24, 3, 3, 2, 2, 512>(), FINC_BOTH(24, 3, 3)};
 #else
 const Inst g_insts[] = {
     // 3x3: every Cq % 4 == 0 up to 32, then K-split (2 / 4 waves per problem) for the banks one wave cannot hold.
     // Variants of one shape are tried in table order.  <24,3,3> first lists its small-batch variant: while the problems
     // number no more than the SIMD pairs of the chip (B*G <= 512), splitting each over 2 waves is 27 % faster
     // (289 vs 395 us at B <= 128); 2-wave problems are packed in pairs (NPW = 2) so that all four SIMDs of a CU get work.
+    // While they do not outnumber the CUs either (B*G <= 256, e.g. the 32 images a GPU gets when c3's batch is cut eight
+    // ways), three waves per problem -- two k-steps each -- are faster again: 306 -> 245 us at B = 8 .. 64 (six waves, one
+    // k-step each: 257 us; profiles/r02/notes/ab32).
     // (Cq = 12, config 2: one k-step per wave while the problems do not outnumber the CUs: 54 -> 48 us at B = 64)
     FINC_BOTH(4, 3, 3),  FINC_BOTH(8, 3, 3),  make_inst<12, 3, 3, 3, 1, 256>(), FINC_BOTH(12, 3, 3), FINC_BOTH(16, 3, 3),
     FINC_BOTH(20, 3, 3),
-    make_inst<24, 3, 3, 2, 2, 512>(), FINC_BOTH(24, 3, 3), FINC_BOTH(28, 3, 3),
+    make_inst<24, 3, 3, 3, 1, 256>(), make_inst<24, 3, 3, 2, 2, 512>(), FINC_BOTH(24, 3, 3), FINC_BOTH(28, 3, 3),
     // Cq = 32: one wave's rings (53 KB at W = 64) let only 2 problems onto a CU; split over 2 waves and packed in pairs
     // the same 2 problems keep all 4 SIMDs busy (1.25 -> 0.89 ms at B = 256, 64x64)
     make_inst<32, 3, 3, 2, 2>(), FINC_BOTH(32, 3, 3),
