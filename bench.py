@@ -388,6 +388,21 @@ def bench_unit(args):
         resid = float((unit(keep["xs"])[0] - zn).abs().max() / zn.abs().max())
     assert err_after <= 1e-5, err_after
     assert resid <= 1e-5, resid
+    # SURVEY 8 f1, reported beside the metric (not part of `value`): the layer's training step -- forward, grad-input and
+    # grad-weight (+ the fused corner-tap mask) through autograd, gradients reset every step
+    xg = x.detach().clone().requires_grad_(True)
+    gz = torch.randn_like(z)
+
+    def step_train():
+        xg.grad = None
+        for p_ in unit.parameters():
+            p_.grad = None
+        zz, _ = unit(xg)
+        zz.backward(gz)
+
+    tr_steps = min(args.steps, 20)
+    tr_dt, _, tr_per = h.timed(step_train, tr_steps, 3)
+    del xg, gz
 
     if rank == 0:
         E = B * C * H * W
@@ -432,6 +447,10 @@ def bench_unit(args):
                         "note": f"fp32-compute-bound shape: at 100 % of the fp32 peak this call reaches {hbm_ceiling:.0%} of "
                                 f"HBM peak" + ("; the north_star's 40 % of HBM on the forward is unreachable at fp32 here"
                                                if hbm_ceiling < 0.4 else "")},
+            "training_step": {"what": "z = unit(x); z.backward(gz): forward + grad-input + grad-weight with the corner-tap mask "
+                                      "(SURVEY 8 f1), HIP kernels under autograd", "ms_per_step": tr_dt / tr_steps * 1e3,
+                              "steps": tr_steps, "launch": launch_stats(tr_per),
+                              "frac_fp32_peak": 3 * alg_flops / (tr_dt / tr_steps) / 1e12 / FP32_PEAK_TFLOPS},
             "roofline": {"kernel": inverse_kernel_name(B, Cq, H, W, K), "bound": "hbm", "achieved": inv_gbs,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": inv_gbs / HBM_PEAK_GBS,
                          "traffic": (traffic or {}).get("inverse_hbm_bytes_per_launch"),
