@@ -1,0 +1,66 @@
+"""Register-allocation invariants of the built library, read from the code objects' own metadata (no GPU).
+
+The sector-pairing and helper-wave forms of the inverse issue their z loads as inline asm and count them by hand; hipcc takes
+an asm output for complete, so a SPILLED load destination is saved to scratch before its data has arrived (DESIGN 3.1 /
+3.4 item 9: that is how a first helper-wave build produced NaNs).  Those kernels must not spill a single register; the
+instantiation rules (`hlp_fits`, the sector-pairing `mode`) exist to guarantee it, and this test catches a compiler or
+source change that breaks the guarantee without any result changing on the shapes the GPU tests happen to run."""
+import os
+import re
+import shutil
+import subprocess
+import tempfile
+
+import pytest
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LLVM = "/opt/rocm/lib/llvm/bin"
+
+
+def kernel_metadata():
+    lib = os.path.join(REPO, "fincflow_amd", "libfinc_hip.so")
+    if not (os.path.exists(lib) and os.path.exists(os.path.join(LLVM, "llvm-objdump"))):
+        pytest.skip("library or LLVM tools not present")
+    out = {}
+    with tempfile.TemporaryDirectory() as d:
+        shutil.copy(lib, d)
+        subprocess.run([os.path.join(LLVM, "llvm-objdump"), "--offloading", "libfinc_hip.so"], cwd=d, check=True,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        for f in sorted(os.listdir(d)):
+            if "gfx950" not in f:
+                continue
+            notes = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", f], cwd=d, capture_output=True, text=True).stdout
+            # one YAML map per kernel: .name / .vgpr_count / .vgpr_spill_count / .sgpr_spill_count / .private_segment_fixed_size
+            for blk in notes.split("- .agpr_count:")[1:]:
+                name = re.search(r"\.name:\s+(\S+)", blk)
+                if not name:
+                    continue
+                grab = lambda key: int(re.search(r"\.%s:\s+(\d+)" % key, blk).group(1))
+                out[name.group(1)] = {"vgpr": grab("vgpr_count"), "vgpr_spills": grab("vgpr_spill_count"),
+                                      "sgpr_spills": grab("sgpr_spill_count"), "scratch": grab("private_segment_fixed_size")}
+    return out
+
+
+def test_asm_load_kernels_do_not_spill():
+    md = kernel_metadata()
+    wave = {k: v for k, v in md.items() if "finc_wave_kernel" in k}
+    assert len(wave) > 50, "the inverse's instantiations were not found in the code objects"
+    # template tail ...ELb<SEC>ELi<NW>ELi<NPW>ELi<S64>ELi<HLP>EE: S64 != 0 (sector pairing) and HLP != 0 (helper waves) carry asm loads
+    asm_loads = {k: v for k, v in wave.items() if re.search(r"Lb1ELi\d+ELi\d+ELi[123]ELi[012]EE", k)}
+    assert len(asm_loads) >= 10, sorted(wave)[:5]
+    bad = {k: v for k, v in asm_loads.items() if v["vgpr_spills"] or v["scratch"]}
+    assert not bad, f"kernels with hand-counted asm loads must not use scratch: {bad}"
+    helper = [k for k in asm_loads if re.search(r"ELi3ELi1EE", k)]
+    assert helper, "no helper-wave instantiation in the library"
+    for k in helper:                       # two waves per SIMD: the 256-register budget
+        assert asm_loads[k]["vgpr"] <= 256, (k, asm_loads[k])
+
+
+def test_hot_kernels_of_the_bench_shapes_do_not_spill():
+    md = kernel_metadata()
+    for pat in (r"finc_conv_kernelILi24ELi3ELi3ELi1ELb1E", r"finc_conv_kernelILi12ELi3ELi3ELi1ELb1E",
+                r"finc_gradw_staged_kernelILi24ELi3ELi3ELb1E", r"finc_mix_kernel"):
+        hits = {k: v for k, v in md.items() if re.search(pat, k)}
+        assert hits, pat
+        for k, v in hits.items():
+            assert v["vgpr_spills"] == 0 and v["scratch"] == 0, (k, v)
