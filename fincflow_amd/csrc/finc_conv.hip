@@ -63,10 +63,11 @@ constexpr int conv_nreg()
 
 // Two waves per SIMD (256 registers each) is what hides one wave's loads, stores and VALU behind the other's MFMAs:
 // single-wave workgroups ask for that register budget when the bank leaves room for the working set (a 252-fragment
-// bank squeezed into 256 registers spills: 10x slower); the K-split variants keep theirs (their waves are many).
+// bank squeezed into 256 registers spills: 10x slower; the 111 registers of <28,3,3> beside the dword form's working set
+// spill 27: 517 vs 269 us at B=128, profiles/r02/notes/ab34); the K-split variants keep theirs (their waves are many).
 template <int CQP, int KH, int KW, int NW, bool WIDE>
 __global__ __launch_bounds__(64 * NW)
-    __attribute__((amdgpu_waves_per_eu(NW == 1 && conv_nreg<CQP, KH, KW, NW>() <= 128 ? 2 : 1))) void finc_conv_kernel(const float *__restrict__ in,
+    __attribute__((amdgpu_waves_per_eu(NW == 1 && conv_nreg<CQP, KH, KW, NW>() <= 104 ? 2 : 1))) void finc_conv_kernel(const float *__restrict__ in,
                                                             const float *__restrict__ packed, float *__restrict__ out,
                                                             int G, int CQ, int H, int W, int NS, int RC,
                                                             unsigned orient)
@@ -563,9 +564,9 @@ template <int CQP, int KH, int KW, int NW>
 constexpr conv_fn wide_fn()
 {
     // the staged form holds KH+1 row slots of operands and its pieces in flight: only where that fits beside the bank
-    // (<28,3,3> and <16,5,5> would spill inside the 256 registers of two waves per SIMD)
+    // (<16,5,5> would spill inside the 256 registers of two waves per SIMD; <28,3,3> and <32,3,3> run one wave per SIMD)
     constexpr int NREG = conv_nreg<CQP, KH, KW, NW>();
-    if constexpr (NW == 1 && KW <= 5 && NREG + (KH + 1) * KW * (CQP / 4) + 64 <= (NREG <= 128 ? 256 : 512))
+    if constexpr (NW == 1 && KW <= 5 && NREG + (KH + 1) * KW * (CQP / 4) + 64 <= (NREG <= 104 ? 256 : 512))
         return finc_conv_kernel<CQP, KH, KW, NW, true>;
     else return nullptr;
 }

@@ -64,3 +64,11 @@ def test_hot_kernels_of_the_bench_shapes_do_not_spill():
         assert hits, pat
         for k, v in hits.items():
             assert v["vgpr_spills"] == 0 and v["scratch"] == 0, (k, v)
+
+
+def test_no_kernel_spills_registers():
+    """A spill in a strip-walk or wavefront kernel costs scratch traffic every step (<28,3,3> of the forward ran 1.9x slower
+    with 27 spilled registers until its occupancy hint was fixed: profiles/r02/notes/ab34)."""
+    md = kernel_metadata()
+    bad = {k: v for k, v in md.items() if v["vgpr_spills"] or v["sgpr_spills"]}
+    assert not bad, bad
