@@ -65,9 +65,12 @@ constexpr int conv_nreg()
 // single-wave workgroups ask for that register budget when the bank leaves room for the working set (a 252-fragment
 // bank squeezed into 256 registers spills: 10x slower; the 111 registers of <28,3,3> beside the dword form's working set
 // spill 27: 517 vs 269 us at B=128, profiles/r02/notes/ab34); the K-split variants keep theirs (their waves are many).
+#ifndef FINC_CONV_2W_MAX   // largest bank (registers) that still asks for two waves per SIMD
+#define FINC_CONV_2W_MAX 104
+#endif
 template <int CQP, int KH, int KW, int NW, bool WIDE>
 __global__ __launch_bounds__(64 * NW)
-    __attribute__((amdgpu_waves_per_eu(NW == 1 && conv_nreg<CQP, KH, KW, NW>() <= 104 ? 2 : 1))) void finc_conv_kernel(const float *__restrict__ in,
+    __attribute__((amdgpu_waves_per_eu(NW == 1 && conv_nreg<CQP, KH, KW, NW>() <= FINC_CONV_2W_MAX ? 2 : 1))) void finc_conv_kernel(const float *__restrict__ in,
                                                             const float *__restrict__ packed, float *__restrict__ out,
                                                             int G, int CQ, int H, int W, int NS, int RC,
                                                             unsigned orient)
@@ -566,7 +569,7 @@ constexpr conv_fn wide_fn()
     // the staged form holds KH+1 row slots of operands and its pieces in flight: only where that fits beside the bank
     // (<16,5,5> would spill inside the 256 registers of two waves per SIMD; <28,3,3> and <32,3,3> run one wave per SIMD)
     constexpr int NREG = conv_nreg<CQP, KH, KW, NW>();
-    if constexpr (NW == 1 && KW <= 5 && NREG + (KH + 1) * KW * (CQP / 4) + 64 <= (NREG <= 104 ? 256 : 512))
+    if constexpr (NW == 1 && KW <= 5 && NREG + (KH + 1) * KW * (CQP / 4) + 64 <= (NREG <= FINC_CONV_2W_MAX ? 256 : 512))
         return finc_conv_kernel<CQP, KH, KW, NW, true>;
     else return nullptr;
 }
@@ -582,7 +585,7 @@ const ConvInst g_conv[] = {
     make_conv<24, 3, 3>(), make_conv<28, 3, 3>(), make_conv<32, 3, 3>(), make_conv<40, 3, 3, 2>(), make_conv<48, 3, 3, 2>(), make_conv<64, 3, 3, 4>(),
     make_conv<4, 2, 2>(),  make_conv<8, 2, 2>(),  make_conv<12, 2, 2>(), make_conv<16, 2, 2>(), make_conv<24, 2, 2>(),
     make_conv<32, 2, 2>(),
-    make_conv<4, 5, 5>(),  make_conv<8, 5, 5>(),  make_conv<12, 5, 5>(), make_conv<16, 5, 5>(), make_conv<48, 5, 5, 4>(),
+    make_conv<4, 5, 5>(),  make_conv<8, 5, 5>(),  make_conv<12, 5, 5>(), make_conv<16, 5, 5>(), make_conv<32, 5, 5, 4>(), make_conv<48, 5, 5, 4>(),
     make_conv<4, 3, 5>(),  make_conv<4, 1, 3>(),  make_conv<4, 3, 1>(),
 };
 const ConvInst *find_conv(int Cq, int KH, int KW)

@@ -270,7 +270,8 @@ def test_ragged_and_degenerate_shapes(shape, dev):
         assert rel_err(ops.finc_forward(t(z, dev), wc, algo=algo).cpu().numpy(), oracle.forward_f32(z, wco)) <= TOL
 
 
-@pytest.mark.parametrize("shape", [(2, 192, 20, 24, 3), (1, 192, 9, 40, 5), (2, 192, 32, 32, 5)])
+@pytest.mark.parametrize("shape", [(2, 192, 20, 24, 3), (1, 192, 9, 40, 5), (2, 192, 32, 32, 5), (2, 128, 12, 32, 5), (1, 128, 7, 21, 5),
+                                   (1, 160, 8, 32, 3), (1, 256, 6, 16, 3)])
 def test_ksplit_forward_and_grad_input(shape, dev):
     """Cq=48: the filter bank does not fit one wave, the strip kernel splits K over 2 (3x3) / 4 (5x5) waves and
     reduces through LDS.  Forward and grad-input against the oracle / its transpose identity."""
