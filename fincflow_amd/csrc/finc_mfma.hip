@@ -1505,6 +1505,19 @@ const Inst *find_inst(int Cq, int KH, int KW, long long problems = -1, int W = 0
             const int P = W < 16 ? W : 16;
             if (lds_bytes(i, W, P) > 160 * 1024) continue;
         }
+        // Wide maps: the band hand-over FIFO grows with W, and once four one-wave problems no longer fit a CU's LDS (W >= 80
+        // at Cq = 24) the helper-wave form is out and only three SIMDs of a CU have a problem.  The packed two-wave form
+        // -- two problems per workgroup, every SIMD busy -- is then the faster one at ANY problem count (B = 256:
+        // 64x80 1,033 -> 764 us, 64x96 1,225 -> 903, 128x128 3,163 -> 2,302; profiles/r02/notes/ab36), although it loses
+        // at 64x64 where four one-wave problems do fit (521 vs 413 us).
+        if (problems >= 0 && W > 0 && i.nw == 1 && i.npw == 1) {
+            const int P = W < 16 ? W : 16;
+            if (4 * lds_bytes(i, W, P) + 64 > 160 * 1024 && problems % 2 == 0) {
+                for (const Inst &k : g_insts)
+                    if (k.cqp == cqp && k.kh == KH && k.kw == KW && k.nw == 2 && k.npw == 2 && lds_bytes(k, W, P) <= 160 * 1024)
+                        return &k;
+            }
+        }
         return &i;
     }
     return nullptr;

@@ -108,6 +108,20 @@ def test_variant_plan_covers_every_row_and_agrees_with_the_library():
     assert _lib.inverse_variant(2, 4, 24, 16, 15, 3, 3) is None          # W % 4 != 0: strict kernel
 
 
+def test_wide_maps_take_the_packed_two_wave_form():
+    """finc_mfma.hip find_inst: once four one-wave problems do not fit a CU's LDS (the band hand-over FIFO grows with W) the
+    packed two-wave form is chosen at any problem count; at 64x64 and below nothing changes (host-side call, no GPU)."""
+    from fincflow_amd import _lib
+    v = _lib.inverse_variant(256, 4, 24, 64, 64, 3, 3)
+    assert (v["nw"], v["npw"], v["sec"]) == (1, 1, 3)                       # helper waves: four problems per workgroup
+    for H, W in ((64, 80), (64, 96), (128, 128), (64, 72)):
+        v = _lib.inverse_variant(256, 4, 24, H, W, 3, 3)
+        assert (v["nw"], v["npw"]) == (2, 2) and v["lds_bytes"] <= 160 * 1024, (H, W, v)
+    assert _lib.inverse_variant(256, 4, 24, 64, 56, 3, 3)["nw"] == 1        # four problems still fit: one wave each
+    assert _lib.inverse_variant(131, 1, 24, 8, 80, 3, 3)["nw"] == 3         # an odd count cannot be packed in pairs
+    assert _lib.inverse_variant(256, 4, 28, 64, 80, 3, 3)["nw"] == 1        # no two-wave row for this bank
+
+
 def test_kernel_attribute_table_is_keyed_by_device_and_kernel():
     """finc_mfma_launch sets the 160 KiB dynamic-LDS attribute once per (device, kernel) -- a per-thread or per-kernel-only
     cache would skip the second device of a process that drives two.  Key logic, host only."""

@@ -97,6 +97,16 @@ def test_every_row_of_the_instantiation_table(row, dev):
                              tag="variant_table", expect_row=row, expect_sec=sec)
 
 
+def test_wide_map_at_a_full_problem_count(dev):
+    """A map wider than 64 columns with more problems than the small-batch rows take: the packed two-wave form (find_inst's
+    LDS rule), against the oracle."""
+    e_max, _ = run_inverse_case(dev, 130, 4, ORIENT_FASTFLOW, 24, 5, 80, 3, 3, seed=4242, tag="wide_map")
+    from fincflow_amd import _lib
+    v = _lib.inverse_variant(130, 4, 24, 5, 80, 3, 3)
+    assert (v["nw"], v["npw"]) == (2, 2)
+    assert e_max <= 1e-5
+
+
 def test_c5_at_the_per_gpu_batch(dev):
     """BASELINE configs[4]: 5x5, C=192, 128x128 at the per-GPU batch of 64 (512 over 8 GPUs).  Forward and inverse of the
     whole batch on the K-split MFMA kernels; images 0, 31 and 63 against the oracle (fp64 solve / fp32 forward), the
