@@ -418,8 +418,9 @@ int finc_backward_f32(const float *grad_z, const float *x, const float *w_canon,
     // grad_w: MFMA strip kernel with the pixels on K + reduce (+ corner-tap mask)
     const size_t gwb = finc_gradw_workspace_bytes(s);
     if (grad_w_canon && workspace && gwb > 0 && workspace_bytes >= pk + gwb) {
-        if (int e = finc_gradw_launch(grad_z, x, grad_w_canon, (char *)workspace + pk, s, st)) return e;
-        grad_w_canon = nullptr;
+        const int e = finc_gradw_launch(grad_z, x, grad_w_canon, (char *)workspace + pk, s, st);
+        if (e == FINC_OK) grad_w_canon = nullptr;
+        else if (e != FINC_ERR_UNSUPPORTED) return e;       // (unsupported for THIS call, e.g. float-aligned views: the direct kernel below)
     }
     if (!grad_x && !grad_w_canon) return FINC_OK;
     return finc_launch_backward_generic(grad_z, x, w_canon, grad_x, grad_w_canon, s, st);

@@ -338,6 +338,145 @@ __global__ __launch_bounds__(64) void finc_gradw_staged_kernel(const float *__re
         }
 }
 
+// -----------------------------------------------------------------------------------------------
+// grad_w, tiled form: ONE 16x16 (o, i) tile pair per workgroup, for the banks whose NTAP * MT * MT accumulator tiles do not fit
+// one wave (Cq > 32 at 3x3, Cq > 16 at 5x5: until round 2 those ran on the direct kernel, 24 .. 78 ms per training step at
+// the c5 bank).  blockIdx = (((g * MTT + mo) * MTT + mi) * WPG + wslot); the wave stages only the 16 gz channels of tile mo
+// and the 16 x channels of tile mi (1 + 2 dwordx4 loads per row) and keeps NTAP accumulators.  A gz tile is read once per
+// mi and an x tile once per mo -- MTT times the minimum, out of L2.  Same partial layout, same reduce kernel.
+// -----------------------------------------------------------------------------------------------
+template <int KH, int KW>
+__global__ __launch_bounds__(64) void finc_gradw_tiled_kernel(const float *__restrict__ gz, const float *__restrict__ x,
+                                                              float *__restrict__ part, int G, int CQ, int H, int W, int NS,
+                                                              int B, int WPG, unsigned orient, int MTT)
+{
+    constexpr int NTAP = KH * KW, RS = KH + 1;
+    constexpr int XP = 24, GP = 20;
+    constexpr int NXI = 2;                                              // 16 channels x (4 pieces + the halo piece) = 80 load slots
+    static_assert(KW <= 5, "the halo is one 16-byte piece");
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    __shared__ __attribute__((aligned(16))) float xt[16 * XP + 4];
+    __shared__ __attribute__((aligned(16))) float gt[16 * GP + 4];
+    const int lane = threadIdx.x;
+    const int q = lane >> 4, m = lane & 15;
+    int bi = blockIdx.x;
+    const int wslot = bi % WPG; bi /= WPG;
+    const int mi = bi % MTT; bi /= MTT;
+    const int mo = bi % MTT;
+    const int g = bi / MTT;
+    const unsigned o = finc_group_orient(orient, g);
+    const bool fh = (o & FINC_FLIP_H) != 0, fw = (o & FINC_FLIP_W) != 0;
+    const int HW = H * W;
+    const unsigned slab_bytes = (unsigned)CQ * (unsigned)HW * 4u;
+    const int cg = 16 * mo, cx = 16 * mi;                               // first channel of the gz tile / of the x tile
+
+    v4f acc[NTAP];
+#pragma unroll
+    for (int t = 0; t < NTAP; ++t) acc[t] = (v4f){0.f, 0.f, 0.f, 0.f};
+    int xrd[KW][4], grd[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+        const int c = 4 * kk + q;
+        grd[kk] = m * GP + (fw ? 15 - c : c);
+#pragma unroll
+        for (int bb = 0; bb < KW; ++bb) xrd[bb][kk] = m * XP + (fw ? 15 - (c - bb) : 4 + (c - bb));
+    }
+    for (int u = wslot; u < B * NS; u += WPG) {
+        const int b = u / NS, strip = u % NS;
+        const size_t slab = ((size_t)b * G + g) * CQ * HW;
+        auto rsrc = [&](const float *base, bool ok) {
+            return __builtin_amdgcn_make_buffer_rsrc((void *)(base + slab), 0, ok ? (int)slab_bytes : 0, 0x00020000);
+        };
+        const int ms = fw ? W - 16 - strip * 16 : strip * 16;
+        const int hm = fw ? ms + 16 : ms - 4;
+        unsigned lvx[NXI], lvg;
+        int lwx[NXI], lwg;
+#pragma unroll
+        for (int i = 0; i < NXI; ++i) {
+            const int t = 64 * i + lane;
+            lvx[i] = OFF_BAD_CHANNEL;
+            lwx[i] = 16 * XP;                                           // scratch piece behind the tile
+            if (t < 64) {
+                const int c = t >> 2, k = t & 3;
+                if (cx + c < CQ) lvx[i] = (unsigned)(cx + c) * HW * 4u + (unsigned)(ms + 4 * k) * 4u;
+                lwx[i] = c * XP + (fw ? 0 : 4) + 4 * k;
+            } else if (t < 80) {
+                const int c = t - 64;
+                if (cx + c < CQ && hm >= 0 && hm < W) lvx[i] = (unsigned)(cx + c) * HW * 4u + (unsigned)hm * 4u;
+                lwx[i] = c * XP + (fw ? 16 : 0);
+            }
+        }
+        {
+            const int c = lane >> 2, k = lane & 3;
+            lvg = cg + c < CQ ? (unsigned)(cg + c) * HW * 4u + (unsigned)(ms + 4 * k) * 4u : OFF_BAD_CHANNEL;
+            lwg = c * GP + 4 * k;
+        }
+        auto rowbytes = [&](int h) { return (unsigned)((fh ? H - 1 - h : h) * W) * 4u; };
+        v4u LX[2][NXI], LG[2];                                          // pieces in flight, two rows ahead, by row parity
+        auto issue = [&](auto par_c, int h) {
+            constexpr int PAR = decltype(par_c)::value;
+            const bool ok = h >= 0 && h < H;
+            const __amdgpu_buffer_rsrc_t rx = rsrc(x, ok), rg = rsrc(gz, ok);
+            const unsigned ro = ok ? rowbytes(h) : 0u;
+#pragma unroll
+            for (int i = 0; i < NXI; ++i) LX[PAR][i] = __builtin_amdgcn_raw_buffer_load_b128(rx, lvx[i], ro, 0);
+            LG[PAR] = __builtin_amdgcn_raw_buffer_load_b128(rg, lvg, ro, 0);
+        };
+        float GA[2][4];
+        float XB[RS][KW][4];
+#pragma unroll
+        for (int sl = 0; sl < RS; ++sl)
+#pragma unroll
+            for (int bb = 0; bb < KW; ++bb)
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) XB[sl][bb][kk] = 0.f;
+        auto stage = [&](auto sn_c, auto pn_c, int row) {
+            constexpr int SN = decltype(sn_c)::value, PN = decltype(pn_c)::value;
+#pragma unroll
+            for (int i = 0; i < NXI; ++i) reinterpret_cast<v4u *>(xt)[lwx[i] >> 2] = LX[PN][i];
+            reinterpret_cast<v4u *>(gt)[lwg >> 2] = LG[PN];
+            issue(IC<PN>{}, row + 2);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                GA[PN][kk] = gt[grd[kk]];
+#pragma unroll
+                for (int bb = 0; bb < KW; ++bb) XB[SN][bb][kk] = xt[xrd[bb][kk]];
+            }
+        };
+        auto step = [&](auto i_c, int h) {
+            constexpr int I = decltype(i_c)::value;
+            constexpr int SC = I % RS, PC = I & 1;
+            stage(IC<(I + 1) % RS>{}, IC<PC ^ 1>{}, h + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int a = 0; a < KH; ++a)
+#pragma unroll
+                for (int bb = 0; bb < KW; ++bb)
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk)
+                        acc[a * KW + bb] = __builtin_amdgcn_mfma_f32_16x16x4f32(GA[PC][kk], XB[(SC + RS - a) % RS][bb][kk], acc[a * KW + bb], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        issue(IC<0>{}, 0);
+        issue(IC<1>{}, 1);
+        stage(IC<0>{}, IC<0>{}, 0);
+        constexpr int UN = (RS % 2 == 0) ? RS : 2 * RS;
+        for (int h0 = 0; h0 < H; h0 += UN) {
+            [&]<int... I>(std::integer_sequence<int, I...>) {
+                ((h0 + I < H ? step(IC<I>{}, h0 + I) : (void)0), ...);
+            }(std::make_integer_sequence<int, UN>{});
+        }
+    }
+    float *dst = part + ((size_t)(g * WPG + wslot) * (NTAP * MTT * MTT)) * 256 + lane;
+#pragma unroll
+    for (int t = 0; t < NTAP; ++t) {
+        const v4f v = acc[t];
+        const float v0 = v.x, v1 = v.y, v2 = v.z, v3 = v.w;
+        float *d = dst + (size_t)((t * MTT + mo) * MTT + mi) * 256;
+        d[0] = v0; d[64] = v1; d[128] = v2; d[192] = v3;
+    }
+}
+
 // gw[g][o][i][kh][kw] = sum over the WPG partials; D layout: lane (q,n), reg r -> o = 16mo+4q+r, i = 16mi+n.
 // A block of 256 threads owns 32 consecutive entries; its 8 thread groups sum 8 interleaved slices of the partials
 // (w = j, j+8, ...) and the slices meet in LDS in a FIXED order: 8x the loads in flight of one thread per entry, and
@@ -369,11 +508,13 @@ __global__ __launch_bounds__(256) void gradw_reduce_kernel(const float *__restri
 }
 
 typedef void (*gradw_fn)(const float *, const float *, float *, int, int, int, int, int, int, int, unsigned);
+typedef void (*gradw_tiled_fn)(const float *, const float *, float *, int, int, int, int, int, int, int, unsigned, int);
 struct GradwInst {
     int cqp, kh, kw;
     int mtg;            // ceil(Cq/16) tiles in both dimensions of the partial layout
     gradw_fn gw;        // dword loads, any W (nullptr: NTAP*MT*MT accumulators would not fit)
     gradw_fn gw_staged; // W % 16 == 0, 16-byte aligned activations (nullptr: none)
+    gradw_tiled_fn gw_tiled;   // one (o, i) tile pair per workgroup, same conditions: for the banks gw cannot hold (nullptr: KW > 5)
 };
 template <int CQP, int KH, int KW>
 constexpr gradw_fn gradw_staged_fn()
@@ -389,8 +530,10 @@ template <int CQP, int KH, int KW>
 constexpr GradwInst make_gradw()
 {
     constexpr int MTG = (CQP + 15) / 16;
-    if constexpr (KH * KW * MTG * MTG * 4 <= 200) return GradwInst{CQP, KH, KW, MTG, finc_gradw_kernel<CQP, KH, KW>, gradw_staged_fn<CQP, KH, KW>()};
-    else return GradwInst{CQP, KH, KW, MTG, nullptr, nullptr};
+    if constexpr (KH * KW * MTG * MTG * 4 <= 200)
+        return GradwInst{CQP, KH, KW, MTG, finc_gradw_kernel<CQP, KH, KW>, gradw_staged_fn<CQP, KH, KW>(), nullptr};
+    else if constexpr (KW <= 5) return GradwInst{CQP, KH, KW, MTG, nullptr, nullptr, finc_gradw_tiled_kernel<KH, KW>};
+    else return GradwInst{CQP, KH, KW, MTG, nullptr, nullptr, nullptr};
 }
 // the (Cq, K) pairs of finc_conv.hip's table
 const GradwInst g_gradw[] = {
@@ -416,24 +559,47 @@ static int gradw_wpg(const FincShape &s)
     const int units = s.B * ((s.W + 15) / 16);
     return units < 256 ? units : 256;
 }
+// tiled form: G * MTT^2 * WPG workgroups of one wave; about two per SIMD
+static int gradw_wpg_tiled(const FincShape &s, int mtt)
+{
+    const int units = s.B * ((s.W + 15) / 16);
+    int w = 2048 / (s.G * mtt * mtt);
+    if (w < 1) w = 1;
+    if (w > 256) w = 256;
+    return units < w ? units : w;
+}
+static bool gradw_use_tiled(const GradwInst *i, const FincShape &s) { return i && !i->gw && i->gw_tiled && s.W % 16 == 0; }
 
 size_t finc_gradw_workspace_bytes(const FincShape &s)
 {
     const GradwInst *i = find_gradw(s.Cq, s.KH, s.KW);
-    if (!i || !i->gw || !finc_conv_supported(s.Cq, s.H, s.W, s.KH, s.KW)) return 0;
+    if (!i || !finc_conv_supported(s.Cq, s.H, s.W, s.KH, s.KW)) return 0;
+    if (gradw_use_tiled(i, s)) return (size_t)s.G * gradw_wpg_tiled(s, i->mtg) * s.KH * s.KW * i->mtg * i->mtg * 256 * sizeof(float);
+    if (!i->gw) return 0;
     return (size_t)s.G * gradw_wpg(s) * s.KH * s.KW * i->mtg * i->mtg * 256 * sizeof(float);
 }
 
+// FINC_ERR_UNSUPPORTED: no MFMA grad-weight kernel for this call (the caller falls back to the direct kernel)
 int finc_gradw_launch(const float *gz, const float *x, float *gw, void *workspace, const FincShape &s, hipStream_t st)
 {
     const GradwInst *i = find_gradw(s.Cq, s.KH, s.KW);
-    if (!i || !i->gw) return FINC_ERR_UNSUPPORTED;
-    const int NS = (s.W + 15) / 16, WPG = gradw_wpg(s);
-    static const bool no_staged = getenv("FINC_GRADW_NO_STAGED") != nullptr;   // experiment switch
+    if (!i) return FINC_ERR_UNSUPPORTED;
+    const int NS = (s.W + 15) / 16;
     const bool aligned16 = (((uintptr_t)gz | (uintptr_t)x) & 15) == 0;
-    const gradw_fn fn = (i->gw_staged && s.W % 16 == 0 && aligned16 && !no_staged) ? i->gw_staged : i->gw;
-    hipLaunchKernelGGL(fn, dim3(s.G * WPG), dim3(64), 0, st, gz, x, (float *)workspace, s.G, s.Cq, s.H, s.W, NS, s.B,
-                       WPG, s.orient);
+    int WPG;
+    if (gradw_use_tiled(i, s)) {
+        if (!aligned16) return FINC_ERR_UNSUPPORTED;
+        WPG = gradw_wpg_tiled(s, i->mtg);
+        hipLaunchKernelGGL(i->gw_tiled, dim3(s.G * i->mtg * i->mtg * WPG), dim3(64), 0, st, gz, x, (float *)workspace, s.G, s.Cq,
+                           s.H, s.W, NS, s.B, WPG, s.orient, i->mtg);
+    } else {
+        if (!i->gw) return FINC_ERR_UNSUPPORTED;
+        WPG = gradw_wpg(s);
+        static const bool no_staged = getenv("FINC_GRADW_NO_STAGED") != nullptr;   // experiment switch
+        const gradw_fn fn = (i->gw_staged && s.W % 16 == 0 && aligned16 && !no_staged) ? i->gw_staged : i->gw;
+        hipLaunchKernelGGL(fn, dim3(s.G * WPG), dim3(64), 0, st, gz, x, (float *)workspace, s.G, s.Cq, s.H, s.W, NS, s.B,
+                           WPG, s.orient);
+    }
     FINC_CHECK_LAUNCH();
     const int per = s.KH * s.KW * i->mtg * i->mtg * 256;
     const int blocks = per / 32;
@@ -442,4 +608,3 @@ int finc_gradw_launch(const float *gz, const float *x, float *gw, void *workspac
     FINC_CHECK_LAUNCH();
     return FINC_OK;
 }
-

@@ -299,7 +299,10 @@ def test_ksplit_forward_and_grad_input(shape, dev):
                                    # W % 16 == 0: the staged form (16-byte pieces through LDS; 4-row blocks behind the last full 16)
                                    (3, 96, 10, 16, 3), (2, 48, 9, 32, 3), (2, 64, 7, 48, 3), (2, 80, 6, 32, 3), (2, 16, 9, 16, 3),
                                    (2, 32, 8, 32, 5), (2, 48, 6, 16, 5), (2, 92, 8, 32, 3), (3, 128, 5, 16, 3), (2, 96, 8, 32, 2),
-                                   (5, 96, 1, 16, 3), (1, 96, 2, 64, 3)])
+                                   (5, 96, 1, 16, 3), (1, 96, 2, 64, 3),
+                                   # banks whose accumulator tiles do not fit one wave: one (o, i) tile pair per workgroup
+                                   (2, 192, 6, 32, 3), (1, 192, 5, 16, 5), (2, 128, 6, 32, 5), (2, 160, 5, 32, 3), (1, 256, 4, 16, 3),
+                                   (3, 188, 4, 48, 3)])
 def test_grad_weight_mfma(shape, dev):
     """grad_w on the MFMA strip kernel (pixels on K) + reduce + corner-tap mask.  Pinned by linearity in the weights:
     <grad_w, dW> == <gz, forward(x; dW)> for any bank dW whose masked entries are zero, and against the direct
