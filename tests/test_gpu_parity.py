@@ -302,7 +302,9 @@ def test_ksplit_forward_and_grad_input(shape, dev):
                                    (5, 96, 1, 16, 3), (1, 96, 2, 64, 3),
                                    # banks whose accumulator tiles do not fit one wave: one (o, i) tile pair per workgroup
                                    (2, 192, 6, 32, 3), (1, 192, 5, 16, 5), (2, 128, 6, 32, 5), (2, 160, 5, 32, 3), (1, 256, 4, 16, 3),
-                                   (3, 188, 4, 48, 3)])
+                                   (3, 188, 4, 48, 3),
+                                   # more (image, strip) units than waves per group: a wave walks several units in a row
+                                   (130, 96, 2, 32, 3), (30, 192, 3, 32, 3), (140, 48, 3, 24, 3)])
 def test_grad_weight_mfma(shape, dev):
     """grad_w on the MFMA strip kernel (pixels on K) + reduce + corner-tap mask.  Pinned by linearity in the weights:
     <grad_w, dW> == <gz, forward(x; dW)> for any bank dW whose masked entries are zero, and against the direct
