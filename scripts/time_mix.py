@@ -13,7 +13,10 @@ def timeit(fn, n=50):
     for _ in range(n): fn()
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / n * 1e3
-for (B, C, H, W) in ((256, 96, 64, 64), (64, 48, 32, 32), (64, 192, 128, 128), (128, 12, 16, 16), (256, 96, 63, 63)):
+SHAPES = ((256, 96, 64, 64), (64, 48, 32, 32), (64, 192, 128, 128), (128, 12, 16, 16), (256, 96, 63, 63))
+if len(sys.argv) > 1 and sys.argv[1] == "sweep":   # every channel count of the kernel's table at a chip-filling size
+    SHAPES = tuple((max(8, 4096 // C) * 8, C, 64, 64) for C in (4, 8, 12, 16, 24, 32, 48, 64, 96, 128, 192))
+for (B, C, H, W) in SHAPES:
     x = torch.randn(B, C, H, W, device=dev); M = torch.randn(C, C, device=dev) / C ** 0.5; b = torch.randn(C, device=dev)
     o = torch.empty_like(x)
     t = timeit(lambda: ops.finc_mix(x, M, b, out=o))
