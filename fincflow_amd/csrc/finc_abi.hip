@@ -232,8 +232,9 @@ static int run(const float *in, const float *w_canon, float *out, int B, int G, 
     }
     if (algo == FINC_ALGO_AUTO) {
         algo = forward ? finc_forward_algo_for(Cq, H, W, KH, KW) : finc_inverse_algo_for(Cq, H, W, KH, KW);
-        // the MFMA inverse moves 16-byte pieces: activations that are only 4-byte aligned take the strict kernel
-        if (!forward && algo == FINC_ALGO_MFMA && ((((uintptr_t)in) | ((uintptr_t)out)) & 15u)) algo = FINC_ALGO_STRICT;
+        // the wavefront kernel moves aligned 16-byte pieces: activations that are only 4-byte aligned take the strict kernel
+        // (the role-split kernel of small problem sets has no alignment rule)
+        if (!forward && algo == FINC_ALGO_MFMA && ((((uintptr_t)in) | ((uintptr_t)out)) & 15u) && !finc_split_takes(s)) algo = FINC_ALGO_STRICT;
     }
     if (algo == FINC_ALGO_STRICT)
         return forward ? finc_launch_forward_generic(in, w_canon, out, s, st)

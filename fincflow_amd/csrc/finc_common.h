@@ -67,6 +67,14 @@ int finc_mfma_table_row(int row, int *info);
 // waits of the helper-wave protocol that ran out of their spin budget since the library was loaded (synchronous copy)
 int finc_mfma_hlp_timeouts(unsigned *count);
 
+// Cq padded as the packed bank of (Cq, KH, KW) has it, or 0 when the shape has no MFMA instantiation
+int finc_mfma_packed_cqp(int Cq, int KH, int KW);
+
+// ---- inverse for the under-filled chip, role-split kernel: finc_split.hip (same packed bank as the wavefront kernel) ----
+bool finc_split_takes(const FincShape &s);       // this problem set runs on the role-split kernel
+int finc_split_info(const FincShape &s, int *waves, int *lds_bytes, int *steps);
+int finc_split_launch(const float *in, const void *packed, float *out, const FincShape &s, hipStream_t st);
+
 // ---- forward / grad-input, MFMA strip kernel: finc_conv.hip ----
 bool finc_conv_supported(int Cq, int H, int W, int KH, int KW);
 size_t finc_conv_packed_bytes(int G, int Cq, int KH, int KW);

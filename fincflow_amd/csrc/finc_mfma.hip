@@ -1451,20 +1451,19 @@ constexpr Inst make_inst()
 #define FINC_BOTH(cqp, kh, kw) make_inst<cqp, kh, kw>()
 
 #ifdef FINC_ONLY_C3   // experiment builds (scripts/build_variant.sh): only the c3 kernels, compiles in seconds
-const Inst g_insts[] = {make_inst<24, 3, 3, 3, 1, 256>(), make_inst<24, 3, 3, 2, 2, 512>(), FINC_BOTH(24, 3, 3)};
+const Inst g_insts[] = {make_inst<24, 3, 3, 2, 2, 512>(), FINC_BOTH(24, 3, 3), FINC_BOTH(12, 3, 3)};
 #else
 const Inst g_insts[] = {
     // 3x3: every Cq % 4 == 0 up to 32, then K-split (2 / 4 waves per problem) for the banks one wave cannot hold.
     // Variants of one shape are tried in table order.  <24,3,3> first lists its small-batch variant: while the problems
     // number no more than the SIMD pairs of the chip (B*G <= 512), splitting each over 2 waves is 27 % faster
     // (289 vs 395 us at B <= 128); 2-wave problems are packed in pairs (NPW = 2) so that all four SIMDs of a CU get work.
-    // While they do not outnumber the CUs either (B*G <= 256, e.g. the 32 images a GPU gets when c3's batch is cut eight
-    // ways), three waves per problem -- two k-steps each -- are faster again: 306 -> 245 us at B = 8 .. 64 (six waves, one
-    // k-step each: 257 us; profiles/r02/notes/ab32).
-    // (Cq = 12, config 2: one k-step per wave while the problems do not outnumber the CUs: 54 -> 48 us at B = 64)
-    FINC_BOTH(4, 3, 3),  FINC_BOTH(8, 3, 3),  make_inst<12, 3, 3, 3, 1, 256>(), FINC_BOTH(12, 3, 3), FINC_BOTH(16, 3, 3),
+    // (While the problems do not outnumber the CUs -- B*G <= 256 -- the 2x2 and 3x3 banks up to Cq = 32 do not come here at
+    // all: they run on the role-split kernel, finc_split.hip.  Its predecessors in this table, three-wave K-splits of
+    // <24,3,3> and <12,3,3>, took 245 / 48 us at c3 / c2 where it takes 165 / 2x us: profiles/r03.)
+    FINC_BOTH(4, 3, 3),  FINC_BOTH(8, 3, 3),  FINC_BOTH(12, 3, 3), FINC_BOTH(16, 3, 3),
     FINC_BOTH(20, 3, 3),
-    make_inst<24, 3, 3, 3, 1, 256>(), make_inst<24, 3, 3, 2, 2, 512>(), FINC_BOTH(24, 3, 3), FINC_BOTH(28, 3, 3),
+    make_inst<24, 3, 3, 2, 2, 512>(), FINC_BOTH(24, 3, 3), FINC_BOTH(28, 3, 3),
     // Cq = 32: one wave's rings (53 KB at W = 64) let only 2 problems onto a CU; split over 2 waves and packed in pairs
     // the same 2 problems keep all 4 SIMDs busy (1.25 -> 0.89 ms at B = 256, 64x64)
     make_inst<32, 3, 3, 2, 2>(), FINC_BOTH(32, 3, 3),
@@ -1559,6 +1558,12 @@ bool finc_mfma_supported(int Cq, int H, int W, int KH, int KW)
     return true;
 }
 
+int finc_mfma_packed_cqp(int Cq, int KH, int KW)
+{
+    const Inst *a = find_inst(Cq, KH, KW);
+    return a ? a->cqp : 0;
+}
+
 size_t finc_mfma_packed_bytes(int G, int Cq, int KH, int KW)
 {
     const Inst *a = find_inst(Cq, KH, KW);
@@ -1582,6 +1587,14 @@ int finc_mfma_variant(int B, int G, int Cq, int H, int W, int KH, int KW, int *i
     const Inst *i = find_inst(Cq, KH, KW, (long long)B * G, W);
     if (!i) return FINC_ERR_UNSUPPORTED;
     const int P = W < 16 ? W : 16;
+    const FincShape fs{B, G, Cq, H, W, KH, KW, 0};
+    if (finc_split_takes(fs)) {                // form 4: the role-split kernel, one workgroup of info[1] waves per problem
+        int waves = 0, lds = 0, steps = 0;
+        if (int e = finc_split_info(fs, &waves, &lds, &steps)) return e;
+        info[0] = i->cqp; info[1] = waves; info[2] = 1; info[3] = 4; info[4] = lds; info[5] = B * G;
+        info[6] = -1; info[7] = (int)(sizeof(g_insts) / sizeof(g_insts[0]));
+        return FINC_OK;
+    }
     info[0] = i->cqp;
     info[1] = i->nw;
     info[2] = i->npw;
@@ -1607,6 +1620,7 @@ int finc_mfma_table_row(int row, int *info)
 int finc_mfma_launch(const float *in, const void *packed, float *out, const FincShape &s, hipStream_t st)
 {
     if (!finc_mfma_supported(s.Cq, s.H, s.W, s.KH, s.KW)) return FINC_ERR_UNSUPPORTED;
+    if (finc_split_takes(s)) return finc_split_launch(in, packed, out, s, st);   // the under-filled chip (finc_split.hip)
     const Inst *i = find_inst(s.Cq, s.KH, s.KW, (long long)s.B * s.G, s.W);
     if (!i) return FINC_ERR_UNSUPPORTED;
     if (((uintptr_t)in & 15u) || ((uintptr_t)out & 15u)) return FINC_ERR_ALIGNMENT;

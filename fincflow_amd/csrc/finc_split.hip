@@ -1,0 +1,627 @@
+// Role-split inverse for the UNDER-FILLED chip (gfx950 / CDNA4 only): B*G problems that do not outnumber the compute
+// units a few times over (c2; c3 at the batch a GPU gets when 256 images are split 4 or 8 ways; the c4 units).
+//
+// There the wavefront kernel (finc_mfma.hip) is bound by the LENGTH OF A STEP, not by throughput: a problem is a chain of
+// NB*W + P - 1 dependent steps (the reference's anti-diagonal order, cinc_cuda_kernel_level2.cu:49-56,98-111, band by
+// band), and a step of one wave is its whole instruction stream -- 162 MFMAs at c3 although only the 36 of the two taps
+// with a + b == 1 need the pixel solved in the previous step.  Splitting the reduction over waves (K-split) shortens the
+// MFMA part but adds an exchange and two barriers to every step of every wave: 0.9 us per step whatever the split
+// (profiles/r03/notes/band_pipeline.md).  So the step is split BY DEPENDENCE instead:
+//
+//   wave 0 ("A")     carries the recurrence and nothing else: acc = prepared part + taps (0,1) and (1,0) applied to the
+//                    pixel of the previous step (registers / DPP row_shr:1, as in the wavefront kernel), pack, publish the
+//                    pixel in the x ring (LDS) and the hand-over FIFO.
+//   waves 1..NBW ("B") prepare, ONE STEP AHEAD, everything that does not need the newest pixel: Linv*z (+ the folded
+//                    bias) and the taps with a + b >= 2, shared out tap by tap.  Their operands are older pixels read
+//                    straight from the x ring -- S_a(tau) is the ring slot of step tau at lane p - a, the rows of the
+//                    band above (lanes p < a) come from the FIFO -- so they keep no operand history at all.  Each leaves
+//                    its partial accumulators in LDS; A adds them up.  The B waves also own the HBM side: one loads z
+//                    (dword per lane and k-step, PF steps ahead), one stores the pixels a step after they were solved.
+//
+// One workgroup barrier per step keeps the four waves in lockstep: what B reads in step t was written in step t-1 or
+// earlier, what A reads in step t was written by B in step t-1 (the partial buffers alternate with the parity of the
+// step).  A's step is 2*NK*MT MFMAs + pack + one LDS round trip + the barrier: ~1,000 cycles at c3 against ~2,200.
+//
+// Same packed bank as the wavefront kernel (finc_mfma_pack), same lanes (lane p owns the rows p, P+p, ... and trails
+// lane p-1 by one step), same arithmetic (exact fp32 MFMA; only the order in which the partial sums of a pixel are added
+// differs).  Any Cq <= CQP (padded channels are masked per k-step) and any W (dword I/O: no alignment rule).
+#include "finc_common.h"
+#include "finc_tile.h"
+
+#include <stdlib.h>
+
+#include <type_traits>
+#include <utility>
+
+namespace {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+constexpr unsigned OFF_INVALID = 0x80000000u;     // voffset beyond any slab: buffer loads return 0, stores are dropped
+constexpr unsigned OFF_BAD_CHANNEL = 0x40000000u;  // added to a valid offset it still lands beyond the slab (< 1 GiB)
+
+template <int I>
+using IC = std::integral_constant<int, I>;
+#define FINC_SB() __builtin_amdgcn_sched_barrier(0)
+
+// channel held by k-slot q of register j of a solved pixel (finc_mfma.hip chan_d: the D layout of the 16-row tiles, then one
+// register per reduced 4-row block)
+__host__ __device__ inline int chan_d(int MTB, int j, int q)
+{
+    if (j < 4 * MTB) return 16 * (j >> 2) + 4 * q + (j & 3);
+    return 16 * MTB + 4 * (j - 4 * MTB) + q;
+}
+
+__device__ inline float row_shr1(float old, float src)   // lane i of each 16-lane row <- lane i-1; lane 0 keeps `old`
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, src),
+                                                                 0x111, 0xf, 0xf, false));
+}
+
+// the taps B prepares (a + b >= 2), ordered by a + b (then row-major): the taps with a + b == 2 come first -- they are the
+// only ones that need the pixel solved in the step before, so shared out round-robin every B wave gets one of them
+template <int KH, int KW>
+struct BTaps {
+    static constexpr int count()
+    {
+        int n = 0;
+        for (int a = 0; a < KH; ++a)
+            for (int b = 0; b < KW; ++b) n += (a + b >= 2);
+        return n;
+    }
+    static constexpr int find(int i, bool want_a)
+    {
+        for (int sum = 2; sum <= KH + KW - 2; ++sum)
+            for (int a = 0; a < KH; ++a)
+                for (int b = 0; b < KW; ++b)
+                    if (a + b == sum && i-- == 0) return want_a ? a : b;
+        return 0;
+    }
+    static constexpr int a_of(int i) { return find(i, true); }
+    static constexpr int b_of(int i) { return find(i, false); }
+};
+
+#ifdef FINC_SPLIT_STAMP   // diagnostic build: busy cycles (barrier exit -> next barrier arrival) per wave of workgroup 0, summed over the steps
+__device__ unsigned long long finc_split_stamps[16];
+#define FINC_ST_BEGIN() unsigned long long st_b_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_b_)::"memory")
+#define FINC_ST_END()                                                                                                     \
+    do {                                                                                                                  \
+        unsigned long long st_e_;                                                                                         \
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_e_)::"memory");             \
+        st_busy += st_e_ - st_b_;                                                                                         \
+    } while (0)
+#else
+#define FINC_ST_BEGIN() do { } while (0)
+#define FINC_ST_END() do { } while (0)
+#endif
+
+constexpr int XSLOTS = 8;        // x ring: the pixels of the last 8 steps (taps reach back KH + KW - 2 <= 8 steps)
+constexpr int JSTRIDE = 2048;    // bytes between the k-steps of the x ring (8 slots x 64 lanes) AND of the FIFO: one immediate
+constexpr int ZJSTRIDE = 3072;   // bytes between the k-steps of the z ring (12 slots x 64 lanes)
+constexpr int UNROLL = 8;        // steps per iteration of the B waves' loop: two I/O windows (the in-flight sets alternate)
+
+template <int CQP, int KH, int KW, int NBW>
+struct SCfg {
+    static constexpr int MTB = CQP / 16, NSM = (CQP % 16) / 4, MT = MTB + NSM, NK = CQP / 4, NTAP = KH * KW;
+    static constexpr int NCH = BTaps<KH, KW>::count();
+    static constexpr int JS = 4 * (KH - 1);                       // FIFO: floats per slot and k-step (4 k-slots x (KH-1) lanes)
+    static constexpr int NPACK = (NK + (NTAP - 1) * NK) * MT + 8 * MT;   // finc_mfma.hip Cfg::NPACK (NW = 1)
+    // LDS (bytes): x ring | FIFO | z ring | partial accumulators [parity][B wave][tile][lane] (v4f)
+    static constexpr int RING_B = 0, FIFO_B = NK * JSTRIDE, ZR_B = 2 * NK * JSTRIDE, PART_B = ZR_B + NK * ZJSTRIDE;
+    static constexpr int LDS_BYTES = PART_B + 2 * NBW * MT * 1024;
+    static_assert(KH + KW - 2 <= XSLOTS, "the x ring must reach back to the farthest tap");
+    // k-steps whose z a B wave loads and whose z-term it adds; registers of the solved pixel it stores
+    static constexpr int jlo(int bi) { return bi * NK / NBW; }
+    static constexpr int jhi(int bi) { return (bi + 1) * NK / NBW; }
+};
+
+// -----------------------------------------------------------------------------------------------
+// grid = B*G workgroups of (1 + NBW) waves.  W % 4 == 0 (16-byte pieces), DF * JS * 4 <= JSTRIDE.
+// -----------------------------------------------------------------------------------------------
+template <int CQP, int KH, int KW, int NBW>
+__global__ __launch_bounds__(64 * (1 + NBW)) void finc_split_kernel(const float *__restrict__ in, const float *__restrict__ packed,
+                                                                   float *__restrict__ out, int G, int CQ, int H, int W, int P,
+                                                                   int T, unsigned orient, int DF)
+{
+    using C = SCfg<CQP, KH, KW, NBW>;
+    constexpr int MT = C::MT, MTB = C::MTB, NK = C::NK, NCH = C::NCH, JS = C::JS;
+    using BT = BTaps<KH, KW>;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    char *const ldsb = reinterpret_cast<char *>(lds);
+    const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // 0: A, 1..NBW: B
+    const int lane = threadIdx.x & 63;
+    const int q = lane >> 4, p = lane & 15;
+    const int bg = blockIdx.x, g = bg % G;
+    const unsigned o = finc_group_orient(orient, g);
+    const bool fh = (o & FINC_FLIP_H) != 0, fw = (o & FINC_FLIP_W) != 0;
+    const int HW = H * W;
+    const unsigned slab_bytes = (unsigned)CQ * (unsigned)HW * 4u;
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)(in + (size_t)bg * CQ * HW), 0, (int)slab_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void *)(out + (size_t)bg * CQ * HW), 0, (int)slab_bytes, 0x00020000);
+
+    for (int i = threadIdx.x; i < C::LDS_BYTES / 4; i += 64 * (1 + NBW)) lds[i] = 0.f;
+
+    const float *pk = packed + (size_t)g * C::NPACK * 64 + lane;
+    auto frag_z = [&](int j, int mt) { return pk[(j * MT + mt) * 64]; };
+    auto frag_tap = [&](int a, int b, int j, int mt) { return pk[(NK * MT + ((a * KW + b - 1) * NK + j) * MT + mt) * 64]; };
+    auto ld = [&](int byte_off) { return *reinterpret_cast<const float *>(ldsb + byte_off); };
+    auto st = [&](int byte_off, float v) { *reinterpret_cast<float *>(ldsb + byte_off) = v; };
+
+    __syncthreads();
+
+    if (role == 0) {
+        // =================================== A: the recurrence ===================================
+        float f01[KW > 1 ? NK : 1][MT], f10[KH > 1 ? NK : 1][MT];
+#pragma unroll
+        for (int j = 0; j < NK; ++j)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                if constexpr (KW > 1) f01[j][mt] = frag_tap(0, 1, j, mt);
+                if constexpr (KH > 1) f10[j][mt] = frag_tap(1, 0, j, mt);
+            }
+        // (the empty asm makes the compiler wait for the loads HERE, not in the loop)
+#pragma unroll
+        for (int j = 0; j < NK; ++j)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                if constexpr (KW > 1) asm volatile("" : "+v"(f01[j][mt]));
+                if constexpr (KH > 1) asm volatile("" : "+v"(f10[j][mt]));
+            }
+        float q0[NK], q1[NK];                  // S_0(t-1) (masked at a row start) and S_1(t-1)
+#pragma unroll
+        for (int j = 0; j < NK; ++j) q0[j] = q1[j] = 0.f;
+        int ca = -p;                           // col of this lane at step t (negative: not started)
+        const bool pusher = KH > 1 && p >= P - (KH - 1) && p < P;
+        // byte addresses inside one k-step's block (the k-step is the instruction's immediate offset)
+        const int ring_w = C::RING_B + lane * 4;
+        const int push_w = C::FIFO_B + (q * (KH - 1) + (p - (P - (KH - 1)))) * 4;
+        const int pop_r = C::FIFO_B + (q * (KH - 1) + (KH - 2)) * 4;       // lane P-1 of the band above: S_1 of lane 0
+        const int part_r = C::PART_B + lane * 16;
+        // FIFO slots: the push of step s goes to slot s % DF; S_a(tau) of the lanes p < a is the push of step tau - (W - P)
+        int fpush = 0;
+        int fpop = ((-(W - P)) % DF + DF) % DF;
+        int tm = 0;                            // t % W
+        __syncthreads();                       // (iteration t = -1: the B waves prepare step 0)
+        unsigned long long st_busy = 0;
+        for (int t = 0; t <= T; ++t) {
+            FINC_ST_BEGIN();
+            const int par = t & 1, slot = t & (XSLOTS - 1);
+            float fv[NK];
+            if constexpr (KH > 1) {
+                if (W > P) {                   // (W == P: the pop is this very step's push -- below, after it)
+#pragma unroll
+                    for (int j = 0; j < NK; ++j) fv[j] = ld(pop_r + fpop * (JS * 4) + j * JSTRIDE);
+                }
+            }
+            // what the B waves prepared for this step: read now, added after the MFMAs (the round trip hides behind them)
+            v4f prep[NBW][MT];
+#pragma unroll
+            for (int i = 0; i < NBW; ++i)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    prep[i][mt] = *reinterpret_cast<const v4f *>(ldsb + part_r + ((par * NBW + i) * MT + mt) * 1024);
+            FINC_SB();                         // (the reads are issued here, not next to their uses)
+            // the (0,1) tap reads the pixel left of this one: none at a row start (scalar test: does any lane start a row?)
+            if constexpr (KW > 1) {
+                if (__builtin_expect(tm < P, 0)) {
+                    const bool rowstart = ca == 0;
+#pragma unroll
+                    for (int j = 0; j < NK; ++j) q0[j] = rowstart ? 0.f : q0[j];
+                }
+            }
+            v4f acc[MT];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = (v4f){0.f, 0.f, 0.f, 0.f};
+            // the MFMAs in a fixed order -- per k-step the tiles of one tap, then of the other, so that two MFMAs on the same
+            // accumulator are MT instructions apart (a 4x4x1 straight behind its predecessor on the same accumulator stalls) --
+            // and nothing else between them: the prepared part is added afterwards, when its LDS round trip is long over
+#pragma unroll
+            for (int j = 0; j < NK; ++j) {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    if constexpr (KW > 1) finc_mma<MTB>(acc[mt], mt, f01[j][mt], q0[j]);
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+                    if constexpr (KH > 1) finc_mma<MTB>(acc[mt], mt, f10[j][mt], q1[j]);
+                FINC_SB();
+            }
+            float xpk[NK];
+            {
+                v4f sum[MT];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    v4f r = prep[0][mt];
+#pragma unroll
+                    for (int i = 1; i < NBW; ++i) r += prep[i][mt];
+                    sum[mt] = acc[mt] + r;
+                }
+#pragma unroll
+                for (int mt = 0; mt < MTB; ++mt) {
+                    xpk[4 * mt + 0] = sum[mt].x; xpk[4 * mt + 1] = sum[mt].y; xpk[4 * mt + 2] = sum[mt].z; xpk[4 * mt + 3] = sum[mt].w;
+                }
+#pragma unroll
+                for (int sb = 0; sb < C::NSM; ++sb) xpk[4 * MTB + sb] = finc_block_reduce(sum[MTB + sb]);
+            }
+            if (__builtin_expect(t < P - 1 || P < 16, 0)) {                // a lane that has not started yields exact zeros
+                const bool started = ca >= 0 && p < P;
+#pragma unroll
+                for (int j = 0; j < NK; ++j) xpk[j] = started ? xpk[j] : 0.f;
+            }
+#pragma unroll
+            for (int j = 0; j < NK; ++j) st(ring_w + slot * 256 + j * JSTRIDE, xpk[j]);
+            if constexpr (KH > 1) {
+                if (pusher) {
+#pragma unroll
+                    for (int j = 0; j < NK; ++j) st(push_w + fpush * (JS * 4) + j * JSTRIDE, xpk[j]);
+                }
+                if (W == P) {
+#pragma unroll
+                    for (int j = 0; j < NK; ++j) fv[j] = ld(pop_r + fpop * (JS * 4) + j * JSTRIDE);
+                }
+#pragma unroll
+                for (int j = 0; j < NK; ++j) q1[j] = row_shr1(fv[j], xpk[j]);
+            }
+#pragma unroll
+            for (int j = 0; j < NK; ++j) q0[j] = xpk[j];
+            ++ca; if (ca == W) ca = 0;
+            ++tm; if (tm == W) tm = 0;
+            ++fpush; if (fpush == DF) fpush = 0;
+            ++fpop; if (fpop == DF) fpop = 0;
+            FINC_ST_END();
+            __syncthreads();
+        }
+#ifdef FINC_SPLIT_STAMP
+        if (blockIdx.x == 0 && lane == 0) { finc_split_stamps[0] = st_busy; finc_split_stamps[9] = T + 1; }
+#else
+        (void)st_busy;
+#endif
+        return;
+    }
+
+    // =================================== B: everything that can be prepared ===================================
+    // One copy of the code per B wave (`bi` is a compile-time constant inside): a step must not contain role branches.
+    auto run_b = [&](auto bi_c) {
+    constexpr int bi = decltype(bi_c)::value;
+    constexpr int JLO = C::jlo(bi), JHI = C::jhi(bi), NJ = JHI - JLO;      // this wave's share of the z-term, of the loads and stores
+    constexpr int NT = (NCH + NBW - 1 - bi) / NBW;                          // its taps: items bi, bi + NBW, ...
+    float fz[NJ > 0 ? NJ : 1][MT];
+    float ft[NT > 0 ? NT : 1][NK][MT];
+    v4f bias[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) bias[mt] = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) fz[j][mt] = finc_zterm_is_zero(MTB, JLO + j, mt) ? 0.f : frag_z(JLO + j, mt);
+    if constexpr (bi == 0) {                   // the folded affine map's shift: the accumulators' start, added once
+        const float *pb = packed + ((size_t)g * C::NPACK + (C::NPACK - 8 * MT)) * 64 + lane;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+            bias[mt] = (v4f){pb[(4 * mt + 0) * 64], pb[(4 * mt + 1) * 64], pb[(4 * mt + 2) * 64], pb[(4 * mt + 3) * 64]};
+    }
+    [&]<int... I>(std::integer_sequence<int, I...>) {
+        (([&] {
+#pragma unroll
+             for (int j = 0; j < NK; ++j)
+#pragma unroll
+                 for (int mt = 0; mt < MT; ++mt) ft[I][j][mt] = frag_tap(BT::a_of(bi + I * NBW), BT::b_of(bi + I * NBW), j, mt);
+         }()), ...);
+    }(std::make_integer_sequence<int, NT>{});
+    // every fragment load must have LANDED before the loop (the empty asm makes the compiler wait here): all VMEM
+    // instructions of the loop are inline asm that the kernel counts itself
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) asm volatile("" : "+v"(fz[j][mt]));
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) asm volatile("" : "+v"(bias[mt]));
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < NK; ++j)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) asm volatile("" : "+v"(ft[i][j][mt]));
+
+    // ---- HBM side: 16-byte pieces = groups of 4 canonical columns of one row; group gi of lane p covers its positions
+    // n = 4gi .. 4gi+3 (n = step - p).  In window w (steps 4w .. 4w+3) a lane reads z of the groups w+f and w+f+1,
+    // f = floor(-p / 4); it LANDS group w+f+2 (requested two windows earlier) into the z ring and REQUESTS group w+f+4.
+    // The ring holds 3 groups: 12 slots [slot][lane] per k-step, slot of position n = n mod 12; a W-flipped group is mirrored
+    // when it lands.  Stores: in window w the group w + fs, fs = floor((-3 - p) / 4) -- the last one whose four pixels are
+    // all in the x ring when the wave prepares step 4w + 2 (i.e. were solved by step 4w) -- is collected from the x ring (time
+    // slots) and leaves as one piece.
+    unsigned zmask[NJ > 0 ? NJ : 1], xmask[NJ > 0 ? NJ : 1];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        zmask[j] = (4 * (JLO + j) + q) < CQ ? (unsigned)((4 * (JLO + j) + q) * HW * 4) : OFF_BAD_CHANNEL;
+        xmask[j] = chan_d(MTB, JLO + j, q) < CQ ? (unsigned)(chan_d(MTB, JLO + j, q) * HW * 4) : OFF_BAD_CHANNEL;
+    }
+    const int f4 = -((p + 3) >> 2), fs4 = -((p + 3 + 3) >> 2);             // floor(-p / 4), floor((-3 - p) / 4)
+    const int dgrp = fw ? -16 : 16;                                        // bytes from a group to the next one of the row
+    const int drow = (fh ? -P : P) * W * 4 - (dgrp / 4) * W;               // ... and from the end of a row to the start of row + P
+    auto piece_off = [&](int row, int col0) { return ((fh ? H - 1 - row : row) * W + (fw ? W - 4 - col0 : col0)) * 4; };
+    // load walk: next group to request (starts at group f); store walk: next group to store (starts at group fs)
+    int lcol = 4 * f4, lrow = p, loff = piece_off(p, 0) + f4 * dgrp;
+    int scol = 4 * fs4, srow = p, soff = piece_off(p, 0) + fs4 * dgrp;
+    v4f zin[2][NJ > 0 ? NJ : 1];               // in flight: the set of window parity wp is requested in the windows of parity wp
+    auto zreq = [&](v4f (&dst)[NJ > 0 ? NJ : 1]) {
+        const bool ok = lcol >= 0 && lrow < H && p < P;
+        const unsigned base = ok ? (unsigned)loff : OFF_INVALID;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(dst[j]) : "v"(base + zmask[j]), "s"(rin) : "memory");
+        lcol += 4; loff += dgrp;
+        if (lcol == W) { lcol = 0; lrow += P; loff += drow; }
+    };
+    // landing: group gl (mod 3) -> slots 4*(gl % 3) + k; element k of the piece is canonical column k, or 3 - k when flipped
+    int gland = ((f4 % 3) + 3) % 3;            // ring group of the next landing
+    const int zr_w = C::ZR_B + lane * 4;
+    const int e0 = fw ? 3 : 0, e1 = fw ? 2 : 1, e2 = fw ? 1 : 2, e3 = fw ? 0 : 3;
+    auto zland = [&](v4f (&src)[NJ > 0 ? NJ : 1], auto vm_c) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(decltype(vm_c)::value) : "memory");
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) asm volatile("" : "+v"(src[j]));      // (ties the reads below to the wait)
+        const int base = zr_w + gland * 1024;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const float v0 = src[j].x, v1 = src[j].y, v2 = src[j].z, v3 = src[j].w;
+            st(base + e0 * 256 + (JLO + j) * ZJSTRIDE, v0);
+            st(base + e1 * 256 + (JLO + j) * ZJSTRIDE, v1);
+            st(base + e2 * 256 + (JLO + j) * ZJSTRIDE, v2);
+            st(base + e3 * 256 + (JLO + j) * ZJSTRIDE, v3);
+        }
+        gland = gland == 2 ? 0 : gland + 1;
+    };
+    // stores: element k of the group was solved at step 4gs + k + p: time slot ((p + k) & 7) ^ (4 * (gs & 1))
+    const int xs0 = C::RING_B + (((p + e0) & 7) * 64 + lane) * 4, xs1 = C::RING_B + (((p + e1) & 7) * 64 + lane) * 4;
+    const int xs2 = C::RING_B + (((p + e2) & 7) * 64 + lane) * 4, xs3 = C::RING_B + (((p + e3) & 7) * 64 + lane) * 4;
+    int stog = (fs4 & 1) * 1024;               // toggles with the group
+    auto xstore = [&]() {
+        const bool ok = scol >= 0 && srow < H && p < P;
+        const unsigned base = ok ? (unsigned)soff : OFF_INVALID;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            v4f v;
+            v.x = ld((xs0 ^ stog) + (JLO + j) * JSTRIDE);
+            v.y = ld((xs1 ^ stog) + (JLO + j) * JSTRIDE);
+            v.z = ld((xs2 ^ stog) + (JLO + j) * JSTRIDE);
+            v.w = ld((xs3 ^ stog) + (JLO + j) * JSTRIDE);
+            // (s_nop: a store of more than 8 bytes reads its data one wait state after issue, and the hazard recognizer does not
+            // see inline asm -- without it the next instruction may overwrite the data registers: measured, lanes 12-15 of one register)
+            asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" ::"v"(v), "v"(base + xmask[j]), "s"(rout) : "memory");
+        }
+        stog ^= 1024;
+        scol += 4; soff += dgrp;
+        if (scol == W) { scol = 0; srow += P; soff += drow; }
+    };
+    // prologue: groups f, f+1 land now (window 0 reads them), f+2 and f+3 wait in the two sets
+    if constexpr (NJ > 0) {
+        v4f tmp0[NJ], tmp1[NJ];
+        zreq(tmp0); zreq(tmp1); zreq(zin[0]); zreq(zin[1]);
+        zland(tmp0, IC<0>{}); zland(tmp1, IC<0>{});
+    }
+    // z read address: slot (n mod 12) of this lane
+    int zn = ((-p) % 12 + 12) % 12;
+
+    float vz[NJ > 0 ? NJ : 1], vt[NT > 0 ? NT : 1][NK];                    // operands (see bstep)
+    // S_a(u - a - b) of tap I for the step u: the x ring at lane p - a (lanes p >= a) / the FIFO (lanes p < a: the band above)
+    auto tap_read = [&](auto i_c, int u, int cbu, int fs2u) {
+        constexpr int I = decltype(i_c)::value;
+        constexpr int item = bi + I * NBW;
+        constexpr int a = BT::a_of(item), b = BT::b_of(item);
+        const int tau = u - a - b;
+        int fs = fs2u - (a + b - 2);           // slot of push step tau - (W - P)
+        if (fs < 0) fs += DF;
+        const int ring = C::RING_B + ((tau & (XSLOTS - 1)) * 64 + lane - a) * 4;
+        const int fifo = C::FIFO_B + (fs * JS + q * (KH - 1) + (KH - 1 - a + p)) * 4;
+        int addr = (a == 0 || p >= a) ? ring : fifo;
+        if constexpr (b > 0) addr = cbu >= b ? addr : C::FIFO_B + JSTRIDE - 4;   // (the zero word)
+#pragma unroll
+        for (int j = 0; j < NK; ++j) vt[I][j] = ld(addr + j * JSTRIDE);
+    };
+    int cb = 0 - p;                            // col of this lane at the step u being prepared (u = t + 1)
+    int fs2 = ((-2 - (W - P)) % DF + DF) % DF; // FIFO slot of S_a(tau) for tau = u - 2: push step tau - (W - P)
+    const int part_w = C::PART_B + lane * 16;
+    unsigned long long st_busy = 0;
+
+    // the operands of step u that are already in LDS one step early: z and the taps with a + b >= 3
+    auto prefetch = [&](int u) {
+        if constexpr (NJ > 0) {
+            const int za = zr_w + zn * 256;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) vz[j] = ld(za + (JLO + j) * ZJSTRIDE);
+        }
+        [&]<int... I>(std::integer_sequence<int, I...>) {
+            (([&] {
+                 constexpr int item = bi + I * NBW;
+                 if constexpr (BT::a_of(item) + BT::b_of(item) > 2) tap_read(IC<I>{}, u, cb, fs2);
+             }()), ...);
+        }(std::make_integer_sequence<int, NT>{});
+    };
+    prefetch(0);
+    auto bstep = [&](auto k_c, int t) {
+        constexpr int KU = decltype(k_c)::value;                            // u % UNROLL
+        constexpr int PH = KU & 3, WP = (KU >> 2) & 1;
+        FINC_ST_BEGIN();
+        const int u = t + 1;
+        constexpr int par = KU & 1;
+        v4f acc[MT];
+        // ---- HBM side of the window
+        if constexpr (NJ > 0 && PH == 0) {
+            // younger than the set that lands: the other set's requests (NJ) and the stores of the two windows in between
+            zland(zin[WP], IC<NJ + 2 * NJ>{});
+            zreq(zin[WP]);
+        }
+        if constexpr (NJ > 0 && PH == 2) xstore();
+        // ---- z-term (+ bias) of step u
+        if constexpr (bi == 0) {
+            if (__builtin_expect(u < P - 1 || P < 16, 0)) {
+                const bool started = cb >= 0 && p < P;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    const float b0 = bias[mt].x, b1 = bias[mt].y, b2 = bias[mt].z, b3 = bias[mt].w;
+                    acc[mt] = (v4f){started ? b0 : 0.f, started ? b1 : 0.f, started ? b2 : 0.f, started ? b3 : 0.f};
+                }
+            } else {
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) acc[mt] = bias[mt];
+            }
+        } else {
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) acc[mt] = (v4f){0.f, 0.f, 0.f, 0.f};
+        }
+        // ---- operands.  What does not need the pixel of the step before -- z and the taps with a + b >= 3 -- was read at the
+        // end of the previous step, BEFORE the barrier (vz / vt of those taps arrive as loop state); only the taps with
+        // a + b == 2 are read now, and their round trip hides behind the MFMAs of the others.  A tap's column mask (b > 0:
+        // column c - b must exist) is applied to the ADDRESS -- an invalid lane reads the zero word of the k-step's FIFO block
+        // -- so nothing stands between an LDS result and its MFMA.
+        [&]<int... I>(std::integer_sequence<int, I...>) {
+            (([&] {
+                 constexpr int item = bi + I * NBW;
+                 if constexpr (BT::a_of(item) + BT::b_of(item) == 2) tap_read(IC<I>{}, u, cb, fs2);
+             }()), ...);
+        }(std::make_integer_sequence<int, NT>{});
+        FINC_SB();
+        if constexpr (NJ > 0) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    if (finc_zterm_is_zero(MTB, JLO + j, mt)) continue;
+                    finc_mma<MTB>(acc[mt], mt, fz[j][mt], vz[j]);
+                }
+            FINC_SB();
+        }
+        // fixed order: the prefetched taps first, one k-step of all of them after the other (MFMAs on the same accumulator
+        // stay apart), then the taps read in this step
+        auto tap_pass = [&](auto pass_c) {
+            constexpr int PASS = decltype(pass_c)::value;
+#pragma unroll
+            for (int j = 0; j < NK; ++j) {
+                [&]<int... I>(std::integer_sequence<int, I...>) {
+                    (([&] {
+                         constexpr int item = bi + I * NBW;
+                         if constexpr ((BT::a_of(item) + BT::b_of(item) == 2) == (PASS == 1)) {
+#pragma unroll
+                             for (int mt = 0; mt < MT; ++mt) finc_mma<MTB>(acc[mt], mt, ft[I][j][mt], vt[I][j]);
+                         }
+                     }()), ...);
+                }(std::make_integer_sequence<int, NT>{});
+                FINC_SB();
+            }
+        };
+        tap_pass(IC<0>{});
+        tap_pass(IC<1>{});
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) *reinterpret_cast<v4f *>(ldsb + part_w + ((par * NBW + bi) * MT + mt) * 1024) = acc[mt];
+        ++cb; if (cb == W) cb = 0;
+        ++fs2; if (fs2 == DF) fs2 = 0;
+        zn = zn == 11 ? 0 : zn + 1;
+        prefetch(u + 1);
+        FINC_ST_END();
+        __syncthreads();
+    };
+    // iterations t = -1 .. T (u = t + 1 = 0 .. T + 1), unrolled by UNROLL: the host rounds T up so that T + 2 is a multiple of
+    // it (the extra steps solve rows below the image: nothing is stored)
+    for (int t0 = -1; t0 < T; t0 += UNROLL) {
+        [&]<int... K>(std::integer_sequence<int, K...>) { ((bstep(IC<K>{}, t0 + K)), ...); }(std::make_integer_sequence<int, UNROLL>{});
+    }
+    // (the last window's store covers the last group of every lane: T + 1 >= NB*W + P and P/4 + fs >= -1)
+#ifdef FINC_SPLIT_STAMP
+    if (blockIdx.x == 0 && lane == 0) finc_split_stamps[1 + bi] = st_busy;
+#else
+    (void)st_busy;
+#endif
+    };   // run_b
+    [&]<int... BI>(std::integer_sequence<int, BI...>) {
+        (([&] {
+             if (role - 1 == BI) run_b(IC<BI>{});
+         }()), ...);
+    }(std::make_integer_sequence<int, NBW>{});
+}
+
+// -----------------------------------------------------------------------------------------------
+// Instantiations: every bank of the wavefront kernel's table with a 2x2 or 3x3 filter that one wave holds
+// -----------------------------------------------------------------------------------------------
+typedef void (*split_fn)(const float *, const float *, float *, int, int, int, int, int, int, unsigned, int);
+struct SInst {
+    int cqp, kh, kw, nbw, lds_bytes;
+    split_fn fn;
+};
+template <int CQP, int KH, int KW, int NBW = 3>
+constexpr SInst make_sinst() { return SInst{CQP, KH, KW, NBW, SCfg<CQP, KH, KW, NBW>::LDS_BYTES, finc_split_kernel<CQP, KH, KW, NBW>}; }
+
+#ifdef FINC_ONLY_C3
+const SInst g_sinsts[] = {make_sinst<24, 3, 3>(), make_sinst<12, 3, 3>()};
+#else
+const SInst g_sinsts[] = {
+    make_sinst<4, 3, 3>(),  make_sinst<8, 3, 3>(),  make_sinst<12, 3, 3>(), make_sinst<16, 3, 3>(), make_sinst<20, 3, 3>(),
+    make_sinst<24, 3, 3>(), make_sinst<28, 3, 3>(), make_sinst<32, 3, 3>(),
+    make_sinst<4, 2, 2>(),  make_sinst<8, 2, 2>(),  make_sinst<12, 2, 2>(), make_sinst<16, 2, 2>(), make_sinst<24, 2, 2>(),
+    make_sinst<32, 2, 2>(),
+};
+#endif
+
+const SInst *find_sinst(int Cq, int KH, int KW)
+{
+    const int cqp = finc_mfma_packed_cqp(Cq, KH, KW);   // the bank is the wavefront kernel's: same padding rule
+    if (cqp == 0) return nullptr;
+    for (const SInst &i : g_sinsts)
+        if (i.cqp == cqp && i.kh == KH && i.kw == KW) return &i;
+    return nullptr;
+}
+
+int fifo_depth(int W, int P, int KH, int KW) { return W - P + KH + KW - 2; }
+
+// the FIFO of a k-step must fit its JSTRIDE bytes
+bool fifo_fits(const SInst &i, int W, int P) { return (size_t)fifo_depth(W, P, i.kh, i.kw) * 4 * (i.kh - 1) * 4 <= (size_t)JSTRIDE - 4; }   // (+ the zero word)
+
+// problems (B*G) up to which the role-split kernel is the faster one; FINC_SPLIT_MAX overrides (0 turns it off: A/B timing)
+long long split_max_problems()
+{
+    static const long long v = [] { const char *e = getenv("FINC_SPLIT_MAX"); return e ? atoll(e) : 256LL; }();
+    return v;
+}
+
+} // namespace
+
+#ifdef FINC_SPLIT_STAMP
+extern "C" int finc_debug_split_stamps(unsigned long long *h) { return (int)hipMemcpyFromSymbol(h, HIP_SYMBOL(finc_split_stamps), sizeof(finc_split_stamps)); }
+#endif
+
+bool finc_split_takes(const FincShape &s)
+{
+    if ((long long)s.B * s.G > split_max_problems()) return false;
+    const SInst *i = find_sinst(s.Cq, s.KH, s.KW);
+    if (!i || s.H < 1 || s.W < 1) return false;
+    const int P = s.W < 16 ? s.W : 16;
+    if (P < s.KH - 1) return false;
+    if (s.W % 4 != 0) return false;                                        // 16-byte pieces
+    if ((size_t)s.Cq * s.H * s.W * 4 >= ((size_t)1 << 30)) return false;   // buffer-offset range marks (OFF_BAD_CHANNEL)
+    return fifo_fits(*i, s.W, P);
+}
+
+int finc_split_info(const FincShape &s, int *waves, int *lds, int *steps)
+{
+    const SInst *i = find_sinst(s.Cq, s.KH, s.KW);
+    if (!i) return FINC_ERR_UNSUPPORTED;
+    const int P = s.W < 16 ? s.W : 16;
+    *waves = 1 + i->nbw;
+    *lds = i->lds_bytes;
+    *steps = ((s.H + P - 1) / P) * s.W + P - 1;
+    return FINC_OK;
+}
+
+int finc_split_launch(const float *in, const void *packed, float *out, const FincShape &s, hipStream_t st)
+{
+    const SInst *i = find_sinst(s.Cq, s.KH, s.KW);
+    if (!i) return FINC_ERR_UNSUPPORTED;
+    const int P = s.W < 16 ? s.W : 16;
+    const int T = ((s.H + P - 1) / P) * s.W + P - 1;           // steps of one problem
+    const int Tr = (T + 2 + UNROLL - 1) / UNROLL * UNROLL - 2; // the B waves' loop is unrolled by UNROLL
+    const size_t lds = (size_t)i->lds_bytes;
+    if (int e = finc_ensure_dynamic_lds((const void *)i->fn, lds)) return e;
+    hipLaunchKernelGGL(i->fn, dim3(s.B * s.G), dim3(64 * (1 + i->nbw)), lds, st, in, (const float *)packed, out, s.G, s.Cq, s.H, s.W, P,
+                       Tr, s.orient, fifo_depth(s.W, P, s.KH, s.KW));
+    FINC_CHECK_LAUNCH();
+    return FINC_OK;
+}

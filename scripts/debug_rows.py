@@ -21,3 +21,11 @@ for g in range(G):
     bad = (d[0, g].amax(dim=0) / sc > 1e-4).nonzero()
     if len(bad):
         print("   first bad (row, col):", bad[0].tolist(), " bad count", len(bad))
+if len(sys.argv) > 6:
+    g = int(sys.argv[6])
+    m = (d[0, g].amax(dim=0) / sc > 1e-4)
+    print("bad rows:", sorted(set(m.nonzero()[:, 0].tolist())))
+    for r in sorted(set(m.nonzero()[:, 0].tolist()))[:6]:
+        print(" row", r, "bad cols:", m[r].nonzero().flatten().tolist()[:40])
+    ch = (d[0, g].amax(dim=(1, 2)) / sc)
+    print("per channel:", " ".join(f"{v:.0e}" for v in ch.tolist()))

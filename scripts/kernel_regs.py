@@ -17,5 +17,5 @@ with tempfile.TemporaryDirectory() as d:
             if not pat.search(dem):
                 continue
             g = lambda k: int(re.search(r"\.%s:\s+(\d+)" % k, blk).group(1))
-            print(f"{dem.split('(')[0][-70:]:70s} agpr {int(blk.split()[0]):3d} total {g('vgpr_count'):3d} spill {g('vgpr_spill_count')} "
+            print(f"{dem[:100]:100s} agpr {int(blk.split()[0]):3d} total {g('vgpr_count'):3d} spill {g('vgpr_spill_count')} "
                   f"scratch {g('private_segment_fixed_size')} maxflat {g('max_flat_workgroup_size')}")

@@ -105,9 +105,25 @@ def report(kind, **fields):
 # ---------------------------------------------------------------------------
 # the MFMA inverse's instantiation table (finc_mfma.hip g_insts), walked by tests
 # ---------------------------------------------------------------------------
-def pick_row(rows, cqp, kh, kw, problems):
-    """Mirror of find_inst's selection rule (table order; max_problems; problems % npw) -- LDS fit not modelled, the
-    test shapes are narrow.  The host test checks this mirror against the library's own answer."""
+SPLIT_MAX_PROBLEMS = 256      # finc_split.hip split_max_problems()
+SPLIT_BANKS = {(3, 3): (4, 8, 12, 16, 20, 24, 28, 32), (2, 2): (4, 8, 12, 16, 24, 32)}
+
+
+def split_takes(cqp, kh, kw, problems, H, W):
+    """Mirror of finc_split.hip finc_split_takes: the role-split kernel runs the problem sets that do not outnumber the
+    compute units, for the 2x2 / 3x3 banks one wave holds, on maps whose hand-over FIFO fits its 2 KB per k-step."""
+    if problems > SPLIT_MAX_PROBLEMS or cqp not in SPLIT_BANKS.get((kh, kw), ()) or H < 1 or W < 4 or W % 4:
+        return False
+    P = min(16, W)
+    return P >= kh - 1 and (W - P + kh + kw - 2) * 4 * (kh - 1) * 4 <= 2048 - 4
+
+
+def pick_row(rows, cqp, kh, kw, problems, H=10, W=32):
+    """Mirror of the library's selection rule: -1 when the role-split kernel takes the problem set, else find_inst's table
+    walk (table order; max_problems; problems % npw) -- LDS fit not modelled, the test shapes are narrow.  The host test
+    checks this mirror against the library's own answer."""
+    if split_takes(cqp, kh, kw, problems, H, W):
+        return -1
     for r, i in enumerate(rows):
         if (i["cqp"], i["kh"], i["kw"]) != (cqp, kh, kw):
             continue
@@ -120,11 +136,12 @@ def pick_row(rows, cqp, kh, kw, problems):
 
 
 def problem_counts_for_row(rows, r):
-    """Problem counts (B*G) that select row r: the smallest, and the ones next to each max_problems edge of the shape."""
+    """Problem counts (B*G) that select row r: the smallest, and the ones next to each max_problems edge of the shape (for
+    the banks the role-split kernel serves: counts beyond its 256 problems)."""
     i = rows[r]
     shape = (i["cqp"], i["kh"], i["kw"])
     edges = sorted({x["max_problems"] for x in rows if (x["cqp"], x["kh"], x["kw"]) == shape and x["max_problems"] > 0})
-    cands = [1, 2, 3, 4, 6, 8]
+    cands = [1, 2, 3, 4, 6, 8, 257, 258, 259, 260, 262, 264]
     for e in edges:
         cands += [e - 2, e - 1, e, e + 1, e + 2, e + 4]
     hits = [n for n in sorted(set(cands)) if n > 0 and pick_row(rows, *shape, n) == r]

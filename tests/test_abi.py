@@ -83,7 +83,7 @@ def test_variant_plan_covers_every_row_and_agrees_with_the_library():
     16-byte form -- so the GPU test provably launches every compiled variant."""
     from helpers import problem_counts_for_row, split_problems
     rows = _lib.inverse_table()
-    assert len(rows) >= 28
+    assert len(rows) >= 27
     hit = set()
     for r, i in enumerate(rows):
         counts = problem_counts_for_row(rows, r)
@@ -108,6 +108,23 @@ def test_variant_plan_covers_every_row_and_agrees_with_the_library():
     assert _lib.inverse_variant(2, 4, 24, 16, 15, 3, 3) is None          # W % 4 != 0: strict kernel
 
 
+def test_role_split_kernel_takes_the_under_filled_chip():
+    """finc_split.hip: problem sets that do not outnumber the compute units (c2; c3 at the per-GPU batch of a 4- or 8-way
+    split; the c4 units) run on the role-split kernel -- form 4, one workgroup of four waves per problem; everything else
+    stays with the wavefront kernel's table (host-only calls)."""
+    from helpers import split_takes
+    for (B, G, Cq, H, W, K), want in (((64, 4, 12, 32, 32, 3), True), ((32, 4, 24, 64, 64, 3), True), ((64, 4, 24, 64, 64, 3), True),
+                                      ((65, 4, 24, 64, 64, 3), False), ((128, 4, 3, 16, 16, 3), False), ((64, 4, 3, 16, 16, 3), True),
+                                      ((16, 4, 12, 4, 4, 3), True), ((1, 1, 23, 40, 36, 3), True), ((8, 4, 24, 8, 80, 3), False),
+                                      ((8, 4, 16, 30, 44, 2), True), ((8, 4, 16, 32, 32, 5), False), ((8, 4, 40, 32, 32, 3), False)):
+        v = _lib.inverse_variant(B, G, Cq, H, W, K, K)
+        assert v is not None, (B, G, Cq, H, W, K)
+        assert (v["sec"] == 4) == want, (B, G, Cq, H, W, K, v)
+        assert split_takes(v["cqp"], K, K, B * G, H, W) == want
+        if want:
+            assert v["nw"] == 4 and v["workgroups"] == B * G and v["row"] == -1 and v["lds_bytes"] <= 64 * 1024, v
+
+
 def test_wide_maps_take_the_packed_two_wave_form():
     """finc_mfma.hip find_inst: once four one-wave problems do not fit a CU's LDS (the band hand-over FIFO grows with W) the
     packed two-wave form is chosen at any problem count; at 64x64 and below nothing changes (host-side call, no GPU)."""
@@ -118,7 +135,7 @@ def test_wide_maps_take_the_packed_two_wave_form():
         v = _lib.inverse_variant(256, 4, 24, H, W, 3, 3)
         assert (v["nw"], v["npw"]) == (2, 2) and v["lds_bytes"] <= 160 * 1024, (H, W, v)
     assert _lib.inverse_variant(256, 4, 24, 64, 56, 3, 3)["nw"] == 1        # four problems still fit: one wave each
-    assert _lib.inverse_variant(131, 1, 24, 8, 80, 3, 3)["nw"] == 3         # an odd count cannot be packed in pairs
+    assert _lib.inverse_variant(131, 1, 24, 8, 80, 3, 3)["nw"] == 1         # an odd count cannot be packed in pairs: one wave each
     assert _lib.inverse_variant(256, 4, 28, 64, 80, 3, 3)["nw"] == 1        # no two-wave row for this bank
 
 

@@ -572,23 +572,34 @@ def test_wider_instantiation_table(cfg, dev):
 
 
 def test_unaligned_activations_fall_back(dev):
-    """A 4-byte aligned (not 16-byte aligned) activation pointer: FINC_ALGO_AUTO takes the strict kernel instead of failing
-    (the MFMA inverse streams 16-byte pieces); asking for the MFMA kernel explicitly reports the alignment."""
+    """A 4-byte aligned (not 16-byte aligned) activation pointer.  The wavefront kernel streams aligned 16-byte pieces:
+    FINC_ALGO_AUTO takes the strict kernel for such a call instead of failing, and asking for the MFMA kernel explicitly
+    reports the alignment.  The role-split kernel of small problem sets has no such rule (its buffer accesses need dword
+    alignment only): the same call runs on it, under AUTO too."""
     from fincflow_amd import _lib, ops
     L = _lib.lib()
-    B, C, H, W, K = 2, 16, 8, 8, 3
-    ws = oracle.make_stored_weights(4, C // 4, K, K, seed=5)
-    wco = oracle.canonicalize(ws, 4, ORIENT_FASTFLOW)
-    wc = canon(ws, 4, ORIENT_FASTFLOW, dev)
-    z = np.random.default_rng(5).standard_normal((B, C, H, W)).astype(np.float32)
-    n = z.size
-    zbuf = torch.zeros(n + 8, device=dev)
-    xbuf = torch.zeros(n + 8, device=dev)
-    zbuf[1:n + 1] = torch.from_numpy(z).to(dev).flatten()                 # data starts 4 bytes into the allocation
-    wsb = torch.empty(L.finc_inverse_workspace_bytes(B, 4, C // 4, H, W, K, K), dtype=torch.uint8, device=dev)
-    args = (zbuf.data_ptr() + 4, wc.data_ptr(), xbuf.data_ptr() + 4, B, 4, C // 4, H, W, K, K, ORIENT_FASTFLOW)
-    st = L.finc_inverse_f32(*args, _lib.ALGO["auto"], wsb.data_ptr(), wsb.numel(), torch.cuda.current_stream().cuda_stream)
-    assert st == 0
-    assert np.array_equal(xbuf[1:n + 1].cpu().numpy().reshape(z.shape), oracle.inverse_f32(z, wco))
-    st = L.finc_inverse_f32(*args, _lib.ALGO["mfma"], wsb.data_ptr(), wsb.numel(), torch.cuda.current_stream().cuda_stream)
-    assert st == 7   # FINC_ERR_ALIGNMENT
+    for B, split in ((80, False), (2, True)):
+        C, H, W, K = 16, 8, 8, 3
+        assert (_lib.inverse_variant(B, 4, C // 4, H, W, K, K)["sec"] == 4) == split
+        ws = oracle.make_stored_weights(4, C // 4, K, K, seed=5)
+        wco = oracle.canonicalize(ws, 4, ORIENT_FASTFLOW)
+        wc = canon(ws, 4, ORIENT_FASTFLOW, dev)
+        z = np.random.default_rng(5).standard_normal((B, C, H, W)).astype(np.float32)
+        n = z.size
+        zbuf = torch.zeros(n + 8, device=dev)
+        xbuf = torch.zeros(n + 8, device=dev)
+        zbuf[1:n + 1] = torch.from_numpy(z).to(dev).flatten()             # data starts 4 bytes into the allocation
+        wsb = torch.empty(L.finc_inverse_workspace_bytes(B, 4, C // 4, H, W, K, K), dtype=torch.uint8, device=dev)
+        args = (zbuf.data_ptr() + 4, wc.data_ptr(), xbuf.data_ptr() + 4, B, 4, C // 4, H, W, K, K, ORIENT_FASTFLOW)
+        st = L.finc_inverse_f32(*args, _lib.ALGO["auto"], wsb.data_ptr(), wsb.numel(), torch.cuda.current_stream().cuda_stream)
+        assert st == 0
+        got = xbuf[1:n + 1].cpu().numpy().reshape(z.shape)
+        if split:
+            assert rel_err(got, oracle.inverse_via_f64(z, wco)) <= 1e-5
+        else:
+            assert np.array_equal(got, oracle.inverse_f32(z, wco))
+        xbuf.zero_()
+        st = L.finc_inverse_f32(*args, _lib.ALGO["mfma"], wsb.data_ptr(), wsb.numel(), torch.cuda.current_stream().cuda_stream)
+        assert st == (0 if split else 7)   # FINC_ERR_ALIGNMENT
+        if split:
+            assert rel_err(xbuf[1:n + 1].cpu().numpy().reshape(z.shape), oracle.inverse_via_f64(z, wco)) <= 1e-5
