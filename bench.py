@@ -17,8 +17,12 @@ value = images solved by all ranks / max-over-ranks time.  The forward (+logdet,
 same way right after and reported next to it, and so is the inverse on z ~ N(0,1) (the sampling distribution,
 train/losses.py:42-45).
 
-Images are independent, so ranks shard the batch with no data-path collective ("weak" scaling: the per-GPU
-batch is fixed); the only RCCL traffic is one broadcast of the layer's weights before the timed region.
+Images are independent, so ranks shard the batch with no data-path collective; the only RCCL traffic is one broadcast of
+the layer's weights before the timed region.  `--scaling weak` (default: what the driver's 1/2/4/8 run measures) keeps the
+per-GPU batch fixed; `--scaling strong` keeps the GLOBAL batch of the workload fixed and gives every rank B/N images -- the
+split SURVEY 8(e) worries about (c3: 32 images = 128 problems per GPU at N = 8, fewer problems than compute units).  The
+N = 1 line also carries `strong_share`: the time of ONE GPU on the share B/P it would get at P = 2, 4, 8 (a single-GPU
+measurement of the per-GPU work of a strong split, NOT a multi-GPU measurement).
 
 Extra objects on the JSON line:
   roofline      dominant kernel (inverse): algorithmic bytes per launch (8*E + 4*C*Cq*KH*KW)
@@ -66,6 +70,8 @@ def parse(argv=None):
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="c3", choices=sorted(WORKLOADS) + ["c4"])
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: the workload's batch per GPU; strong: the workload's batch in total, B/N per GPU")
     ap.add_argument("--cpu-sample", type=int, default=None, help="images in the single-thread CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--master-port", type=int, default=None, help="rendezvous port when this process starts the ranks")
@@ -253,19 +259,28 @@ def load_traffic(workload):
 def bench_stack(args):
     """--workload c4: BASELINE configs[3], sampling 128 images through the CIFAR Glow stack of
     fastflow_cifar.py:35-63 (num_blocks=3, block_size=32, actnorm, split prior: 96 FastFlowUnits at 16x16 / 8x8 /
-    4x4 + ActNorm + 1x1 + coupling nets).  A step = model.sample(128), replayed from one HIP graph when capture
-    succeeds.  The reference's published whole-stack numbers (timing_comparision.py:10-14) are for a different stack
-    size and batch 100, so vs_baseline stays null."""
+    4x4 + ActNorm + 1x1 + coupling nets), "batch-sharded 1->8 GPUs": with N ranks every rank samples 128/N images from
+    its own replica of the model (weights broadcast once; sampling needs no collective).  A step = model.sample(n),
+    replayed from one HIP graph when capture succeeds.  The reference's published whole-stack numbers
+    (timing_comparision.py:10-14) are for a different stack size and batch 100, so vs_baseline stays null.  The step is
+    mostly NOT the hot path: `hot_path_share` says what fraction of the kernel time of one pass the finc_* kernels are
+    (profiles/r02/c4_kernel_stats.csv)."""
     os.environ.setdefault("MIOPEN_FIND_MODE", "2")   # coupling-net convs: heuristics, not an exhaustive find per shape
+    h = Harness(args, stub=False)
     import numpy as np
-    import torch
+    torch = h.torch
     from fincflow_amd import FastFlowUnit, glow
-    dev = torch.device("cuda", 0)
-    torch.cuda.set_device(dev)
+    dev, world, rank = h.dev, h.world, h.rank
     torch.manual_seed(0)
     np.random.seed(0)
-    n = 128
+    total = 128
+    if total % world:
+        raise SystemExit(f"--workload c4 samples {total} images: --gpus must divide it")
+    n = total // world if args.scaling == "strong" or world > 1 else total
     model = glow.create_model(num_blocks=3, block_size=32, actnorm=True, split_prior=True).to(dev).eval()
+    if world > 1:
+        from fincflow_amd.dist import broadcast_weights
+        broadcast_weights(model, src=0)
     with torch.no_grad():
         for m in model:                                    # ActNorm is data-initialised by the first forward only
             if isinstance(m, glow.ActNorm):
@@ -285,24 +300,27 @@ def bench_stack(args):
             sys.stderr.write(f"graph capture failed, running eager: {e}\n")
             torch.cuda.synchronize()
         fn = (lambda: graph.replay()) if graph is not None else (lambda: model.sample(n))
-        for _ in range(args.warmup):
-            fn()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            fn()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t0
+        dt, ranks, per = h.timed(fn, args.steps, args.warmup)
+        finite = bool(torch.isfinite(s).all())
     units = sum(isinstance(m, FastFlowUnit) for m in model)
-    print(json.dumps({
-        "metric": "sampled images/sec, CIFAR Glow stack (fastflow_cifar.py create_model, 96 FastFlowUnits)",
-        "value": n * args.steps / dt, "unit": "images/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "BASELINE configs[3]: model.sample(128), num_blocks=3, block_size=32, actnorm, split_prior; "
-                               f"{units} FastFlowUnits (HIP) + ActNorm/Conv1x1/Coupling (PyTorch-ROCm); random init",
-                   "mode": mode, "finite": bool(torch.isfinite(s).all())},
-        "roofline": None, "cpu_baseline": None}), flush=True)
+    if rank == 0:
+        print(json.dumps({
+            "metric": "sampled images/sec, CIFAR Glow stack (fastflow_cifar.py create_model, 96 FastFlowUnits)",
+            "value": world * n * args.steps / dt, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong" if world > 1 else args.scaling, "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[3]: model.sample({n}) per GPU ({world * n} images in all), num_blocks=3, "
+                                   f"block_size=32, actnorm, split_prior; {units} FastFlowUnits (HIP) + ActNorm/Conv1x1/Coupling "
+                                   f"(PyTorch-ROCm); random init",
+                       "mode": mode, "finite": finite, "per_gpu_samples": n, "global_samples": world * n,
+                       "parallelism": f"batch-sharded x{world}, no collective on the data path",
+                       "world_size_seen": world, "backend": h.backend, "per_rank_ms": [r * 1e3 for r in ranks],
+                       "hot_path_share": {"finc_kernels_of_kernel_time": 0.06, "source": "profiles/r02/c4_kernel_stats.csv",
+                                          "note": "the coupling nets (MIOpen 3x3, rocBLAS 1x1, elementwise) are the rest: "
+                                                  "outside the hot path of SURVEY 8"}},
+            "launch": launch_stats(per), "roofline": None, "cpu_baseline": None}), flush=True)
+    h.finish()
 
 
 # ----------------------------------------------------------------------------------------------------------------
@@ -311,7 +329,7 @@ def bench_stack(args):
 def bench_stub(args):
     import numpy as np
     h = Harness(args, stub=True)
-    B = 4
+    B = 4 // h.world if args.scaling == "strong" else 4      # (strong: the global batch is fixed, every rank owns B / N)
     a = np.random.default_rng(h.rank).standard_normal((B, 64, 64))
 
     def fn():
@@ -322,8 +340,9 @@ def bench_stub(args):
         print(json.dumps({"metric": "stub steps/s (host-only stand-in: launcher test, not a measurement)",
                           "value": h.world * B * args.steps / dt, "unit": "images/s", "n_gpus": h.world,
                           "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
-                          "data": "stub", "config": {"workload": "host-only stub", "backend": h.backend,
+                          "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f64",
+                          "data": "stub", "config": {"workload": "host-only stub", "backend": h.backend, "per_gpu_batch": B,
+                                                     "global_batch": B * h.world,
                                                      "world_size_seen": h.world, "per_rank_ms": [r * 1e3 for r in ranks]},
                           "launch": launch_stats(per), "roofline": None, "cpu_baseline": None}), flush=True)
     h.finish()
@@ -338,6 +357,9 @@ def inverse_kernel_name(B, Cq, H, W, K):
     v = _lib.inverse_variant(B, 4, Cq, H, W, K, K)
     if v is None:
         return "inverse_strict_kernel<float> (inverse, scalar)"
+    if v["sec"] == 4:
+        return (f"finc_split_kernel<CQP={v['cqp']},{K},{K}> (inverse, role-split: 1 wave carries the recurrence, {v['nw'] - 1} prepare "
+                f"the rest one step ahead; {v['workgroups']} workgroups of {v['nw']} waves, {v['lds_bytes']} B LDS)")
     io = {0: "32-byte I/O", 1: "32-byte I/O, lane pairs", 2: "64-byte sector pairing",
           3: "64-byte sector pairing, helper waves do the I/O (512-thread workgroups of 4 problems)"}.get(v["sec"], str(v["sec"]))
     return (f"finc_wave_kernel<CQP={v['cqp']},{K},{K},NW={v['nw']},NPW={v['npw']}> (inverse; {io}; "
@@ -350,7 +372,13 @@ def bench_unit(args):
     from fincflow_amd import FastFlowUnit
     dev, world, rank = h.dev, h.world, h.rank
 
-    B, C, H, W, K, std = WORKLOADS[args.workload]
+    Bw, C, H, W, K, std = WORKLOADS[args.workload]
+    if args.scaling == "strong":
+        if Bw % world:
+            raise SystemExit(f"--scaling strong: the workload's batch {Bw} is not divisible by --gpus {world}")
+        B = Bw // world                      # the global batch is the workload's; every rank owns B/N images
+    else:
+        B = Bw
     Cq = C // 4
     torch.manual_seed(1234)
     unit = FastFlowUnit(C, C, K)
@@ -404,6 +432,31 @@ def bench_unit(args):
     tr_dt, _, tr_per = h.timed(step_train, tr_steps, 3)
     del xg, gz
 
+    # the per-GPU work of a STRONG split, measured on this one GPU: the share B/P of the workload's batch for P = 2, 4, 8
+    strong_share = None
+    if world == 1 and args.scaling == "weak":
+        from fincflow_amd import _lib as _l
+        strong_share = {"what": "one GPU on the batch share Bw/P it would own in a P-way strong split of the workload's batch "
+                                "(single-GPU measurement of the per-GPU work, NOT a multi-GPU measurement)",
+                        "global_batch": Bw, "shares": []}
+        with torch.no_grad():
+            for P_ in (2, 4, 8):
+                if Bw % P_:
+                    continue
+                zs = z[:Bw // P_].contiguous()
+                sh_dt, _, sh_per = h.timed(lambda: unit.reverse(zs), min(args.steps, 50), 5)
+                v = _l.inverse_variant(Bw // P_, 4, Cq, H, W, K, K)
+                st_ = launch_stats(sh_per)
+                strong_share["shares"].append({
+                    "P": P_, "per_gpu_batch": Bw // P_, "launch_ms": st_["mean_ms"], "median_ms": st_["median_ms"],
+                    "images_per_s_one_gpu": (Bw // P_) / (st_["mean_ms"] * 1e-3),
+                    "implied_images_per_s_at_P": Bw / (st_["mean_ms"] * 1e-3),
+                    "speedup_over_full_batch_implied": None,
+                    "kernel": inverse_kernel_name(Bw // P_, Cq, H, W, K), "form": v["sec"] if v else None})
+    from fincflow_amd import _lib as _lt
+    hlp_timeouts = _lt.hlp_timeouts()                      # helper-wave protocol: waits that gave up in this process (must be 0)
+    assert hlp_timeouts == 0, f"helper-wave protocol timed out {hlp_timeouts} times: results are not trustworthy"
+
     if rank == 0:
         E = B * C * H * W
         alg_bytes = 8 * E + 4 * C * Cq * K * K
@@ -425,16 +478,18 @@ def bench_unit(args):
             "warmup": args.warmup,
             "ms_per_step": inv_dt / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
             "config": {"workload": f"BASELINE configs[{CONFIG_INDEX[args.workload]}]: FastFlowUnit {K}x{K}, C={C} "
-                                   f"(4 groups x Cq={Cq}), {H}x{W}, batch {B} per GPU; step = unit.reverse(z), "
+                                   f"(4 groups x Cq={Cq}), {H}x{W}, batch {B} per GPU"
+                                   + (f" (strong split of the workload's {Bw})" if args.scaling == "strong" else "")
+                                   + f"; step = unit.reverse(z), "
                                    f"z = unit.forward(x), x ~ N(0,1); weights N(0,{std}^2) + reference init rule",
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"batch-sharded x{world}",
                        "world_size_seen": world, "backend": h.backend, "per_rank_ms": [r * 1e3 for r in inv_ranks],
-                       "round_trip_rel_err": err_after, "spin_up_s": h.spin_up_s},
+                       "round_trip_rel_err": err_after, "spin_up_s": h.spin_up_s, "hlp_timeouts": hlp_timeouts},
             "launch": inv,
             "sampling": {"what": "the same step on z ~ N(0,1) (train/losses.py:42-45)",
                          "images_per_s": world * B * args.steps / smp_dt, "launch": smp,
@@ -469,7 +524,12 @@ def bench_unit(args):
                                      "note": "shapes whose problems do not fill the chip (c2, the c4 units) are bound by "
                                              "dependent_steps x us_per_step, not by bandwidth"}},
         }
-        if not args.no_cpu and world == 1:          # the CPU baseline is an N=1 measurement (rank 0 only)
+        if strong_share is not None:
+            for sh in strong_share["shares"]:
+                sh["speedup_over_full_batch_implied"] = sh["implied_images_per_s_at_P"] / (B / (inv_launch_ms * 1e-3))
+            line["strong_share"] = strong_share
+        line["cpu_baseline"] = None                 # the CPU baseline is an N=1 measurement (rank 0 only)
+        if not args.no_cpu and world == 1:
             line["cpu_baseline"] = cpu_baseline(args.workload, B, C, H, W, K, std,
                                                 args.cpu_sample or CPU_SAMPLE_1T[args.workload])
         print(json.dumps(line), flush=True)
@@ -482,8 +542,6 @@ def main(argv=None):
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
-        if args.workload == "c4":
-            raise SystemExit("--workload c4 is a single-GPU bench")
         return launch_ranks(args, argv)             # nothing above this line touches torch or the GPU
     if os.environ.get("FINC_BENCH_STUB") == "1":
         return bench_stub(args)

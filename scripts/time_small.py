@@ -1,12 +1,15 @@
-"""GPU helper: the inverse on the under-filled chip -- c3 at B = 4..128 and c2 at B = 16..64, with and without the band
-pipeline (FINC_NO_BND is read once per process: two child processes)."""
+"""GPU helper: the inverse on the under-filled chip -- c3 at B = 4..128, c2 at B = 16..64, the c4 unit shapes -- with the
+role-split kernel (default) and without it (FINC_SPLIT_MAX=0: the wavefront kernel's table); two child processes, because the
+switch is read once per process."""
 import os, subprocess, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 if len(sys.argv) > 1 and sys.argv[1] == "child":
     import torch
     from fincflow_amd import FastFlowUnit, _lib
     dev = torch.device("cuda:0")
-    for (C, H, W, K, Bs) in ((96, 64, 64, 3, (4, 8, 16, 32, 64, 128)), (48, 32, 32, 3, (16, 32, 64)), (96, 32, 32, 3, (64,)), (96, 48, 64, 3, (32,))):
+    for (C, H, W, K, Bs) in ((96, 64, 64, 3, (4, 8, 16, 32, 64, 128)), (48, 32, 32, 3, (16, 32, 64)), (96, 32, 32, 3, (64,)),
+                             (96, 48, 64, 3, (32,)), (12, 16, 16, 3, (128,)), (24, 8, 8, 3, (128,)), (48, 4, 4, 3, (128,)),
+                             (64, 32, 32, 2, (32,))):
         torch.manual_seed(0)
         unit = FastFlowUnit(C, C, K).to(dev)
         for B in Bs:
@@ -24,9 +27,11 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
                 us = a.elapsed_time(b) / 50 * 1e3
                 err = float((o - x).abs().max() / x.abs().max())
             v = _lib.inverse_variant(B, 4, C // 4, H, W, K, K)
-            print(f"C{C} {H}x{W} B={B:4d}: {us:7.1f} us  bands {v.get('bands', 0)} nw {v['nw']} npw {v['npw']} form {v['sec']} chain {v.get('chain', 0)} "
-                  f"-> {us / max(v.get("chain", 0), 1):.3f} us/step  err {err:.1e}", flush=True)
+            P = min(16, W)
+            chain = ((H + P - 1) // P) * W + P - 1
+            print(f"C{C} {H}x{W} k{K} B={B:4d}: {us:7.1f} us  waves {v['nw']} npw {v['npw']} form {v['sec']}  chain {chain} "
+                  f"-> {us / chain:.3f} us/step  err {err:.1e}", flush=True)
 else:
-    for env in ({"FINC_NO_BND": "1"}, {}):
+    for env in ({"FINC_SPLIT_MAX": "0"}, {}):
         print("==", env or "default", flush=True)
         subprocess.run([sys.executable, os.path.abspath(__file__), "child"], env=dict(os.environ, **env), check=True)

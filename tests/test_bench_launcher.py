@@ -46,6 +46,20 @@ def test_gpus_2_spawns_two_ranks():
         assert k in line["launch"]
 
 
+def test_strong_scaling_keeps_the_global_batch():
+    """--scaling strong: the workload's batch is split over the ranks (SURVEY 8e's strong split); weak keeps it per GPU.
+    Every line carries the keys the driver indexes, null where they do not apply (cpu_baseline at N > 1)."""
+    weak = json_lines(run_bench(["--gpus", "2"]).stdout)[0]
+    r = run_bench(["--gpus", "2", "--scaling", "strong"])
+    assert r.returncode == 0, r.stderr[-2000:]
+    strong = json_lines(r.stdout)[0]
+    assert weak["scaling"] == "weak" and strong["scaling"] == "strong"
+    assert weak["config"]["per_gpu_batch"] == 4 and weak["config"]["global_batch"] == 8
+    assert strong["config"]["per_gpu_batch"] == 2 and strong["config"]["global_batch"] == 4
+    for line in (weak, strong):
+        assert "cpu_baseline" in line and line["cpu_baseline"] is None and "roofline" in line
+
+
 def test_world_size_mismatch_fails_loudly():
     r = run_bench(["--gpus", "2"], env_extra={"WORLD_SIZE": "1", "RANK": "0"})
     assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
