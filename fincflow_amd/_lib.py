@@ -22,6 +22,7 @@ SYMBOLS = [
     "finc_canonicalize_weights_f64", "finc_inverse_f64", "finc_forward_f64",
     "finc_inverse_kernel_variant", "finc_debug_attr_table_insert", "finc_debug_inverse_table_row",
     "finc_mix_supported_f32", "finc_mix_f32", "finc_pack_forward_weights_affine_f32", "finc_debug_hlp_timeouts",
+    "finc_build_flags", "finc_clear_fault", "finc_debug_backward_variant",
 ]
 
 _lib = None
@@ -42,6 +43,8 @@ def lib():
     L = ctypes.CDLL(LIB_PATH)
     vp, i, u, sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_uint, ctypes.c_size_t
     L.finc_version.restype = i
+    L.finc_build_flags.restype = u
+    L.finc_clear_fault.restype = i
     L.finc_status_string.restype = ctypes.c_char_p
     L.finc_status_string.argtypes = [i]
     L.finc_last_hip_error.restype = ctypes.c_char_p
@@ -74,6 +77,7 @@ def lib():
     L.finc_debug_attr_table_insert.argtypes = [i, sz]
     L.finc_debug_inverse_table_row.argtypes = [i, ctypes.POINTER(ctypes.c_int)]
     L.finc_debug_hlp_timeouts.argtypes = [ctypes.POINTER(ctypes.c_uint)]
+    L.finc_debug_backward_variant.argtypes = [i, i, i, i, i, i, i, ctypes.POINTER(ctypes.c_int)]
     L.finc_mix_supported_f32.argtypes = [i]
     L.finc_mix_f32.argtypes = [vp, vp, vp, vp, i, i, i, vp]
     for name in SYMBOLS:
@@ -91,6 +95,23 @@ def inverse_variant(B, G, Cq, H, W, KH, KW):
     check(st, "finc_inverse_kernel_variant")
     keys = ("cqp", "nw", "npw", "sec", "lds_bytes", "workgroups", "row", "rows")
     return dict(zip(keys, list(info)))
+
+
+def backward_variant(B, G, Cq, H, W, KH, KW):
+    """Kernels finc_backward_f32 runs for this shape: grad-weight form (0 direct, 1 dword MFMA, 2 staged, 3 tiled), grad-input
+    waves per strip (0 = direct kernel, > 1 = K-split) and whether grad-input takes the staged form."""
+    info = (ctypes.c_int * 3)()
+    check(lib().finc_debug_backward_variant(B, G, Cq, H, W, KH, KW, info), "finc_debug_backward_variant")
+    return {"gradw": ("direct", "dword", "staged", "tiled")[info[0]], "gradx_waves": info[1], "gradx_staged": bool(info[2])}
+
+
+def build_flags():
+    """Measurement knobs the library was built with (0 = product build)."""
+    return int(lib().finc_build_flags())
+
+
+def clear_fault():
+    check(lib().finc_clear_fault(), "finc_clear_fault")
 
 
 def hlp_timeouts():

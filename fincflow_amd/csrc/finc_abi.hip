@@ -17,15 +17,15 @@ std::mutex g_table_mutex;
 std::vector<std::pair<int, const void *>> g_attr_done;   // (device, kernel) pairs whose LDS attribute is set
 constexpr int MAX_DEVICES = 64;
 int *g_invariant_flag[MAX_DEVICES];                       // one 4-byte device word per device, allocated on first use
+volatile unsigned *g_fault_host[MAX_DEVICES];             // one pinned, mapped host word per device: set by a kernel that gave up a wait
+std::vector<std::pair<int, size_t>> g_debug_tokens;       // finc_debug_attr_table_insert's own table (never the live one)
 
-// true if (device, fn) was not in the table yet (and is now)
-bool attr_table_insert(int device, const void *fn)
+// caller holds g_table_mutex
+bool attr_table_has(int device, const void *fn)
 {
-    std::lock_guard<std::mutex> lk(g_table_mutex);
     for (const auto &e : g_attr_done)
-        if (e.first == device && e.second == fn) return false;
-    g_attr_done.emplace_back(device, fn);
-    return true;
+        if (e.first == device && e.second == fn) return true;
+    return false;
 }
 
 template <typename T>
@@ -85,8 +85,38 @@ int finc_ensure_dynamic_lds(const void *fn, size_t bytes)
     if (bytes <= 48 * 1024) return FINC_OK;
     int dev = 0;
     FINC_HIP_TRY(hipGetDevice(&dev));
-    if (!attr_table_insert(dev, fn)) return FINC_OK;
+    // one lock over lookup, hipFuncSetAttribute and insert: a second thread on the device must not see the entry before the
+    // attribute is set, and a failed call must leave no entry behind (the next launch tries again)
+    std::lock_guard<std::mutex> lk(g_table_mutex);
+    if (attr_table_has(dev, fn)) return FINC_OK;
     FINC_HIP_TRY(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    g_attr_done.emplace_back(dev, fn);
+    return FINC_OK;
+}
+
+int finc_fault_gate(bool arm)
+{
+    int dev = 0;
+    FINC_HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= MAX_DEVICES) return FINC_ERR_BAD_DIMS;
+    volatile unsigned *w = g_fault_host[dev];
+    if (!w && arm) {
+        std::lock_guard<std::mutex> lk(g_table_mutex);
+        if (!g_fault_host[dev]) {
+            unsigned *h = nullptr, *d = nullptr;
+            FINC_HIP_TRY(hipHostMalloc((void **)&h, sizeof(unsigned), hipHostMallocMapped));
+            *h = 0;
+            FINC_HIP_TRY(hipHostGetDevicePointer((void **)&d, h, 0));
+            if (int e = finc_mfma_arm_fault_word(d)) return e;
+            g_fault_host[dev] = h;
+        }
+        w = g_fault_host[dev];
+    }
+    if (w && *w != 0) {
+        strncpy(g_hip_error, "a helper-wave wait of an earlier launch on this device gave up: its output is not valid (finc_clear_fault() resets)",
+                sizeof(g_hip_error) - 1);
+        return FINC_ERR_LAUNCH;
+    }
     return FINC_OK;
 }
 
@@ -107,7 +137,22 @@ static int canonicalize(const T *w_stored, T *w_canon, int G, int Cq, int KH, in
 
 extern "C" {
 
-int finc_version(void) { return 100; }
+int finc_version(void) { return 101; }
+
+unsigned finc_build_flags(void)
+{
+    return FINC_BUILD_FLAGS | finc_build_flags_mfma() | finc_build_flags_split() | finc_build_flags_conv() | finc_build_flags_gradw() |
+           finc_build_flags_mix() | finc_build_flags_generic();
+}
+
+int finc_clear_fault(void)
+{
+    int dev = 0;
+    FINC_HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= MAX_DEVICES) return FINC_ERR_BAD_DIMS;
+    if (g_fault_host[dev]) *g_fault_host[dev] = 0;
+    return FINC_OK;
+}
 
 const char *finc_status_string(int status)
 {
@@ -146,6 +191,7 @@ int finc_check_invariant_f32(const float *w_canon, int G, int Cq, int KH, int KW
     int dev = 0;
     FINC_HIP_TRY(hipGetDevice(&dev));
     if (dev < 0 || dev >= MAX_DEVICES) return FINC_ERR_BAD_DIMS;
+    if (int e = finc_fault_gate(false)) return e;          // (a synchronous call is a natural place to report a protocol fault)
     // the call is synchronous anyway: one lock covers the lazily allocated per-device flag word and its use, so
     // concurrent checks (DataParallel replica threads) neither allocate twice nor share the word
     std::lock_guard<std::mutex> lk(g_table_mutex);
@@ -163,7 +209,13 @@ int finc_check_invariant_f32(const float *w_canon, int G, int Cq, int KH, int KW
 
 int finc_debug_attr_table_insert(int device, size_t kernel_token)
 {
-    return attr_table_insert(device, (const void *)kernel_token) ? 1 : 0;
+    // the key logic of the (device, kernel) table on a table of its OWN: a test token must never land in the live table
+    // (a token equal to a real kernel address would make the next launch skip its attribute)
+    std::lock_guard<std::mutex> lk(g_table_mutex);
+    for (const auto &e : g_debug_tokens)
+        if (e.first == device && e.second == kernel_token) return 0;
+    g_debug_tokens.emplace_back(device, kernel_token);
+    return 1;
 }
 
 size_t finc_workspace_bytes(int G, int Cq, int KH, int KW)
@@ -374,6 +426,19 @@ int finc_mix_f32(const float *in, const float *mat, const float *bias, float *ou
     if (misaligned(in) || misaligned(mat) || misaligned(out) || (bias && misaligned(bias))) return FINC_ERR_ALIGNMENT;
     if ((size_t)B * C * HW >= ((size_t)1 << 40)) return FINC_ERR_BAD_DIMS;
     return finc_mix_launch(in, mat, bias, out, B, C, HW, (hipStream_t)stream);
+}
+
+int finc_debug_backward_variant(int B, int G, int Cq, int H, int W, int KH, int KW, int *info)
+{
+    if (!info) return FINC_ERR_NULL_POINTER;
+    if (int e = check_shape(B, G, Cq, H, W, KH, KW)) return e;
+    FincShape s{B, G, Cq, H, W, KH, KW, 0};
+    info[0] = finc_gradw_variant(s);
+    int c[3] = {0, 0, 0};
+    const bool mfma = finc_conv_variant(B, G, Cq, H, W, KH, KW, c) == FINC_OK;
+    info[1] = mfma ? c[0] : 0;
+    info[2] = mfma ? c[1] : 0;
+    return FINC_OK;
 }
 
 int finc_debug_hlp_timeouts(unsigned *h_count)

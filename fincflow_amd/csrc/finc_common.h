@@ -5,6 +5,7 @@
 #include <stdint.h>
 
 #include "../../include/finc.h"
+#include "finc_experiment.h"   // the measurement knobs: an error if one is set without -DFINC_EXPERIMENT
 
 #define FINC_FLIP_W 1u
 #define FINC_FLIP_H 2u
@@ -35,6 +36,20 @@ void finc_set_hip_error(hipError_t e);
 
 // hipFuncAttributeMaxDynamicSharedMemorySize = 160 KiB, once per (device, kernel), thread-safe (finc_abi.hip)
 int finc_ensure_dynamic_lds(const void *fn, size_t bytes);
+
+// Protocol faults (helper-wave waits that gave up): finc_fault_gate returns FINC_ERR_LAUNCH if the device's fault word is
+// set (sticky; no synchronisation -- the word lives in mapped host memory); `arm` allocates and publishes the word on the
+// first call per device.  finc_abi.hip owns the per-device table, finc_mfma.hip the device symbol.
+int finc_fault_gate(bool arm);
+int finc_mfma_arm_fault_word(unsigned *device_ptr_to_host_word);
+
+// the measurement knobs each kernel translation unit was built with (finc_experiment.h); finc_build_flags() ORs them
+unsigned finc_build_flags_mfma();
+unsigned finc_build_flags_split();
+unsigned finc_build_flags_conv();
+unsigned finc_build_flags_gradw();
+unsigned finc_build_flags_mix();
+unsigned finc_build_flags_generic();
 
 struct FincShape {
     int B, G, Cq, H, W, KH, KW;
@@ -84,6 +99,9 @@ int finc_conv_pack(const float *wc, void *packed, int G, int Cq, int KH, int KW,
 int finc_conv_launch(const float *in, const void *packed, float *out, const FincShape &s, hipStream_t st);
 size_t finc_gradw_workspace_bytes(const FincShape &s); // 0: no MFMA grad-weight kernel for this shape
 int finc_gradw_launch(const float *gz, const float *x, float *gw, void *workspace, const FincShape &s, hipStream_t st);
+int finc_gradw_variant(const FincShape &s);   // 0 direct, 1 dword MFMA, 2 staged, 3 tiled
+// info[0..2] = {waves per strip (K-split), staged form (1) or dword form (0), strips per slab}; FINC_ERR_UNSUPPORTED: direct kernel
+int finc_conv_variant(int B, int G, int Cq, int H, int W, int KH, int KW, int *info);
 
 // ---- per-pixel channel mixing (1x1 conv + folded affine): finc_mix.hip ----
 bool finc_mix_supported(int C);

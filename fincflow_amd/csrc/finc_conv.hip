@@ -649,3 +649,17 @@ int finc_conv_launch(const float *in, const void *packed, float *out, const Finc
     FINC_CHECK_LAUNCH();
     return FINC_OK;
 }
+
+int finc_conv_variant(int B, int G, int Cq, int H, int W, int KH, int KW, int *info)
+{
+    const ConvInst *i = find_conv(Cq, KH, KW);
+    if (!i || !finc_conv_supported(Cq, H, W, KH, KW)) return FINC_ERR_UNSUPPORTED;
+    static const bool no_wide = getenv("FINC_CONV_NO_WIDE") != nullptr;
+    info[0] = i->nw;
+    info[1] = (i->fn_wide && W % 16 == 0 && !no_wide) ? 1 : 0;
+    info[2] = (W + 15) / 16;
+    (void)B; (void)G; (void)H;
+    return FINC_OK;
+}
+
+unsigned finc_build_flags_conv() { return FINC_BUILD_FLAGS; }

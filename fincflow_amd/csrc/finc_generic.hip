@@ -283,3 +283,5 @@ int finc_launch_repitch(const float *in, float *out, long long rows, int Win, in
     FINC_CHECK_LAUNCH();
     return FINC_OK;
 }
+
+unsigned finc_build_flags_generic() { return FINC_BUILD_FLAGS; }

@@ -608,3 +608,17 @@ int finc_gradw_launch(const float *gz, const float *x, float *gw, void *workspac
     FINC_CHECK_LAUNCH();
     return FINC_OK;
 }
+
+// which grad-weight kernel finc_backward_f32 runs for this shape, given 16-byte aligned activations and a full workspace:
+// 0 direct (no MFMA instantiation), 1 dword MFMA kernel, 2 staged (16-byte pieces through LDS), 3 tiled (one tile pair per workgroup)
+int finc_gradw_variant(const FincShape &s)
+{
+    const GradwInst *i = find_gradw(s.Cq, s.KH, s.KW);
+    if (!i || finc_gradw_workspace_bytes(s) == 0) return 0;
+    if (gradw_use_tiled(i, s)) return 3;
+    if (!i->gw) return 0;
+    static const bool no_staged = getenv("FINC_GRADW_NO_STAGED") != nullptr;
+    return (i->gw_staged && s.W % 16 == 0 && !no_staged) ? 2 : 1;
+}
+
+unsigned finc_build_flags_gradw() { return FINC_BUILD_FLAGS; }

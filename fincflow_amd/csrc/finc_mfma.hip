@@ -202,6 +202,14 @@ __device__ unsigned long long finc_stamp_buf[64];
 #endif
 
 __device__ unsigned finc_hlp_timeouts = 0;       // helper-wave protocol: waits that gave up (must stay 0)
+// A give-up must not pass unnoticed (the launch would return FINC_OK with garbage in its output): besides the counter the
+// kernel sets a word in HOST memory (pinned, mapped; armed once per device by the first helper-wave launch), which the next
+// finc_* call on that device reads without any synchronisation and turns into FINC_ERR_LAUNCH -- sticky until
+// finc_clear_fault().
+__device__ unsigned *finc_fault_word = nullptr;
+#ifndef FINC_HLP_BUDGET_LOG2   // test-only builds shorten the spin budget (2^20 polls ~ 0.1 s) so that an injected fault ends quickly
+#define FINC_HLP_BUDGET_LOG2 20
+#endif
 #ifdef FINC_HLP_COUNT    // diagnostic build: how often the compute wave finds its partner late (word 0: landing, 1: x-ring reads)
 __device__ unsigned finc_hlp_late[2] = {0, 0};
 #define FINC_HLP_LATE(k) do { if ((threadIdx.x & 63) == 0) atomicAdd(&finc_hlp_late[k], 1u); } while (0)
@@ -314,6 +322,9 @@ __global__ __launch_bounds__(HLP ? 512 : 64 * NW * NPW) void finc_wave_kernel(co
     const unsigned flag_a = (unsigned)(uintptr_t)(lds + 4 * wave_lds + 4 * prob);   // +0: A, +4: B, +8: B2, +12: A1 (bytes)
     auto flag_set = [flag_a](auto word_c, int v) {
         constexpr int WORD = decltype(word_c)::value;
+#ifdef FINC_HLP_INJECT_TIMEOUT   // test-only build: the helper stops announcing its landings -> the compute wave's wait gives up
+        if (WORD == 1 && v >= 8) return;
+#endif
         if constexpr (HLP) asm volatile("ds_write_b32 %0, %1 offset:%2" ::"v"(flag_a), "v"(v), "n"(4 * WORD) : "memory");
     };
     // two-stage wait for the compute role: `peek` only issues the read (no wait); `check` -- a few hundred cycles later, when
@@ -329,7 +340,7 @@ __global__ __launch_bounds__(HLP ? 512 : 64 * NW * NPW) void finc_wave_kernel(co
 #define FINC_HLP_NOWAIT 0
 #endif
         if constexpr (HLP && !((FINC_HLP_NOWAIT >> WORD) & 1)) {
-            int budget = 1 << 20;              // bounded (~0.1 s): a protocol bug must not hang the GPU ...
+            int budget = 1 << FINC_HLP_BUDGET_LOG2;   // bounded (~0.1 s): a protocol bug must not hang the GPU ...
             for (; budget > 0; --budget) {
                 int v;
                 asm volatile("ds_read_b32 %0, %1 offset:%2\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(flag_a), "n"(4 * WORD) : "memory");
@@ -337,7 +348,10 @@ __global__ __launch_bounds__(HLP ? 512 : 64 * NW * NPW) void finc_wave_kernel(co
                 __builtin_amdgcn_s_sleep(2);
             }
             // ... and must not pass unnoticed: finc_debug_hlp_timeouts() reads this counter (tests assert it stays 0)
-            if (budget == 0 && (threadIdx.x & 63) == 0) atomicAdd(&finc_hlp_timeouts, 1u);
+            if (budget == 0 && (threadIdx.x & 63) == 0) {
+                atomicAdd(&finc_hlp_timeouts, 1u);
+                if (finc_fault_word) __hip_atomic_store(finc_fault_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
     };
 
@@ -1540,6 +1554,12 @@ extern "C" int finc_debug_stamps(unsigned long long *host_out, int n)
 }
 #endif
 
+int finc_mfma_arm_fault_word(unsigned *device_ptr_to_host_word)
+{
+    FINC_HIP_TRY(hipMemcpyToSymbol(HIP_SYMBOL(finc_fault_word), &device_ptr_to_host_word, sizeof(device_ptr_to_host_word)));
+    return FINC_OK;
+}
+
 int finc_mfma_hlp_timeouts(unsigned *count)
 {
     FINC_HIP_TRY(hipMemcpyFromSymbol(count, HIP_SYMBOL(finc_hlp_timeouts), sizeof(unsigned)));
@@ -1620,6 +1640,7 @@ int finc_mfma_table_row(int row, int *info)
 int finc_mfma_launch(const float *in, const void *packed, float *out, const FincShape &s, hipStream_t st)
 {
     if (!finc_mfma_supported(s.Cq, s.H, s.W, s.KH, s.KW)) return FINC_ERR_UNSUPPORTED;
+    if (int e = finc_fault_gate(false)) return e;          // an earlier launch on this device gave up a protocol wait
     if (finc_split_takes(s)) return finc_split_launch(in, packed, out, s, st);   // the under-filled chip (finc_split.hip)
     const Inst *i = find_inst(s.Cq, s.KH, s.KW, (long long)s.B * s.G, s.W);
     if (!i) return FINC_ERR_UNSUPPORTED;
@@ -1634,6 +1655,9 @@ int finc_mfma_launch(const float *in, const void *packed, float *out, const Finc
     const bool hlp = s64 && i->fn_hlp && ((long long)s.B * s.G) % 4 == 0 && lds_hlp <= 160 * 1024 && !finc_no_hlp();
     const wave_fn fn = hlp ? i->fn_hlp : s64 ? i->fn_s64 : (s.W % 8 == 0) ? i->fn_sec : i->fn;
     if (int e = finc_ensure_dynamic_lds((const void *)fn, hlp ? lds_hlp : lds)) return e;
+    if (hlp) {
+        if (int e = finc_fault_gate(true)) return e;       // (arms the device's fault word on the first helper-wave launch)
+    }
     if (hlp)
         hipLaunchKernelGGL(fn, dim3(s.B * s.G / 4), dim3(512), lds_hlp, st, in, (const float *)packed, out, s.G, s.Cq, s.H, s.W, P,
                            Tend, s.orient);
@@ -1643,3 +1667,5 @@ int finc_mfma_launch(const float *in, const void *packed, float *out, const Finc
     FINC_CHECK_LAUNCH();
     return FINC_OK;
 }
+
+unsigned finc_build_flags_mfma() { return FINC_BUILD_FLAGS; }

@@ -252,3 +252,5 @@ int finc_mix_launch(const float *in, const float *mat, const float *bias, float 
     FINC_CHECK_LAUNCH();
     return FINC_OK;
 }
+
+unsigned finc_build_flags_mix() { return FINC_BUILD_FLAGS; }

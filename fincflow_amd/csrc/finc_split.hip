@@ -625,3 +625,5 @@ int finc_split_launch(const float *in, const void *packed, float *out, const Fin
     FINC_CHECK_LAUNCH();
     return FINC_OK;
 }
+
+unsigned finc_build_flags_split() { return FINC_BUILD_FLAGS; }

@@ -46,18 +46,36 @@ class ActNorm(FlowLayer):
         self.translation = nn.Parameter(torch.zeros(n_dims))
         self.log_scale = nn.Parameter(torch.zeros(n_dims))
         self.register_buffer('initialized', torch.tensor(0))
+        # host-side mirror of `initialized` (None: unknown, read the buffer once): the buffer lives on the device, and
+        # testing it costs a device->host sync per layer and call -- 96 per pass of the CIFAR stack, and no HIP graph
+        self._init_known = None
+
+    def _is_initialized(self):
+        if self._init_known is None:
+            self._init_known = bool(self.initialized)      # one sync, then cached
+        return self._init_known
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        self._init_known = None                            # a checkpoint brings its own flag
+        return super()._load_from_state_dict(*args, **kwargs)
+
+    def mark_initialized(self):
+        """Skip the data-dependent initialisation (parameters set by hand or by a checkpoint): no sync, graph-safe."""
+        self.initialized.fill_(1)
+        self._init_known = True
 
     def _shaped(self, input):
         shape = (1, -1) + (1,) * (input.dim() - 2)
         return self.translation.view(shape), self.log_scale.view(shape)
 
     def forward(self, input, context=None):
-        if not self.initialized:
+        if not self._is_initialized():
             with torch.no_grad():
                 dims = [d for d in range(input.dim()) if d != 1]
                 self.translation.copy_(input.mean(dim=dims))
                 self.log_scale.copy_(torch.log(input.std(dim=dims) + 1e-8))
                 self.initialized.fill_(1)
+                self._init_known = True
         t, ls = self._shaped(input)
         return (input - t) * torch.exp(-ls), self.logdet(input, context)
 
@@ -68,7 +86,7 @@ class ActNorm(FlowLayer):
     def forward_affine_params(self):
         """forward(x) = (x - translation) * exp(-log_scale): what FlowSequential folds into the FastFlowUnit in front of
         this layer (only once the data-dependent initialisation has happened)."""
-        if not bool(self.initialized):
+        if not self._is_initialized():
             return None
         return self.log_scale, self.translation
 

@@ -60,10 +60,14 @@ class PaddedConv2d(FlowLayer):
         # (left, right, top, bottom), layers/conv.py:41-55
         self.pad = {'TL': (K_W - 1, 0, K_H - 1, 0), 'TR': (0, K_W - 1, K_H - 1, 0),
                     'BL': (K_W - 1, 0, 0, K_H - 1), 'BR': (0, K_W - 1, 0, K_H - 1)}[order]
-        # parameter holder only (state-dict keys conv.weight / conv.bias as in the reference).  The FInC unit never sets
-        # bias (fastflow.py:24-27); with it the layer is conv(x) + b and the reverse subtracts b first
-        # (layers/conv.py:113-117) -- a per-channel add around the same two launches.
-        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size, bias=bool(bias))
+        # Parameter holder only, and bias-free WHATEVER the argument says -- exactly as the reference builds it
+        # (layers/conv.py:60 hard-codes bias=False), so the state dict has the one key `conv.weight` and reference
+        # checkpoints load strictly.  The reference then carries a dead `conv.bias is not None` branch in its reverse
+        # (layers/conv.py:113-117); here `bias=True` makes that branch live through a parameter of the layer's OWN,
+        # `bias` (zero-initialised, as the reference's reset would leave a bias): conv(x) + b, and the reverse subtracts b
+        # first -- a per-channel add around the same two launches.  The FInC unit never sets it (fastflow.py:24-27).
+        self.conv = nn.Conv2d(in_channels, out_channels, kernel_size, bias=False)
+        self.bias = nn.Parameter(torch.zeros(out_channels)) if bias else None
         self._cache = ops.PackedWeights()
         self.reset_parameters()
 
@@ -105,17 +109,19 @@ class PaddedConv2d(FlowLayer):
 
     def forward(self, x, context=None, compute_expensive=None):
         if torch.is_grad_enabled() and (x.requires_grad or self.conv.weight.requires_grad):
-            out = ops.conv_forward(x, self.conv.weight, 1, self._orient)
+            out = ops.conv_forward(x, [self.conv.weight], 1, self._orient, self._cache)
         else:  # density evaluation / sampling checks: cached fragments, one launch
             out = self._cache.forward(x.contiguous(), [self.conv.weight], 1, self._orient)
-        if self.conv.bias is not None:
-            out = out + self.conv.bias.view(1, -1, 1, 1)
+        b = self.bias if self.bias is not None else self.conv.bias          # (conv.bias: set by hand, the reference's dead branch)
+        if b is not None:
+            out = out + b.view(1, -1, 1, 1)
         return out, 0.0
 
     def reverse(self, x, context=None, compute_expensive=None):
         with torch.no_grad():
-            if self.conv.bias is not None:
-                x = x - self.conv.bias.reshape(-1, x.shape[1], 1, 1)
+            b = self.bias if self.bias is not None else self.conv.bias
+            if b is not None:
+                x = x - b.reshape(-1, x.shape[1], 1, 1)
             y = self._cache.inverse(x.contiguous(), [self.conv.weight], 1, self._orient)
         return y, 0
 
@@ -145,8 +151,7 @@ class FastFlowUnit(nn.Module):
 
     def forward(self, x, context=None):
         if torch.is_grad_enabled() and (x.requires_grad or any(w.requires_grad for w in self._weights())):
-            w = torch.cat(self._weights(), dim=0)
-            out = ops.conv_forward(x, w, 4, ops.ORIENT_FASTFLOW)
+            out = ops.conv_forward(x, self._weights(), 4, ops.ORIENT_FASTFLOW, self._cache)
         else:  # density evaluation / sampling checks: cached fragments, one launch
             out = self._cache.forward(x.contiguous(), self._weights(), 4, ops.ORIENT_FASTFLOW)
         return out, 0.0
@@ -232,7 +237,14 @@ def load_reference_checkpoint(model, checkpoint, strict=True, validate=True, tru
     state = checkpoint.get("model_state_dict", checkpoint) if isinstance(checkpoint, dict) else checkpoint
     if state and all(k.startswith("module.") for k in state):
         state = {k[len("module."):]: v for k, v in state.items()}
-    result = model.load_state_dict(state, strict=strict)
+    # a PaddedConv2d built with bias=True owns a `bias` the reference never wrote (its conv is bias-free, layers/conv.py:60):
+    # that key may be missing from a reference checkpoint -- the zero initialisation stands -- everything else is strict
+    own_bias = {name + ".bias" for name, m in model.named_modules() if isinstance(m, PaddedConv2d) and m.bias is not None}
+    own_bias |= {"bias"} if isinstance(model, PaddedConv2d) and model.bias is not None else set()
+    result = model.load_state_dict(state, strict=False)
+    missing = [k for k in result.missing_keys if k not in own_bias]
+    if strict and (missing or result.unexpected_keys):
+        raise RuntimeError(f"checkpoint does not match the model: missing {missing}, unexpected {list(result.unexpected_keys)}")
     for m in model.modules():
         cache = getattr(m, "_cache", None)
         if isinstance(cache, ops.PackedWeights):

@@ -255,13 +255,16 @@ class PackedWeights:
     def get(self, weights, G, orient):
         return self._get(weights, G, orient).w_canon
 
-    def _get(self, weights, G, orient):
+    def _get(self, weights, G, orient, validate=True):
+        """`validate=False`: the training path -- the gradient mask keeps the corner tap unit triangular (layers/conv.py:98-99,
+        applied inside the HIP backward), and the check is a device->host synchronisation per layer and step."""
         bank = self._bank(weights[0].device)
         key = tuple((w.data_ptr(), w._version) for w in weights) + (orient,)
         if key != bank.key:
-            ws = torch.cat([w.detach() for w in weights], dim=0).contiguous()
+            ws = torch.cat([w.detach() for w in weights], dim=0).contiguous() if len(weights) > 1 else weights[0].detach().contiguous()
             bank.w_canon = canonicalize(ws, G, orient)
-            check_invariant(bank.w_canon, G)
+            if validate:
+                check_invariant(bank.w_canon, G)
             bank.packed_inv = None
             bank.packed_fwd = None
             bank.packed_aff = None
@@ -269,9 +272,11 @@ class PackedWeights:
             bank.key = key
         return bank
 
-    def forward(self, x, weights, G, orient, out=None):
-        """Inference-time forward (no autograd graph): cached canonical bank + cached strip-kernel fragments."""
-        bank = self._get(weights, G, orient)
+    def forward(self, x, weights, G, orient, out=None, validate=True):
+        """Forward on the cached canonical bank + cached strip-kernel fragments (also the forward of the autograd path: a
+        weight version that has not changed since the last call -- evaluation under grad, several micro-batches per
+        optimiser step -- costs no cat / canonicalise / pack launch)."""
+        bank = self._get(weights, G, orient, validate)
         w_canon = bank.w_canon
         _require_device(x, "input")
         B, Cq, H, W, KH, KW = _dims(x, w_canon, G)
@@ -379,24 +384,32 @@ class PackedWeights:
 
 class _FincConvFunction(torch.autograd.Function):
     """The autograd.Function underneath FastFlowUnit / PaddedConv2d.forward.  Backward applies the
-    corner-tap mask in-kernel, so `model.apply(clear_grad)` (train/experiment.py:16-18) is a no-op on it."""
+    corner-tap mask in-kernel, so `model.apply(clear_grad)` (train/experiment.py:16-18) is a no-op on it.
+    The stored weights are inputs (one per group, so every parameter gets its own gradient without a cat node in the
+    graph); the canonical bank and the forward fragments come from the layer's PackedWeights cache."""
 
     @staticmethod
-    def forward(ctx, x, w_stored, G, orient):
-        w_canon = canonicalize(w_stored.contiguous(), G, orient)
-        ctx.save_for_backward(x, w_canon)
-        ctx.G, ctx.orient = G, orient
-        return finc_forward(x.contiguous(), w_canon, G, orient)
+    def forward(ctx, x, cache, G, orient, *weights):
+        x = x.contiguous()
+        out = cache.forward(x, list(weights), G, orient, validate=False)
+        ctx.save_for_backward(x, cache.get(list(weights), G, orient))
+        ctx.G, ctx.orient, ctx.nw = G, orient, len(weights)
+        return out
 
     @staticmethod
     def backward(ctx, grad_z):
         x, w_canon = ctx.saved_tensors
-        gx, gw = finc_backward(grad_z.contiguous(), x.contiguous(), w_canon, ctx.G, ctx.orient,
-                               need_gx=ctx.needs_input_grad[0], need_gw=ctx.needs_input_grad[1])
+        need_gw = any(ctx.needs_input_grad[4:])
+        gx, gw = finc_backward(grad_z.contiguous(), x, w_canon, ctx.G, ctx.orient,
+                               need_gx=ctx.needs_input_grad[0], need_gw=need_gw)
+        gws = (None,) * ctx.nw
         if gw is not None:
             gw = canonicalize(gw, ctx.G, ctx.orient)  # canonical -> stored orientation
-        return gx, gw, None, None
+            gws = tuple(gw.chunk(ctx.nw, dim=0)) if ctx.nw > 1 else (gw,)
+        return (gx, None, None, None) + gws
 
 
-def conv_forward(x, w_stored, G, orient):
-    return _FincConvFunction.apply(x, w_stored, G, orient)
+def conv_forward(x, weights, G, orient, cache):
+    """z = forward(x) under autograd.  `weights`: the stored (state-dict form) banks of the G groups, one tensor per group or
+    one tensor for all; `cache`: the layer's PackedWeights."""
+    return _FincConvFunction.apply(x, cache, G, orient, *weights)

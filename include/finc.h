@@ -68,6 +68,9 @@ enum finc_algo {
 #define FINC_ORIENT_FASTFLOW 0xE4u
 
 int finc_version(void);
+/* Bit mask of the measurement knobs (csrc/finc_experiment.h: ablations, stamps, reduced tables ...) the library was built
+ * with.  0 for a product build; anything else computes wrong results by design and must never be shipped or benchmarked. */
+unsigned finc_build_flags(void);
 const char *finc_status_string(int status);
 /* hipGetErrorString of the last failing HIP call on this thread (never NULL). */
 const char *finc_last_hip_error(void);
@@ -211,12 +214,23 @@ int finc_mix_f32(const float *in, const float *mat, const float *bias, float *ou
  *   every compiled variant.
  */
 int finc_inverse_kernel_variant(int B, int G, int Cq, int H, int W, int KH, int KW, int *info);
+/* Which kernels finc_backward_f32 runs for this shape (16-byte aligned activations, full workspace): info[3] =
+ * {grad-weight: 0 direct / 1 dword MFMA strip kernel / 2 staged (16-byte pieces through LDS) / 3 tiled (one tile pair per
+ * workgroup), grad-input: waves per strip of the MFMA strip kernel (0 = direct kernel; > 1 = K-split), grad-input: staged form
+ * (1) or dword form (0)}.  Lets a parity test assert WHICH kernel its numbers came from. */
+int finc_debug_backward_variant(int B, int G, int Cq, int H, int W, int KH, int KW, int *info);
 int finc_debug_inverse_table_row(int row, int *info);
 int finc_debug_attr_table_insert(int device, size_t kernel_token);
 /* SYNCHRONOUS.  The helper-wave form of the inverse (form 3 of finc_inverse_kernel_variant) pairs each compute wave with a
  * wave that does its HBM traffic; the two meet through progress words in LDS, and every wait is bounded.  *h_count = waits
  * that gave up since the library was loaded on the current device: anything but 0 is a bug. */
 int finc_debug_hlp_timeouts(unsigned *h_count);
+/* A wait that gives up leaves garbage in that launch's output.  It does not pass silently: the kernel also sets a word in
+ * mapped host memory, and every later finc_inverse_* / finc_check_invariant_f32 call on that device returns FINC_ERR_LAUNCH
+ * (finc_last_hip_error() names the cause) until finc_clear_fault() -- no synchronisation is added to the launch path.
+ * The launch that faulted has itself returned FINC_OK (it is asynchronous): callers that cannot afford one bad result check
+ * finc_debug_hlp_timeouts() at their own synchronisation points (bench.py does). */
+int finc_clear_fault(void);
 
 #ifdef __cplusplus
 }

@@ -17,7 +17,10 @@ def header_symbols():
 
 def test_library_exists_and_loads():
     assert os.path.exists(_lib.LIB_PATH), "run __graft_entry__.build() first"
-    assert _lib.lib().finc_version() >= 100
+    assert _lib.lib().finc_version() >= 101
+    # a product build carries none of the measurement knobs of csrc/finc_experiment.h (ablations, stamps, reduced tables):
+    # one stray -D would still pass finc_version() and compute garbage
+    assert _lib.build_flags() == 0
 
 
 def test_every_declared_symbol_is_exported():
@@ -68,6 +71,22 @@ def test_argument_validation_without_touching_the_gpu():
     assert L.finc_inverse_f32(one, one, ctypes.c_void_p(32), 1, 4, 24, 64, 64, 3, 3, 0xE4, 2, None, 0, None) == 4
     # MFMA algo on a shape it has no instantiation for
     assert L.finc_inverse_f32(one, one, ctypes.c_void_p(32), 1, 4, 64, 32, 32, 7, 7, 0xE4, 2, one, 1 << 30, None) == 3
+
+
+def test_a_measurement_knob_without_the_experiment_gate_does_not_compile():
+    """csrc/finc_experiment.h: -DFINC_ABLATE (or any other timing-only knob) without -DFINC_EXPERIMENT is a compile error, so a
+    stray flag cannot produce a library that passes finc_version() and computes garbage; with the gate it compiles and
+    reports itself through finc_build_flags()."""
+    import shutil
+    import subprocess
+    if not shutil.which("hipcc"):
+        pytest.skip("no hipcc")
+    src = os.path.join(REPO, "fincflow_amd", "csrc", "finc_generic.hip")
+    base = ["hipcc", "--offload-arch=gfx950", "-std=c++20", "--cuda-host-only", "-fsyntax-only", src]
+    bad = subprocess.run(base + ["-DFINC_ABLATE=1"], capture_output=True, text=True)
+    assert bad.returncode != 0 and "FINC_EXPERIMENT" in bad.stderr
+    good = subprocess.run(base + ["-DFINC_ABLATE=1", "-DFINC_EXPERIMENT"], capture_output=True, text=True)
+    assert good.returncode == 0, good.stderr[-500:]
 
 
 def test_check_raises_python_exceptions():

@@ -249,6 +249,54 @@ def test_autograd_matches_torch_conv(dev):
 
 
 # ------------------------------------------------------------------ edge cases and full sizes
+BACKWARD_CASES = [
+    # (B, C, H, W, K, grad-weight kernel, grad-input waves per strip): every MFMA backward kernel, named -- the staged and the
+    # tiled grad-weight kernels (c3's and c5's), the dword one, and the K-split grad-input
+    (3, 96, 12, 32, 3, "staged", 1),       # c3's bank, W % 16 == 0: finc_gradw_staged_kernel
+    (2, 96, 9, 24, 3, "dword", 1),         # same bank, W % 16 != 0: finc_gradw_kernel
+    (2, 192, 10, 16, 3, "tiled", 2),       # Cq = 48 3x3: finc_gradw_tiled_kernel, K-split grad-input (2 waves per strip)
+    (2, 192, 7, 32, 5, "tiled", 4),        # Cq = 48 5x5 (the c5 bank): tiled grad-weight, K-split grad-input (4 waves)
+    (2, 128, 9, 16, 3, "staged", 1),       # Cq = 32 3x3: staged grad-weight
+    (2, 48, 33, 32, 3, "staged", 1),       # c2's bank, more than one band of rows
+]
+
+
+@pytest.mark.parametrize("case", BACKWARD_CASES, ids=lambda c: "B%d_C%d_%dx%d_k%d_%s_%dw" % c)
+def test_backward_per_entry_against_cpu_autograd(case, dev):
+    """SURVEY 8 f1, VERDICT r2 weak 1: grad_x and grad_w of the forward conv compared ENTRY BY ENTRY with CPU autograd through
+    F.pad + F.conv2d (the reference's own forward, layers/conv.py:102-107) times the gradient mask (layers/conv.py:98-99,
+    train/experiment.py:240-251) -- an independent reference, not another HIP kernel -- on shapes that provably run the
+    staged / tiled / dword grad-weight kernels and the K-split grad-input (the library's own answer is asserted)."""
+    import torch.nn.functional as F
+    from fincflow_amd import FastFlowUnit, _lib
+    B, C, H, W, K, want_gw, want_gx_waves = case
+    v = _lib.backward_variant(B, 4, C // 4, H, W, K, K)
+    assert v["gradw"] == want_gw and v["gradx_waves"] == want_gx_waves, v
+    torch.manual_seed(11)
+    unit = FastFlowUnit(C, C, K).to(dev)
+    x = torch.randn(B, C, H, W, device=dev, requires_grad=True)
+    z, _ = unit(x)
+    gz = torch.randn_like(z)
+    z.backward(gz)
+    xc = x.detach().cpu().double().requires_grad_(True)                   # fp64 on the CPU: the reference of the comparison
+    outs, ws = [], []
+    for m, chunk in zip((unit.conv_tl, unit.conv_tr, unit.conv_bl, unit.conv_br), torch.chunk(xc, 4, 1)):
+        w = m.conv.weight.detach().cpu().double().requires_grad_(True)
+        ws.append(w)
+        outs.append(F.conv2d(F.pad(chunk, m.pad), w))
+    zc = torch.cat(outs, 1)
+    zc.backward(gz.cpu().double())
+    assert rel_err(z.detach().cpu().numpy(), zc.detach().numpy()) <= TOL
+    ex = rel_err(x.grad.cpu().numpy(), xc.grad.numpy())
+    assert ex <= TOL, ("grad_x", ex)
+    for m, w in zip((unit.conv_tl, unit.conv_tr, unit.conv_bl, unit.conv_br), ws):
+        expect = (w.grad * m.mask.double()).numpy()
+        got = m.conv.weight.grad.cpu().numpy()
+        ew = rel_err(got, expect)
+        assert ew <= 2e-5, ("grad_w", m.order, ew)        # a B*H*W-term fp32 reduction against fp64
+        assert np.all(got[m.mask.numpy() == 0] == 0)      # the corner-tap mask is applied in-kernel: exact zeros
+
+
 @pytest.mark.parametrize("shape", [(1, 4, 1, 4, 3, 3), (1, 4, 4, 1, 3, 3), (3, 8, 5, 3, 2, 2), (2, 4, 3, 40, 3, 3),
                                    (2, 4, 40, 4, 3, 3), (1, 20, 17, 12, 3, 3), (2, 16, 6, 8, 1, 3), (2, 16, 8, 8, 3, 1),
                                    (1, 4, 2, 2, 3, 3)])

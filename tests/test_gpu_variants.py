@@ -264,7 +264,7 @@ def test_staged_forward_against_the_oracle(shape, dev):
     gz = rng.standard_normal(z.shape).astype(np.float32)
     x2 = rng.standard_normal(x.shape).astype(np.float32)
     xt = t(x, dev).requires_grad_(True)
-    ops.conv_forward(xt, t(ws, dev), G, orient).backward(t(gz, dev))
+    ops.conv_forward(xt, [t(ws, dev)], G, orient, ops.PackedWeights()).backward(t(gz, dev))
     lhs = float(np.sum(gz.astype(np.float64) * oracle.forward_f32(x2, wco, G, orient)))
     rhs = float(np.sum(xt.grad.cpu().numpy().astype(np.float64) * x2))
     assert abs(lhs - rhs) <= 1e-4 * max(1.0, abs(lhs)), (shape, lhs, rhs)
@@ -318,16 +318,19 @@ def test_fp64_inverse_is_bit_exact_with_the_reference_solver(shape, dev):
 # ------------------------------------------------------------------ PaddedConv2d(bias=True)
 @pytest.mark.parametrize("order", ["TL", "BR"])
 def test_padded_conv_with_bias(order, dev):
-    """layers/conv.py:60,102-117: conv(pad(x)) + b forward, reverse subtracts b first; state dict carries conv.bias."""
+    """layers/conv.py:60,102-117: conv(pad(x)) + b forward, reverse subtracts b first.  The holder conv stays bias-free as in
+    the reference (its nn.Conv2d is built with bias=False whatever the argument), the bias is the layer's own zero-initialised
+    parameter: the state dict is the reference's key plus `bias`."""
     import torch.nn.functional as F
     from fincflow_amd import PaddedConv2d
     torch.manual_seed(4)
     m = PaddedConv2d(6, 6, (3, 3), bias=True, order=order)
-    assert sorted(m.state_dict().keys()) == ["conv.bias", "conv.weight"]
+    assert sorted(m.state_dict().keys()) == ["bias", "conv.weight"] and m.conv.bias is None
+    assert torch.equal(m.bias.detach(), torch.zeros(6))
     with torch.no_grad():
-        m.conv.bias.copy_(torch.randn(6))
+        m.bias.copy_(torch.randn(6))
     x = torch.randn(2, 6, 9, 12)
-    ref = F.conv2d(F.pad(x, m.pad), m.conv.weight.detach(), m.conv.bias.detach())
+    ref = F.conv2d(F.pad(x, m.pad), m.conv.weight.detach(), m.bias.detach())
     m = m.to(dev)
     with torch.no_grad():
         z, ld = m(x.to(dev))
@@ -337,7 +340,7 @@ def test_padded_conv_with_bias(order, dev):
     xg = x.to(dev).requires_grad_(True)                           # autograd path: bias gets its gradient too
     zz, _ = m(xg)
     zz.sum().backward()
-    assert m.conv.bias.grad is not None and torch.allclose(m.conv.bias.grad.cpu(), torch.full((6,), 2.0 * 9 * 12))
+    assert m.bias.grad is not None and torch.allclose(m.bias.grad.cpu(), torch.full((6,), 2.0 * 9 * 12))
 
 
 # ------------------------------------------------------------------ unaligned views through the module
@@ -507,3 +510,65 @@ def test_helper_wave_protocol_never_times_out(dev):
             for _ in range(300):
                 assert torch.equal(unit.reverse(z), ref)
     assert _lib.hlp_timeouts() == 0
+
+
+FAULT_SCRIPT = r"""
+import sys, torch
+sys.path.insert(0, %(repo)r)
+from fincflow_amd import FastFlowUnit, _lib
+assert _lib.build_flags() != 0                       # a test-only build: the knobs announce themselves
+dev = torch.device("cuda:0")
+unit = FastFlowUnit(96, 96, 3).to(dev)
+z = torch.randn(65, 96, 32, 32, device=dev)          # 260 problems: the helper-wave form (more than the role-split kernel takes)
+assert _lib.inverse_variant(65, 4, 24, 32, 32, 3, 3)["sec"] == 3
+with torch.no_grad():
+    unit.reverse(z)                                  # the injected fault: the helper never announces a landing -> waits give up
+    torch.cuda.synchronize()
+    n = _lib.hlp_timeouts()
+    assert n > 0, "the injected fault did not show in the counter"
+    try:
+        unit.reverse(z)
+        print("NOT-RAISED")
+    except _lib.FincError as e:
+        print("RAISED", "gave up" in str(e))
+    _lib.clear_fault()
+    unit.reverse(z)                                  # the gate is open again (the build still faults: the word is set anew)
+    torch.cuda.synchronize()
+    try:
+        unit.reverse(z)
+        print("NOT-RAISED-2")
+    except _lib.FincError:
+        print("RAISED-2")
+"""
+
+
+def test_a_protocol_timeout_is_an_error_not_a_silent_wrong_answer(dev, tmp_path):
+    """ADVICE r2 / VERDICT r2 weak 4: a helper-wave wait that gives up used to bump a counter nobody read.  Now the kernel
+    also sets a word in mapped host memory and the next finc_* call on the device returns FINC_ERR_LAUNCH (sticky until
+    finc_clear_fault()).  Exercised with a TEST-ONLY build (-DFINC_EXPERIMENT -DFINC_HLP_INJECT_TIMEOUT: the helper stops
+    announcing its landings) in a process of its own; the product library never carries the knob (finc_build_flags() == 0)."""
+    import os
+    import shutil
+    import subprocess
+    import sys
+    from helpers import REPO
+    if not shutil.which("hipcc"):
+        pytest.skip("no hipcc on this box")
+    csrc = os.path.join(REPO, "fincflow_amd", "csrc")
+    objs = [os.path.join(csrc, o) for o in ("finc_abi.o", "finc_generic.o", "finc_conv.o", "finc_gradw.o", "finc_mix.o")]
+    if not all(os.path.exists(o) for o in objs):
+        pytest.skip("object files of the product build are not in the tree")
+    lib = str(tmp_path / "libfinc_faulty.so")
+    flags = ["-O3", "-fPIC", "--offload-arch=gfx950", "-std=c++20", "-mllvm", "-amdgpu-mfma-vgpr-form", "-DFINC_EXPERIMENT", "-DFINC_ONLY_C3",
+             "-DFINC_HLP_INJECT_TIMEOUT", "-DFINC_HLP_BUDGET_LOG2=8"]
+    for name in ("finc_mfma", "finc_split"):
+        subprocess.run(["hipcc"] + flags + ["-c", os.path.join(csrc, name + ".hip"), "-o", str(tmp_path / (name + ".o"))], check=True,
+                       capture_output=True, timeout=600)
+    subprocess.run(["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs +
+                   [str(tmp_path / "finc_mfma.o"), str(tmp_path / "finc_split.o")], check=True, capture_output=True, timeout=300)
+    r = subprocess.run([sys.executable, "-c", FAULT_SCRIPT % {"repo": REPO}], env=dict(os.environ, FINCFLOW_LIB=lib),
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "RAISED True" in r.stdout and "RAISED-2" in r.stdout and "NOT-RAISED" not in r.stdout, r.stdout
+    from fincflow_amd import _lib
+    assert _lib.build_flags() == 0 and _lib.hlp_timeouts() == 0           # this process runs the product library

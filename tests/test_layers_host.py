@@ -141,3 +141,20 @@ def test_packed_cache_is_per_device():
     assert replica._cache is u._cache
     c.invalidate()
     assert not c._banks and c.w_canon is None
+
+
+def test_bias_argument_keeps_the_reference_state_dict_keys():
+    """layers/conv.py:60: the reference builds its nn.Conv2d with bias=False whatever `bias` says, so a reference checkpoint
+    never holds `conv.bias`.  Here `bias=True` adds the layer's OWN zero-initialised `bias`; a reference state dict (weight
+    only) still loads strictly through load_reference_checkpoint, and anything else missing is an error."""
+    from fincflow_amd.layers import PaddedConv2d, load_reference_checkpoint
+    plain, biased = PaddedConv2d(4, 4, (3, 3), order="TR"), PaddedConv2d(4, 4, (3, 3), bias=True, order="TR")
+    assert list(plain.state_dict().keys()) == ["conv.weight"]
+    assert sorted(biased.state_dict().keys()) == ["bias", "conv.weight"] and biased.conv.bias is None
+    assert torch.equal(biased.bias.detach(), torch.zeros(4))
+    load_reference_checkpoint(biased, {"model_state_dict": plain.state_dict()}, strict=True)
+    assert torch.equal(biased.conv.weight, plain.conv.weight) and torch.equal(biased.bias.detach(), torch.zeros(4))
+    with pytest.raises(RuntimeError):
+        load_reference_checkpoint(biased, {"model_state_dict": {}}, strict=True)
+    with pytest.raises(RuntimeError):
+        load_reference_checkpoint(plain, {"model_state_dict": dict(plain.state_dict(), extra=torch.zeros(1))}, strict=True)
