@@ -64,6 +64,12 @@ class ActNorm(FlowLayer):
         self.initialized.fill_(1)
         self._init_known = True
 
+    def reset_initialization(self):
+        """Ask for the data-dependent initialisation again (the next forward computes it).  Writing the `initialized` buffer
+        directly is not seen by the host-side mirror once it is known."""
+        self.initialized.fill_(0)
+        self._init_known = False
+
     def _shaped(self, input):
         shape = (1, -1) + (1,) * (input.dim() - 2)
         return self.translation.view(shape), self.log_scale.view(shape)
