@@ -346,6 +346,15 @@ __global__ __launch_bounds__(64 * NW)
     const unsigned lin1 = (colok && lastok) ? coloff + qoff : OFF_BAD_CHANNEL;
     const unsigned lhal0 = hok ? hcoloff + qoff : OFF_BAD_CHANNEL;
     const unsigned lhal1 = (hok && lastok) ? hcoloff + qoff : OFF_BAD_CHANNEL;
+    unsigned linj[NW > 1 ? NKZ : 1], lhalj[NW > 1 ? NKZ : 1];   // (K-split) lane offsets per k-step: OFF_BAD_CHANNEL where channel 4j + q >= CQ
+    if constexpr (NW > 1) {
+#pragma unroll
+        for (int j = 0; j < NKZ; ++j) {
+            const bool chok = 4 * (wv * NKZ + j) + q < CQ;
+            linj[j] = (colok && chok) ? coloff + qoff : OFF_BAD_CHANNEL;
+            lhalj[j] = (hok && chok) ? hcoloff + qoff : OFF_BAD_CHANNEL;
+        }
+    }
     const unsigned lo_base = colok ? coloff + 4u * qoff : OFF_BAD_CHANNEL;   // 16-row tile: channel 16mt + 4q + r
     unsigned lo_tail[4];                                  // last 16-row tile when it ends the group (Cq % 16 == 0 shapes)
 #pragma unroll
@@ -393,10 +402,14 @@ __global__ __launch_bounds__(64 * NW)
 #pragma unroll
         for (int j = 0; j < NKZ; ++j) {
             const int so = 4 * (wv * NKZ + j) * HW * 4;   // uniform: channel 4j of this wave's k-step j
-            const unsigned u = __builtin_amdgcn_raw_buffer_load_b32(rin, j == NKZ - 1 ? v1 : v0, so, 0);
+            // K-split banks also serve channel counts well below CQP (Cq = 50 on the 64-channel bank): there ANY k-step of the
+            // last waves may hold padded channels, so every k-step has its own lane offsets (one mark at most: no wrap past 2^32)
+            const unsigned vj = NW > 1 ? ro + linj[j] : (j == NKZ - 1 ? v1 : v0);
+            const unsigned u = __builtin_amdgcn_raw_buffer_load_b32(rin, vj, so, 0);
             nxt[j] = __builtin_bit_cast(float, u);
             if constexpr (KW > 1) {
-                const unsigned uh = __builtin_amdgcn_raw_buffer_load_b32(rin, j == NKZ - 1 ? h1 : h0, so, 0);
+                const unsigned hj = NW > 1 ? ro + lhalj[j] : (j == NKZ - 1 ? h1 : h0);
+                const unsigned uh = __builtin_amdgcn_raw_buffer_load_b32(rin, hj, so, 0);
                 nxh[j] = __builtin_bit_cast(float, uh);
             }
         }
@@ -585,15 +598,19 @@ const ConvInst g_conv[] = {
     make_conv<24, 3, 3>(), make_conv<28, 3, 3>(), make_conv<32, 3, 3>(), make_conv<40, 3, 3, 2>(), make_conv<48, 3, 3, 2>(), make_conv<64, 3, 3, 4>(),
     make_conv<4, 2, 2>(),  make_conv<8, 2, 2>(),  make_conv<12, 2, 2>(), make_conv<16, 2, 2>(), make_conv<24, 2, 2>(),
     make_conv<32, 2, 2>(),
-    make_conv<4, 5, 5>(),  make_conv<8, 5, 5>(),  make_conv<12, 5, 5>(), make_conv<16, 5, 5>(), make_conv<32, 5, 5, 4>(), make_conv<48, 5, 5, 4>(),
+    make_conv<4, 5, 5>(),  make_conv<8, 5, 5>(),  make_conv<12, 5, 5>(), make_conv<16, 5, 5>(), make_conv<24, 5, 5, 2>(), make_conv<32, 5, 5, 4>(),
+    make_conv<48, 5, 5, 4>(),
     make_conv<4, 3, 5>(),  make_conv<4, 1, 3>(),  make_conv<4, 3, 1>(),
 };
+// the smallest compiled bank that holds Cq channels (padded channels are masked in-kernel: one-wave banks hold up to 3 of
+// them -- the table has every multiple of 4 there --, the K-split banks any number)
 const ConvInst *find_conv(int Cq, int KH, int KW)
 {
-    const int cqp = (Cq + 3) / 4 * 4;
+    const ConvInst *best = nullptr;
     for (const ConvInst &i : g_conv)
-        if (i.cqp == cqp && i.kh == KH && i.kw == KW) return &i;
-    return nullptr;
+        if (i.cqp >= Cq && i.kh == KH && i.kw == KW && (!best || i.cqp < best->cqp)) best = &i;
+    if (best && best->nw == 1 && best->cqp - Cq > 3) return nullptr;   // (a one-wave kernel masks the last group of four only)
+    return best;
 }
 
 } // namespace

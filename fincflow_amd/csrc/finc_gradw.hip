@@ -541,15 +541,17 @@ const GradwInst g_gradw[] = {
     make_gradw<24, 3, 3>(), make_gradw<28, 3, 3>(), make_gradw<32, 3, 3>(), make_gradw<40, 3, 3>(), make_gradw<48, 3, 3>(), make_gradw<64, 3, 3>(),
     make_gradw<4, 2, 2>(),  make_gradw<8, 2, 2>(),  make_gradw<12, 2, 2>(), make_gradw<16, 2, 2>(), make_gradw<24, 2, 2>(),
     make_gradw<32, 2, 2>(),
-    make_gradw<4, 5, 5>(),  make_gradw<8, 5, 5>(),  make_gradw<12, 5, 5>(), make_gradw<16, 5, 5>(), make_gradw<32, 5, 5>(), make_gradw<48, 5, 5>(),
+    make_gradw<4, 5, 5>(),  make_gradw<8, 5, 5>(),  make_gradw<12, 5, 5>(), make_gradw<16, 5, 5>(), make_gradw<24, 5, 5>(), make_gradw<32, 5, 5>(),
+    make_gradw<48, 5, 5>(),
     make_gradw<4, 3, 5>(),  make_gradw<4, 1, 3>(),  make_gradw<4, 3, 1>(),
 };
+// the smallest compiled bank that holds Cq channels (every kernel here tests `channel < CQ` per lane: any padding is fine)
 const GradwInst *find_gradw(int Cq, int KH, int KW)
 {
-    const int cqp = (Cq + 3) / 4 * 4;
+    const GradwInst *best = nullptr;
     for (const GradwInst &i : g_gradw)
-        if (i.cqp == cqp && i.kh == KH && i.kw == KW) return &i;
-    return nullptr;
+        if (i.cqp >= Cq && i.kh == KH && i.kw == KW && (!best || i.cqp < best->cqp)) best = &i;
+    return best;
 }
 
 } // namespace

@@ -435,7 +435,15 @@ __global__ __launch_bounds__(HLP ? 512 : 64 * NW * NPW) void finc_wave_kernel(co
     unsigned cmask[NKD];
 #pragma unroll
     for (int j = 0; j < NKD; ++j) cmask[j] = chan_d(C::MTB, wv * NKD + j, q) < CQ ? 0u : OFF_BAD_CHANNEL;
-    const unsigned zlast = (4 * (wv * NKZ + NKZ - 1) + q) < CQ ? 0u : OFF_BAD_CHANNEL;  // only the last k-step can hold a padded channel
+    const unsigned zlast = (4 * (wv * NKZ + NKZ - 1) + q) < CQ ? 0u : OFF_BAD_CHANNEL;  // only the last k-step can hold a padded channel ...
+    // ... in the one-wave kernels (the table has every multiple of 4 there).  The K-split banks also serve channel counts well
+    // below CQP (Cq = 50 on the 64-channel bank): any k-step of the last waves may be padded, so each has its own mark.
+    unsigned zpad[NW > 1 ? NKZ : 1];
+    if constexpr (NW > 1) {
+#pragma unroll
+        for (int j = 0; j < NKZ; ++j) zpad[j] = (4 * (wv * NKZ + j) + q) < CQ ? 0u : OFF_BAD_CHANNEL;
+    }
+    auto zmark = [&](int j) { return NW > 1 ? zpad[j] : (j == NKZ - 1 ? zlast : 0u); };
     const int rowstep = (fh ? -P : P) * W * 4;                               // bytes from a row to the same column of row+P
     const int dirw = fw ? -1 : 1;
 
@@ -614,7 +622,7 @@ __global__ __launch_bounds__(HLP ? 512 : 64 * NW * NPW) void finc_wave_kernel(co
         const unsigned vb = ok ? (unsigned)loffS[WP] : OFF_INVALID;
 #pragma unroll
         for (int j = 0; j < NKZ; ++j)
-            Z[WP][j] = __builtin_amdgcn_raw_buffer_load_b128(rin, j == NKZ - 1 ? vb + zlast : vb, j * 16 * HW, FINC_LD_AUX);
+            Z[WP][j] = __builtin_amdgcn_raw_buffer_load_b128(rin, (NW > 1 || j == NKZ - 1) ? vb + zmark(j) : vb, j * 16 * HW, FINC_LD_AUX);
         lcolS[WP] += 8;
         loffS[WP] += 32 * dirw;
         if (lcolS[WP] == W) { lcolS[WP] = 0; lrowS[WP] += P; loffS[WP] += rowstep - dirw * W * 4; }
@@ -659,7 +667,7 @@ __global__ __launch_bounds__(HLP ? 512 : 64 * NW * NPW) void finc_wave_kernel(co
         if constexpr (!SEC) return;
         const unsigned vt = st_off == OFF_INVALID ? OFF_INVALID : st_off + lane_t;
         const unsigned vb = st_off == OFF_INVALID ? OFF_INVALID : st_off + lane_b;
-        const int cpad = C::CQP - CQ;                           // 0..3 padded channels (uniform)
+        const int cpad = C::CQP - CQ;                           // padded channels (uniform; 0..3 in the one-wave kernels)
 #pragma unroll
         for (int j = 0; j < NKD; ++j) {
             if (j < j0 || j >= j1) continue;
@@ -670,7 +678,7 @@ __global__ __launch_bounds__(HLP ? 512 : 64 * NW * NPW) void finc_wave_kernel(co
             unsigned vo = tile ? vt : vb;
             // only a register of the last channel group can hold a padded channel
             const bool last_group = tile ? (C::NSM == 0 && (jj >> 2) == C::MTB - 1) : jj == C::NKDT - 1;
-            if (last_group && cpad != 0) vo += cmask[j];
+            if ((NW > 1 || last_group) && cpad != 0) vo += cmask[j];   // (K-split banks: any register may hold a padded channel)
             v4u v;
             v.x = __builtin_bit_cast(unsigned, XS[WP][j][0]);
             v.y = __builtin_bit_cast(unsigned, XS[WP][j][1]);
@@ -724,7 +732,7 @@ __global__ __launch_bounds__(HLP ? 512 : 64 * NW * NPW) void finc_wave_kernel(co
 #pragma unroll
         for (int j = 0; j < NKZ; ++j) {
             if (j < j0 || j >= j1) continue;
-            zb[j] = __builtin_amdgcn_raw_buffer_load_b128(rin, j == NKZ - 1 ? vb + zlast : vb, j * 16 * HW, FINC_LD_AUX);
+            zb[j] = __builtin_amdgcn_raw_buffer_load_b128(rin, (NW > 1 || j == NKZ - 1) ? vb + zmark(j) : vb, j * 16 * HW, FINC_LD_AUX);
         }
         if (advance) {
             lcol += 4;
@@ -769,7 +777,7 @@ __global__ __launch_bounds__(HLP ? 512 : 64 * NW * NPW) void finc_wave_kernel(co
             const int uni = __builtin_amdgcn_readfirstlane((tile ? 16 * (jj >> 2) + (jj & 3) : 16 * C::MTB + 4 * (jj - 4 * C::MTB)) * HW * 4);
             unsigned vo = tile ? vt : vb;
             const bool last_group = tile ? (C::NSM == 0 && (jj >> 2) == C::MTB - 1) : jj == C::NKDT - 1;
-            if (last_group && cpad != 0) vo += cmask[j];
+            if ((NW > 1 || last_group) && cpad != 0) vo += cmask[j];
             v4u v;
             v.x = __builtin_bit_cast(unsigned, sv[j][0]);
             v.y = __builtin_bit_cast(unsigned, sv[j][1]);
@@ -1484,7 +1492,9 @@ const Inst g_insts[] = {
     make_inst<40, 3, 3, 2, 2>(), make_inst<40, 3, 3, 2>(), make_inst<48, 3, 3, 4>(), make_inst<64, 3, 3, 4>(),
     FINC_BOTH(4, 2, 2),  FINC_BOTH(8, 2, 2),  FINC_BOTH(12, 2, 2), FINC_BOTH(16, 2, 2), FINC_BOTH(24, 2, 2), FINC_BOTH(32, 2, 2),
     FINC_BOTH(4, 5, 5),  FINC_BOTH(8, 5, 5),  FINC_BOTH(12, 5, 5), FINC_BOTH(16, 5, 5),
-    make_inst<32, 5, 5, 4>(), make_inst<48, 5, 5, 4>(),
+    // (Cq = 17 .. 24 at 5x5 -- the 20-channel 5x5 layers of fastflow/test_examples.py:218-222 -- on two waves: the operands
+    // of a 5x5 filter do not rotate in place, and their ageing copies beside 450 fragments do not fit one wave)
+    make_inst<24, 5, 5, 2>(), make_inst<32, 5, 5, 4>(), make_inst<48, 5, 5, 4>(),
     FINC_BOTH(4, 3, 5),
 };
 #endif
@@ -1507,9 +1517,25 @@ bool finc_no_s64()
 
 // first variant of the shape (any: they share the packed layout); with a problem count and a width, the first variant
 // that may run them
+// Cq padded to the smallest compiled bank that holds it (0: none).  One-wave kernels mask the last group of four only -- the
+// table has every multiple of 4 up to their largest bank --, the K-split banks any number of padded channels.
+int padded_cq(int Cq, int KH, int KW)
+{
+    int best = 0, nw = 1;
+    for (const Inst &i : g_insts)
+        if (i.cqp >= Cq && i.kh == KH && i.kw == KW && (best == 0 || i.cqp < best)) { best = i.cqp; nw = i.nw; }
+    if (best && best - Cq > 3) {               // needs a K-split bank: every variant of that bank must be one
+        for (const Inst &i : g_insts)
+            if (i.cqp == best && i.kh == KH && i.kw == KW && i.nw == 1) return 0;
+    }
+    (void)nw;
+    return best;
+}
+
 const Inst *find_inst(int Cq, int KH, int KW, long long problems = -1, int W = 0)
 {
-    const int cqp = (Cq + 3) / 4 * 4;
+    const int cqp = padded_cq(Cq, KH, KW);
+    if (cqp == 0) return nullptr;
     for (const Inst &i : g_insts) {
         if (i.cqp != cqp || i.kh != KH || i.kw != KW) continue;
         if (problems >= 0) {

@@ -621,6 +621,58 @@ def test_wider_instantiation_table(cfg, dev):
         assert rel_err(ops.finc_forward(t(x, dev), wc, algo="auto").cpu().numpy(), z) <= TOL
 
 
+PADDED_BANK_CASES = [
+    # (Cq, K, std, B, H, W): channel counts BETWEEN the compiled banks -- the reference's own shape sweep has 20-channel 5x5 and
+    # 50-channel 3x3 layers (fastflow/test_examples.py:218-222) -- run on the next larger bank with the padded channels masked
+    # (these used to fall to the scalar kernel, 100x slower)
+    (36, 3, 0.03, 2, 19, 24), (44, 3, 0.03, 1, 18, 32), (50, 3, 0.025, 1, 20, 24), (52, 3, 0.025, 2, 9, 20), (61, 3, 0.02, 1, 17, 16),
+    (20, 5, 0.02, 2, 21, 24), (18, 5, 0.02, 1, 9, 20), (28, 5, 0.02, 1, 18, 16), (40, 5, 0.015, 1, 10, 24),
+]
+
+
+@pytest.mark.parametrize("case", PADDED_BANK_CASES, ids=lambda c: "Cq%d_k%d" % (c[0], c[1]))
+def test_channel_counts_between_the_compiled_banks(case, dev):
+    """Inverse, forward and backward for a Cq that has no bank of its own: the library answers MFMA (not strict), the variant
+    reports the padded bank, and the results match the oracle / CPU autograd per entry."""
+    import torch.nn.functional as F
+    from fincflow_amd import FastFlowUnit, _lib, ops
+    Cq, K, std, B, H, W = case
+    L = _lib.lib()
+    assert L.finc_inverse_algo_for(Cq, H, W, K, K) == _lib.ALGO["mfma"] and L.finc_forward_algo_for(Cq, H, W, K, K) == _lib.ALGO["mfma"]
+    v = _lib.inverse_variant(B, 4, Cq, H, W, K, K)
+    assert v is not None and v["cqp"] >= Cq and v["cqp"] - Cq >= 0 and v["nw"] > 1, v
+    rng = np.random.default_rng(Cq * 7 + K)
+    ws = oracle.make_stored_weights(4, Cq, K, K, seed=Cq + K, std=std)
+    wco = oracle.canonicalize(ws, 4, ORIENT_FASTFLOW)
+    x = rng.standard_normal((B, 4 * Cq, H, W)).astype(np.float32)
+    z = oracle.forward_f32(x, wco, nthreads=8)
+    ref, ref32 = oracle.inverse_via_f64(z, wco, nthreads=8), oracle.inverse_f32(z, wco, nthreads=8)
+    tol = max(TOL, 2.0 * rel_err(ref32, ref))
+    wc = canon(ws, 4, ORIENT_FASTFLOW, dev)
+    assert rel_err(ops.finc_inverse(t(z, dev), wc, algo="mfma").cpu().numpy(), ref) <= tol
+    assert rel_err(ops.finc_forward(t(x, dev), wc, algo="mfma").cpu().numpy(), z) <= TOL
+    # backward through the module, per entry against CPU autograd (fp64)
+    torch.manual_seed(Cq)
+    unit = FastFlowUnit(4 * Cq, 4 * Cq, K).to(dev)
+    with torch.no_grad():
+        for cv in (unit.conv_tl, unit.conv_tr, unit.conv_bl, unit.conv_br):
+            cv.conv.weight.mul_(1 - (1 - std / 0.05) * cv.mask.to(dev))
+    xg = t(x, dev).requires_grad_(True)
+    zz, _ = unit(xg)
+    gz = torch.randn_like(zz)
+    zz.backward(gz)
+    xc = torch.from_numpy(x).double().requires_grad_(True)
+    outs, wsc = [], []
+    for m, chunk in zip((unit.conv_tl, unit.conv_tr, unit.conv_bl, unit.conv_br), torch.chunk(xc, 4, 1)):
+        w = m.conv.weight.detach().cpu().double().requires_grad_(True)
+        wsc.append(w)
+        outs.append(F.conv2d(F.pad(chunk, m.pad), w))
+    torch.cat(outs, 1).backward(gz.cpu().double())
+    assert rel_err(xg.grad.cpu().numpy(), xc.grad.numpy()) <= TOL
+    for m, w in zip((unit.conv_tl, unit.conv_tr, unit.conv_bl, unit.conv_br), wsc):
+        assert rel_err(m.conv.weight.grad.cpu().numpy(), (w.grad * m.mask.double()).numpy()) <= 2e-5
+
+
 def test_unaligned_activations_fall_back(dev):
     """A 4-byte aligned (not 16-byte aligned) activation pointer.  The wavefront kernel streams aligned 16-byte pieces:
     FINC_ALGO_AUTO takes the strict kernel for such a call instead of failing, and asking for the MFMA kernel explicitly
