@@ -58,10 +58,13 @@ WORKLOADS = {
     # BASELINE configs[4]: batch 512 sharded over 8 GPUs = 64 per GPU.  std 0.02: at 5x5/Cq=48 the init std 0.05 of
     # layers/conv.py:64 makes the inverse itself unstable; 0.02 matches the operator norm of c3.
     "c5": (64, 192, 128, 128, 5, 0.02),
+    # the per-GPU work of an 8-way STRONG split of configs[2] (256 images over 8 GPUs): 128 problems, fewer than compute units --
+    # the role-split kernel's regime (profiles, A/B runs; `--scaling strong --gpus 8` runs exactly this on every rank)
+    "c3_share8": (32, 96, 64, 64, 3, 0.05),
 }
-CONFIG_INDEX = {"c3": 2, "c2": 1, "c5": 4}
+CONFIG_INDEX = {"c3": 2, "c2": 1, "c5": 4, "c3_share8": 2}
 # single-thread CPU sample sizes (images): about 10-20 s of host work per workload
-CPU_SAMPLE_1T = {"c3": 64, "c2": 64, "c5": 2}
+CPU_SAMPLE_1T = {"c3": 64, "c2": 64, "c5": 2, "c3_share8": 32}
 
 
 def parse(argv=None):

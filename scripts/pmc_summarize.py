@@ -7,6 +7,8 @@ for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursiv
         k = row["Kernel_Name"]
         if "finc_wave_kernel" in k:
             k = "inverse"
+        elif "finc_split_kernel" in k:
+            k = "inverse_split"
         elif "finc_conv_kernel" in k:
             k = "forward"
         else:
