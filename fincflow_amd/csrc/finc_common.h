@@ -97,6 +97,13 @@ size_t finc_conv_packed_bytes(int G, int Cq, int KH, int KW);
 int finc_conv_pack(const float *wc, void *packed, int G, int Cq, int KH, int KW, bool transpose, hipStream_t st,
                    const float *scale = nullptr, const float *shift = nullptr);
 int finc_conv_launch(const float *in, const void *packed, float *out, const FincShape &s, hipStream_t st);
+// ---- 3x3 forward / grad-input with 1.5x fewer multiplies (Winograd F(2,3) along W): finc_wino.hip; its bank sits behind the
+// strip kernels' in the packed buffer
+size_t finc_wino_packed_bytes(int G, int Cq, int KH, int KW);          // 0: no Winograd kernel for this bank
+bool finc_wino_takes(const float *in, const float *out, const FincShape &s);
+int finc_wino_pack(const float *wc, void *packed, int G, int Cq, bool transpose, hipStream_t st, const float *scale, const float *shift);
+int finc_wino_launch(const float *in, const void *packed, float *out, const FincShape &s, hipStream_t st);
+unsigned finc_build_flags_wino();
 size_t finc_gradw_workspace_bytes(const FincShape &s); // 0: no MFMA grad-weight kernel for this shape
 int finc_gradw_launch(const float *gz, const float *x, float *gw, void *workspace, const FincShape &s, hipStream_t st);
 int finc_gradw_variant(const FincShape &s);   // 0 direct, 1 dword MFMA, 2 staged, 3 tiled

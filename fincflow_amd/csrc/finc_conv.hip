@@ -622,10 +622,13 @@ bool finc_conv_supported(int Cq, int H, int W, int KH, int KW)
     return true;
 }
 
+// the strip kernels' bank; behind it (3x3 banks one wave holds) the Winograd bank of finc_wino.hip: which of the two a launch
+// reads is decided per call (width parity, alignment), so a packed buffer carries both
+static size_t conv_bank_bytes(const ConvInst *i, int G) { return (size_t)(i->nfrag + 4 * i->mt) * 64 * sizeof(float) * (size_t)G; }
 size_t finc_conv_packed_bytes(int G, int Cq, int KH, int KW)
 {
     const ConvInst *i = find_conv(Cq, KH, KW);
-    return i ? (size_t)(i->nfrag + 4 * i->mt) * 64 * sizeof(float) * (size_t)G : 0;
+    return i ? conv_bank_bytes(i, G) + finc_wino_packed_bytes(G, Cq, KH, KW) : 0;
 }
 
 int finc_conv_pack(const float *wc, void *packed, int G, int Cq, int KH, int KW, bool transpose, hipStream_t st,
@@ -639,6 +642,8 @@ int finc_conv_pack(const float *wc, void *packed, int G, int Cq, int KH, int KW,
     hipLaunchKernelGGL(conv_pack_kernel, dim3(blocks, G), dim3(256), 0, st, wc, scale, shift, (float *)packed, Cq, KH, KW,
                        i->mt, i->mtb, i->nkz, transpose ? 1 : 0, i->nfrag);
     FINC_CHECK_LAUNCH();
+    if (finc_wino_packed_bytes(G, Cq, KH, KW))
+        return finc_wino_pack(wc, (char *)packed + conv_bank_bytes(i, G), G, Cq, transpose, st, scale, shift);
     return FINC_OK;
 }
 
@@ -646,6 +651,9 @@ int finc_conv_launch(const float *in, const void *packed, float *out, const Finc
 {
     const ConvInst *i = find_conv(s.Cq, s.KH, s.KW);
     if (!i || !finc_conv_supported(s.Cq, s.H, s.W, s.KH, s.KW)) return FINC_ERR_UNSUPPORTED;
+    // 3x3 with fewer multiplies (Winograd F(2,3) along W: finc_wino.hip) where the call allows it
+    if (finc_wino_packed_bytes(s.G, s.Cq, s.KH, s.KW) && finc_wino_takes(in, out, s))
+        return finc_wino_launch(in, (const char *)packed + conv_bank_bytes(i, s.G), out, s, st);
     const int NS = (s.W + 15) / 16;
     // about one wave per SIMD (measured: more chunks than that cost more in per-wave bank loads than they gain; 2 chunks
     // still pay up to 2 waves per SIMD), in chunks of at least 4 rows (every chunk recomputes KH-1 rows of operands)
@@ -675,7 +683,8 @@ int finc_conv_variant(int B, int G, int Cq, int H, int W, int KH, int KW, int *i
     info[0] = i->nw;
     info[1] = (i->fn_wide && W % 16 == 0 && !no_wide) ? 1 : 0;
     info[2] = (W + 15) / 16;
-    (void)B; (void)G; (void)H;
+    const FincShape s{B, G, Cq, H, W, KH, KW, 0};
+    if (finc_wino_packed_bytes(G, Cq, KH, KW) && finc_wino_takes(nullptr, nullptr, s)) info[1] = 2;   // (2: the Winograd kernel)
     return FINC_OK;
 }
 

@@ -23,4 +23,12 @@ scripts/pmc_run.sh ${TAG}_c3 > gpurun_out/${TAG}_pmc_c3.log 2>&1
 echo "pmc c3 done"
 scripts/pmc_run.sh ${TAG}_share8 --workload c3_share8 > gpurun_out/${TAG}_pmc_share8.log 2>&1
 echo "pmc share8 done"
-find gpurun_out/${TAG}_prof_c3 gpurun_out/${TAG}_prof_share8 -name "*kernel_stats.csv" | head
+# keep the summaries, drop the raw traces (gpurun merges at most 64 MiB back)
+mkdir -p gpurun_out/${TAG}
+cp $(find gpurun_out/${TAG}_prof_c3 -name "*kernel_stats.csv" | head -1) gpurun_out/${TAG}/c3_kernel_stats.csv
+cp $(find gpurun_out/${TAG}_prof_share8 -name "*kernel_stats.csv" | head -1) gpurun_out/${TAG}/c3_share8_kernel_stats.csv
+cp gpurun_out/pmc_${TAG}_c3/summary.json gpurun_out/${TAG}/c3_pmc_summary.json
+cp gpurun_out/pmc_${TAG}_share8/summary.json gpurun_out/${TAG}/c3_share8_pmc_summary.json
+mv gpurun_out/${TAG}_bench_*.json gpurun_out/${TAG}/
+rm -rf gpurun_out/${TAG}_prof_c3 gpurun_out/${TAG}_prof_share8 gpurun_out/pmc_${TAG}_c3 gpurun_out/pmc_${TAG}_share8
+ls -la gpurun_out/${TAG}
