@@ -77,6 +77,8 @@ def parse(argv=None):
                     help="weak: the workload's batch per GPU; strong: the workload's batch in total, B/N per GPU")
     ap.add_argument("--cpu-sample", type=int, default=None, help="images in the single-thread CPU baseline sample")
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
+    ap.add_argument("--no-share", action="store_true",
+                    help="skip the strong_share legs (profile runs: they launch other variants of the inverse kernel)")
     ap.add_argument("--master-port", type=int, default=None, help="rendezvous port when this process starts the ranks")
     return ap.parse_args(argv)
 
@@ -437,7 +439,7 @@ def bench_unit(args):
 
     # the per-GPU work of a STRONG split, measured on this one GPU: the share B/P of the workload's batch for P = 2, 4, 8
     strong_share = None
-    if world == 1 and args.scaling == "weak":
+    if world == 1 and args.scaling == "weak" and not args.no_share:
         from fincflow_amd import _lib as _l
         strong_share = {"what": "one GPU on the batch share Bw/P it would own in a P-way strong split of the workload's batch "
                                 "(single-GPU measurement of the per-GPU work, NOT a multi-GPU measurement)",
@@ -464,6 +466,8 @@ def bench_unit(args):
         E = B * C * H * W
         alg_bytes = 8 * E + 4 * C * Cq * K * K
         alg_flops = 2 * E * K * K * Cq
+        conv_form = _lt.backward_variant(B, 4, Cq, H, W, K, K)["conv_form"]
+        fwd_flops = alg_flops * 2 // 3 if conv_form == "winograd" else alg_flops   # 4 frequencies x 3 row taps per 2 outputs
         inv, fwd, smp = launch_stats(inv_per), launch_stats(fwd_per), launch_stats(smp_per)
         inv_launch_ms, fwd_launch_ms = inv["mean_ms"], fwd["mean_ms"]
         inv_gbs = alg_bytes / (inv_launch_ms * 1e-3) / 1e9
@@ -499,16 +503,20 @@ def bench_unit(args):
                          "forward_residual_rel_err": resid},
             "forward": {"ms_per_img": fwd_dt / args.steps / B * 1e3, "images_per_s": world * B * args.steps / fwd_dt,
                         "logdet": 0.0, "launch_ms": fwd_launch_ms, "launch": fwd,
+                        "kernel": conv_form,
                         "frac_hbm_peak": alg_bytes / (fwd_launch_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                        "frac_fp32_peak": alg_flops / (fwd_launch_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
-                        "hbm_frac_ceiling_at_fp32": hbm_ceiling,
-                        "note": f"fp32-compute-bound shape: at 100 % of the fp32 peak this call reaches {hbm_ceiling:.0%} of "
-                                f"HBM peak" + ("; the north_star's 40 % of HBM on the forward is unreachable at fp32 here"
-                                               if hbm_ceiling < 0.4 else "")},
+                        "executed_flops_per_launch": fwd_flops,
+                        "frac_fp32_peak": fwd_flops / (fwd_launch_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
+                        "direct_equivalent_frac_fp32_peak": alg_flops / (fwd_launch_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
+                        "hbm_frac_ceiling_at_fp32": hbm_ceiling * alg_flops / fwd_flops,
+                        "note": f"fp32-compute-bound shape: at 100 % of the fp32 peak the direct sum reaches {hbm_ceiling:.0%} of "
+                                f"HBM peak" + (f"; the Winograd F(2,3) kernel executes 2/3 of the direct multiplies, which lifts "
+                                               f"that ceiling to {hbm_ceiling * 1.5:.0%}" if conv_form == "winograd" else "")},
             "training_step": {"what": "z = unit(x); z.backward(gz): forward + grad-input + grad-weight with the corner-tap mask "
                                       "(SURVEY 8 f1), HIP kernels under autograd", "ms_per_step": tr_dt / tr_steps * 1e3,
                               "steps": tr_steps, "launch": launch_stats(tr_per),
-                              "frac_fp32_peak": 3 * alg_flops / (tr_dt / tr_steps) / 1e12 / FP32_PEAK_TFLOPS},
+                              "frac_fp32_peak": (alg_flops + 2 * fwd_flops) / (tr_dt / tr_steps) / 1e12 / FP32_PEAK_TFLOPS,
+                              "direct_equivalent_frac_fp32_peak": 3 * alg_flops / (tr_dt / tr_steps) / 1e12 / FP32_PEAK_TFLOPS},
             "roofline": {"kernel": inverse_kernel_name(B, Cq, H, W, K), "bound": "hbm", "achieved": inv_gbs,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": inv_gbs / HBM_PEAK_GBS,
                          "traffic": (traffic or {}).get("inverse_hbm_bytes_per_launch"),

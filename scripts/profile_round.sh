@@ -13,10 +13,12 @@ for w in c2 c5 c3_share8; do
   python3 bench.py --workload $w --steps 50 --no-cpu > gpurun_out/${TAG}_bench_$w.json 2>> gpurun_out/${TAG}_bench.err
   echo "bench $w done"
 done
+python3 bench.py --workload c4 --steps 20 --warmup 3 --no-cpu > gpurun_out/${TAG}_bench_c4.json 2>> gpurun_out/${TAG}_bench.err
+echo "bench c4 done"
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/${TAG}_prof_c3 -- python3 $ROOT/bench.py --no-cpu > $ROOT/gpurun_out/${TAG}_bench_c3_under_rocprof.json 2> $ROOT/gpurun_out/${TAG}_prof_c3.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/${TAG}_prof_c3 -- python3 $ROOT/bench.py --no-cpu --no-share > $ROOT/gpurun_out/${TAG}_bench_c3_under_rocprof.json 2> $ROOT/gpurun_out/${TAG}_prof_c3.err
 echo "rocprof c3 done"
-rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/${TAG}_prof_share8 -- python3 $ROOT/bench.py --workload c3_share8 --no-cpu > $ROOT/gpurun_out/${TAG}_bench_share8_under_rocprof.json 2> $ROOT/gpurun_out/${TAG}_prof_share8.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/${TAG}_prof_share8 -- python3 $ROOT/bench.py --workload c3_share8 --no-cpu --no-share > $ROOT/gpurun_out/${TAG}_bench_share8_under_rocprof.json 2> $ROOT/gpurun_out/${TAG}_prof_share8.err
 echo "rocprof share8 done"
 cd $ROOT
 scripts/pmc_run.sh ${TAG}_c3 > gpurun_out/${TAG}_pmc_c3.log 2>&1
