@@ -22,7 +22,7 @@ SYMBOLS = [
     "finc_canonicalize_weights_f64", "finc_inverse_f64", "finc_forward_f64",
     "finc_inverse_kernel_variant", "finc_debug_attr_table_insert", "finc_debug_inverse_table_row",
     "finc_mix_supported_f32", "finc_mix_f32", "finc_pack_forward_weights_affine_f32", "finc_debug_hlp_timeouts",
-    "finc_build_flags", "finc_clear_fault", "finc_debug_backward_variant",
+    "finc_build_flags", "finc_inverse_packed_premultiplied_f32", "finc_inverse_premultiplied_supported", "finc_clear_fault", "finc_debug_backward_variant",
 ]
 
 _lib = None
@@ -63,6 +63,8 @@ def lib():
     L.finc_pack_forward_weights_affine_f32.argtypes = [vp, vp, vp, vp, i, i, i, i, vp]
     runp = [vp, vp, vp, i, i, i, i, i, i, i, u, vp]
     L.finc_inverse_packed_f32.argtypes = runp
+    L.finc_inverse_packed_premultiplied_f32.argtypes = runp
+    L.finc_inverse_premultiplied_supported.argtypes = [i, i, i, i, i, i, i]
     L.finc_forward_packed_f32.argtypes = runp
     L.finc_backward_workspace_bytes.restype = sz
     L.finc_inverse_workspace_bytes.restype = sz

@@ -137,7 +137,7 @@ static int canonicalize(const T *w_stored, T *w_canon, int G, int Cq, int KH, in
 
 extern "C" {
 
-int finc_version(void) { return 101; }
+int finc_version(void) { return 102; }
 
 unsigned finc_build_flags(void)
 {
@@ -384,6 +384,23 @@ int finc_forward_packed_f32(const float *x, const void *packed, float *z, int B,
                             int KW, unsigned orient, finc_stream_t stream)
 {
     return run_packed(x, packed, z, B, G, Cq, H, W, KH, KW, orient, stream, true);
+}
+
+int finc_inverse_premultiplied_supported(int B, int G, int Cq, int H, int W, int KH, int KW)
+{
+    if (check_shape(B, G, Cq, H, W, KH, KW)) return 0;
+    return finc_mfma_zpre_takes(FincShape{B, G, Cq, H, W, KH, KW, 0}) ? 1 : 0;
+}
+
+int finc_inverse_packed_premultiplied_f32(const float *zp, const void *packed, float *x, int B, int G, int Cq, int H, int W,
+                                          int KH, int KW, unsigned orient, finc_stream_t stream)
+{
+    if (!zp || !packed || !x) return FINC_ERR_NULL_POINTER;
+    if (int e = check_shape(B, G, Cq, H, W, KH, KW)) return e;
+    if (misaligned(zp) || misaligned(x)) return FINC_ERR_ALIGNMENT;
+    if (zp == x) return FINC_ERR_BAD_DIMS;
+    FincShape s{B, G, Cq, H, W, KH, KW, orient};
+    return finc_mfma_launch(zp, packed, x, s, (hipStream_t)stream, true);
 }
 
 static int run_f64(const double *in, const double *w_canon, double *out, int B, int G, int Cq, int H, int W, int KH,

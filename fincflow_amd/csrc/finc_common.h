@@ -73,7 +73,9 @@ size_t finc_mfma_packed_bytes(int G, int Cq, int KH, int KW);
 // scale / shift [G*Cq] or nullptr: the affine map z = scale*y + shift folded in front of the inverse
 int finc_mfma_pack(const float *wc, const float *scale, const float *shift, void *packed, int G, int Cq, int KH, int KW,
                    hipStream_t st);
-int finc_mfma_launch(const float *in, const void *packed, float *out, const FincShape &s, hipStream_t st);
+// zpre: `in` is Linv * z already (the caller's channel mix applied blockdiag(Linv)): the helper-wave form without its z-term
+int finc_mfma_launch(const float *in, const void *packed, float *out, const FincShape &s, hipStream_t st, bool zpre = false);
+bool finc_mfma_zpre_takes(const FincShape &s);
 // info[0..7] = {Cq padded, waves per problem, problems per workgroup, 32-byte I/O (1) or 16-byte (0), LDS bytes of a
 // workgroup, workgroups, index into the instantiation table, rows of the table}; FINC_ERR_UNSUPPORTED if none applies
 int finc_mfma_variant(int B, int G, int Cq, int H, int W, int KH, int KW, int *info);

@@ -264,7 +264,13 @@ constexpr unsigned OFF_BAD_CHANNEL = 0x40000000u; // added to a valid offset it 
 //   B2  helper -> compute   B2 >= w+1: the x-ring reads of window w are done -- checked before the x-ring write of step 4w+1
 // LDS executes a wave's operations in order and has no cache, so a flag written after the data is seen after the data.
 // Every spin is bounded.
-template <int CQP, int KH, int KW, bool SEC, int NW = 1, int NPW = 1, int S64 = 0, int HLP = 0>
+// ZPRE ("z premultiplied", HLP form only): the input is z' = Linv * z already -- in a flow stack the channel mix in front of
+// the unit applies blockdiag(Linv) for free (fincflow_amd/glow.py) -- so the z-term's MFMAs (15 of the 162 of a
+// c3 step) disappear from the compute wave.  The helper fetches channel chan_d(j, q) instead of 4j+q into k-slot q of
+// register j (the addressing of the store side), so what the compute wave reads from the z ring IS the accumulators' start
+// (16-row tiles) resp. the term to add behind the 4-row blocks' reduce; the folded shift of the bank is not applied (the
+// caller's mix carries it).
+template <int CQP, int KH, int KW, bool SEC, int NW = 1, int NPW = 1, int S64 = 0, int HLP = 0, bool ZPRE = false>
 __global__ __launch_bounds__(HLP ? 512 : 64 * NW * NPW) void finc_wave_kernel(const float *__restrict__ in,
                                                             const float *__restrict__ packed, float *__restrict__ out,
                                                             int G, int CQ, int H, int W, int P, int Tend,
@@ -276,6 +282,7 @@ __global__ __launch_bounds__(HLP ? 512 : 64 * NW * NPW) void finc_wave_kernel(co
     constexpr int SS = NK * JS;               // FIFO: floats per step slot
     extern __shared__ __attribute__((aligned(16))) float lds[];
     static_assert(!HLP || (S64 == 3 && NW == 1 && NPW == 1), "helper waves: the sector-pairing kernel, one compute wave per problem");
+    static_assert(!ZPRE || HLP, "premultiplied input: the helper-wave form only");
     const int wvt = (HLP || NW * NPW > 1) ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0;  // wave of the workgroup
     const bool helper = HLP && wvt >= 4;      // waves 4-7: the HBM side of problems 0-3
     const int wv = HLP ? 0 : wvt % NW;        // wave of the problem (K-split)
@@ -374,6 +381,7 @@ __global__ __launch_bounds__(HLP ? 512 : 64 * NW * NPW) void finc_wave_kernel(co
 #pragma unroll
         for (int f = 0; f < NFRAG; ++f) {
             if (f % MT >= C::MTB) continue;    // a 4-row block: packed below
+            if (ZPRE && f < NKZ * MT) { af[f] = 0.f; continue; }   // (no z-term)
             if (NW == 1 && f < NKZ * MT && finc_zterm_is_zero(C::MTB, f / MT, f % MT)) { af[f] = 0.f; continue; }
             af[f] = pk[gindex(f) * 64];
         }
@@ -397,6 +405,7 @@ __global__ __launch_bounds__(HLP ? 512 : 64 * NW * NPW) void finc_wave_kernel(co
 #pragma unroll
         for (int f = 0; f < NFRAG; ++f) {
             if (f % MT >= C::MTB) continue;
+            if (ZPRE && f < NKZ * MT) continue;
             if (NW == 1 && f < NKZ * MT && finc_zterm_is_zero(C::MTB, f / MT, f % MT)) continue;   // never read
             asm volatile("" : "+a"(af[f]));
         }
@@ -593,8 +602,15 @@ __global__ __launch_bounds__(HLP ? 512 : 64 * NW * NPW) void finc_wave_kernel(co
                 const unsigned vu = ok ? (unsigned)(loffS[WP] + 32 * dirw) : OFF_INVALID;
 #pragma unroll
                 for (int j = 0; j < NKZ; ++j) {
-                    const unsigned ol = j == NKZ - 1 ? vl + zlast : vl, ou = j == NKZ - 1 ? vu + zlast : vu;
-                    const int so = __builtin_amdgcn_readfirstlane(j * 16 * HW);
+                    unsigned ol = j == NKZ - 1 ? vl + zlast : vl, ou = j == NKZ - 1 ? vu + zlast : vu;
+                    int so = __builtin_amdgcn_readfirstlane(j * 16 * HW);
+                    if constexpr (ZPRE) {      // register j = D register j of the pixel: the store side's channel map
+                        const bool tile = j < 4 * C::MTB;
+                        const bool last_group = tile ? (C::NSM == 0 && (j >> 2) == C::MTB - 1) : j == C::NKDT - 1;
+                        const unsigned add = (tile ? lane_t - lane_b : 0u) + ((last_group && C::CQP != CQ) ? cmask[j] : 0u);
+                        ol = vl + add; ou = vu + add;       // (loffS carries lane_b = q*HW*4, the k-slot's share of a block register)
+                        so = __builtin_amdgcn_readfirstlane((tile ? 16 * (j >> 2) + (j & 3) : 16 * C::MTB + 4 * (j - 4 * C::MTB)) * HW * 4);
+                    }
                     if constexpr (ZA_AGPR)
                         asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=a"(ZA[WP][j]) : "v"(ol), "s"(rin), "s"(so) : "memory");
                     else
@@ -1018,6 +1034,10 @@ __global__ __launch_bounds__(HLP ? 512 : 64 * NW * NPW) void finc_wave_kernel(co
         v4f acc[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acc[mt] = (v4f){0.f, 0.f, 0.f, 0.f};   // set in the prologue (step -1)
+        // ZPRE: z' of the 4-row blocks' channels (operand layout: channel base + q in lane row q) joins behind the reduce
+        float zqc[C::NSM > 0 ? C::NSM : 1], zqn[C::NSM > 0 ? C::NSM : 1];
+#pragma unroll
+        for (int sb = 0; sb < (C::NSM > 0 ? C::NSM : 1); ++sb) zqc[sb] = zqn[sb] = 0.f;
 
         auto phase_a = [&](auto pha_c, int j0, int j1) {
             constexpr int PHA = decltype(pha_c)::value;
@@ -1126,7 +1146,17 @@ __global__ __launch_bounds__(HLP ? 512 : 64 * NW * NPW) void finc_wave_kernel(co
             // The accumulators of the next pixel start from the bias: it is the C operand of the first z-term MFMA of
             // every tile (k-step 0 is never a structural zero), so the start costs no instruction.  Both branches define
             // accn by that MFMA -- a select on accn itself would make the common path copy the bias every step.
-            if (__builtin_expect(any_idle, 0)) {
+            if constexpr (ZPRE) {
+                // no z-term: the ring holds the accumulators' start (idle lanes: zv was zeroed above, so they keep producing
+                // exact zeros); the 4-row blocks start from zero and take their z' behind the reduce of the NEXT step
+#pragma unroll
+                for (int mt = 0; mt < C::MTB; ++mt) accn[mt] = (v4f){zv[4 * mt], zv[4 * mt + 1], zv[4 * mt + 2], zv[4 * mt + 3]};
+#pragma unroll
+                for (int sb = 0; sb < C::NSM; ++sb) {
+                    accn[C::MTB + sb] = (v4f){0.f, 0.f, 0.f, 0.f};
+                    zqn[sb] = zv[4 * C::MTB + sb];
+                }
+            } else if (__builtin_expect(any_idle, 0)) {
                 // a lane that has not started must keep producing exact zeros: its "pixels" are what lane p+1 and, through
                 // the FIFO, the first band's lanes 0..KH-2 read as the (non-existent) rows above the image
                 FINC_COLD();
@@ -1148,6 +1178,7 @@ __global__ __launch_bounds__(HLP ? 512 : 64 * NW * NPW) void finc_wave_kernel(co
             for (int j = 1; j < NKZ; ++j)
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
+                    if (ZPRE) continue;
                     if (NW == 1 && finc_zterm_is_zero(C::MTB, j, mt)) continue;   // Linv is lower triangular
                     mma(accn[mt], FZ + j * MT + mt, zv[j]);
                 }
@@ -1191,6 +1222,10 @@ __global__ __launch_bounds__(HLP ? 512 : 64 * NW * NPW) void finc_wave_kernel(co
                 }
                 if constexpr (NW == 1) {
                     pack_d<C>(acc, xpk);
+                    if constexpr (ZPRE) {
+#pragma unroll
+                        for (int sb = 0; sb < C::NSM; ++sb) xpk[4 * C::MTB + sb] += zqc[sb];
+                    }
                 } else {
 #pragma unroll
                     for (int j = 0; j < NKD; ++j) {
@@ -1260,6 +1295,10 @@ __global__ __launch_bounds__(HLP ? 512 : 64 * NW * NPW) void finc_wave_kernel(co
             // ---- advance
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) acc[mt] = accn[mt];
+            if constexpr (ZPRE) {
+#pragma unroll
+                for (int sb = 0; sb < C::NSM; ++sb) zqc[sb] = zqn[sb];
+            }
             if constexpr (NW > 1) __syncthreads();     // every wave has read its shares: the buffer may be rewritten
             ++tp1;
             ++tm; if (tm == W) tm = 0;
@@ -1299,11 +1338,17 @@ __global__ __launch_bounds__(HLP ? 512 : 64 * NW * NPW) void finc_wave_kernel(co
             for (int mt = 0; mt < MT; ++mt) {
                 const float b0 = bias[mt].x, b1 = bias[mt].y, b2 = bias[mt].z, b3 = bias[mt].w;
                 acc[mt] = (v4f){started ? b0 : 0.f, started ? b1 : 0.f, started ? b2 : 0.f, started ? b3 : 0.f};
+                if constexpr (ZPRE) acc[mt] = (v4f){0.f, 0.f, 0.f, 0.f};
             }
 #pragma unroll
             for (int j = 0; j < NKZ; ++j) {
                 const float v = zrd[j * C::ZSLOTS * 64];
                 const float zvj = started ? v : 0.f;
+                if constexpr (ZPRE) {
+                    if (j < 4 * C::MTB) acc[j >> 2][j & 3] = zvj;
+                    else zqc[j - 4 * C::MTB] = zvj;
+                    continue;
+                }
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     if (NW == 1 && finc_zterm_is_zero(C::MTB, j, mt)) continue;
@@ -1429,6 +1474,7 @@ struct Inst {
     wave_fn fn_sec;  // 32-byte-piece I/O (W % 8 == 0)
     wave_fn fn_s64;  // 64-byte sector pairing (W % 16 == 0); nullptr where the variant does not exist
     wave_fn fn_hlp;  // sector pairing + helper waves: 8-wave workgroups of 4 problems (problem count % 4 == 0); or nullptr
+    wave_fn fn_zpre; // fn_hlp for a premultiplied input (ZPRE); or nullptr
     int nkz, nkd, nk, mt, nfrag, mtb;  // nkz/nkd/nfrag: per GROUP (packing); nk: per wave; mt = mtb tiles + 4-row blocks
     int nw, wnkz, wnkd;                // K-split: waves per problem, per-wave k-steps
     int npw;                           // problems packed into one workgroup (the launch needs B*G % npw == 0)
@@ -1455,7 +1501,7 @@ constexpr Inst make_inst()
 #endif
     constexpr int mode = !one ? 0 : (FINC_S64_MODE == 3 && pinned + 8 * C::NKZ + 8 * C::NKD <= 256) ? 3
                                   : (FINC_S64_MODE >= 1 && pinned + 8 * C::NKD <= 256) ? 1 : 0;
-    wave_fn f64 = nullptr, fhl = nullptr;
+    wave_fn f64 = nullptr, fhl = nullptr, fzp = nullptr;
     if constexpr (mode != 0) f64 = finc_wave_kernel<CQP, KH, KW, true, NW, NPW, mode>;
 #ifndef FINC_HLP_MODE
 #define FINC_HLP_MODE 1
@@ -1465,8 +1511,11 @@ constexpr Inst make_inst()
     // set, helper VGPRs = two store sets + the other parked set + bookkeeping, compute AGPRs = the pinned fragments
     // (filters whose operands do not rotate in place -- 5x5 -- keep explicit ageing copies: too many VGPRs in the compute role)
     constexpr bool hlp_fits = 16 * C::NKZ + 4 * C::NKD <= 124 && 12 * C::NKD + 48 <= 124 && pinned <= 124 && (KH - 1 + KW) < 6;
-    if constexpr (mode == 3 && FINC_HLP_MODE && hlp_fits) fhl = finc_wave_kernel<CQP, KH, KW, true, NW, NPW, 3, 1>;
-    return Inst{CQP, KH, KW, finc_wave_kernel<CQP, KH, KW, false, NW, NPW>, finc_wave_kernel<CQP, KH, KW, true, NW, NPW>, f64, fhl,
+    if constexpr (mode == 3 && FINC_HLP_MODE && hlp_fits) {
+        fhl = finc_wave_kernel<CQP, KH, KW, true, NW, NPW, 3, 1>;
+        fzp = finc_wave_kernel<CQP, KH, KW, true, NW, NPW, 3, 1, true>;
+    }
+    return Inst{CQP, KH, KW, finc_wave_kernel<CQP, KH, KW, false, NW, NPW>, finc_wave_kernel<CQP, KH, KW, true, NW, NPW>, f64, fhl, fzp,
                 C::NKZT, C::NKDT, C::NK, C::MT, C::NFRAGT, C::MTB, NW, C::NKZ, C::NKD, NPW, MAXP};
 }
 
@@ -1663,9 +1712,21 @@ int finc_mfma_table_row(int row, int *info)
     return FINC_OK;
 }
 
-int finc_mfma_launch(const float *in, const void *packed, float *out, const FincShape &s, hipStream_t st)
+// the premultiplied-input form exists for the shapes the helper-wave kernel takes (a full chip: the role-split kernel's
+// small problem sets and the forms without helper waves keep their z-term)
+bool finc_mfma_zpre_takes(const FincShape &s)
+{
+    if (!finc_mfma_supported(s.Cq, s.H, s.W, s.KH, s.KW) || finc_split_takes(s)) return false;
+    const Inst *i = find_inst(s.Cq, s.KH, s.KW, (long long)s.B * s.G, s.W);
+    if (!i || !i->fn_zpre || s.W % 16 != 0 || finc_no_s64() || finc_no_hlp()) return false;
+    const int P = 16;
+    return ((long long)s.B * s.G) % 4 == 0 && 4 * lds_bytes(*i, s.W, P) + 64 <= 160 * 1024;
+}
+
+int finc_mfma_launch(const float *in, const void *packed, float *out, const FincShape &s, hipStream_t st, bool zpre)
 {
     if (!finc_mfma_supported(s.Cq, s.H, s.W, s.KH, s.KW)) return FINC_ERR_UNSUPPORTED;
+    if (zpre && !finc_mfma_zpre_takes(s)) return FINC_ERR_UNSUPPORTED;
     if (int e = finc_fault_gate(false)) return e;          // an earlier launch on this device gave up a protocol wait
     if (finc_split_takes(s)) return finc_split_launch(in, packed, out, s, st);   // the under-filled chip (finc_split.hip)
     const Inst *i = find_inst(s.Cq, s.KH, s.KW, (long long)s.B * s.G, s.W);
@@ -1679,7 +1740,7 @@ int finc_mfma_launch(const float *in, const void *packed, float *out, const Finc
     // helper waves: 4 problems per 8-wave workgroup; their rings + 3 progress words each must fit one CU's LDS
     const size_t lds_hlp = 4 * lds + 64;
     const bool hlp = s64 && i->fn_hlp && ((long long)s.B * s.G) % 4 == 0 && lds_hlp <= 160 * 1024 && !finc_no_hlp();
-    const wave_fn fn = hlp ? i->fn_hlp : s64 ? i->fn_s64 : (s.W % 8 == 0) ? i->fn_sec : i->fn;
+    const wave_fn fn = zpre ? i->fn_zpre : hlp ? i->fn_hlp : s64 ? i->fn_s64 : (s.W % 8 == 0) ? i->fn_sec : i->fn;
     if (int e = finc_ensure_dynamic_lds((const void *)fn, hlp ? lds_hlp : lds)) return e;
     if (hlp) {
         if (int e = finc_fault_gate(true)) return e;       // (arms the device's fault word on the first helper-wave launch)

@@ -166,6 +166,31 @@ class Conv1x1(FlowLayer):
             self._aff_key = key
         return ops.finc_mix(z.contiguous(), self._m_aff, self._b_aff)
 
+    def reverse_premultiplied(self, z, lead, log_scale=None, translation=None):
+        """blockdiag(lead) (exp(log_scale) * reverse(z) + translation) in ONE launch: `lead` [G, Cq, Cq] is the inverse of
+        the unit triangular tap of the FastFlowUnit that follows in the reverse chain, which then runs
+        without its z-term.  The product with a block-diagonal matrix is folded into the mix's matrix and bias on the host,
+        once per weight version.  None when this call cannot take the HIP path."""
+        if not self._hip(z):
+            return None
+        from . import ops
+        w_inv = self._inverse_matrix()
+        key = (lead.data_ptr(), lead._version) + (() if log_scale is None else
+                                                  (log_scale.data_ptr(), log_scale._version, translation.data_ptr(),
+                                                   translation._version))
+        if getattr(self, "_lead_key", None) != key or getattr(self, "_lead_inv", None) is not w_inv:
+            with torch.no_grad():
+                m = w_inv.double()
+                b = None
+                if log_scale is not None:
+                    m = torch.exp(log_scale.detach().double()).view(-1, 1) * m
+                    b = translation.detach().double()
+                blk = torch.block_diag(*lead.double().unbind(0))
+                self._m_lead = (blk @ m).float().contiguous()
+                self._b_lead = None if b is None else (blk @ b).float().contiguous()
+            self._lead_key, self._lead_inv = key, w_inv
+        return ops.finc_mix(z.contiguous(), self._m_lead, self._b_lead)
+
     def logdet(self, input, context=None):
         raise NotImplementedError
 

@@ -172,6 +172,25 @@ class FastFlowUnit(nn.Module):
             return self._cache.inverse_affine(y.contiguous(), self._weights(), 4, ops.ORIENT_FASTFLOW, log_scale,
                                               translation)
 
+    def reverse_after_mix(self, u, mix, affine=None):
+        """reverse(affine(mix.reverse(u))) in TWO launches that cost less than the plain two: the channel mix
+        in front of the unit in the reverse chain (Conv1x1.reverse, with the ActNorm between them as a row scaling and a
+        bias) also applies blockdiag(Linv_g) of this unit -- the same dense C x C product per pixel -- and the inverse
+        runs without its z-term.  `mix` exposes `reverse_premultiplied(u, lead, log_scale, translation)`.  None when this
+        call cannot take that path (shape without the kernel, autograd on, CPU tensors)."""
+        if torch.is_grad_enabled() and (u.requires_grad or any(w.requires_grad for w in self._weights())):
+            return None
+        if not u.is_cuda or u.dtype != torch.float32 or u.dim() != 4:
+            return None
+        with torch.no_grad():
+            if not self._cache.premultiplied_supported(tuple(u.shape), self._weights(), 4, ops.ORIENT_FASTFLOW):
+                return None
+            lead = self._cache.lead_inverse(self._weights(), 4, ops.ORIENT_FASTFLOW)
+            zp = mix.reverse_premultiplied(u, lead, *(affine if affine is not None else (None, None)))
+            if zp is None:
+                return None
+            return self._cache.inverse_premultiplied(zp, self._weights(), 4, ops.ORIENT_FASTFLOW)
+
     def forward_affine(self, x, log_scale, translation):
         """(forward(x) - translation) * exp(-log_scale): the ActNorm behind the unit rides in the forward bank (SURVEY 8
         f3, forward direction).  Inference only; None if this call cannot take the fused path."""
@@ -318,6 +337,8 @@ class FlowSequential(nn.Module):
     #: fold a per-channel affine layer (a module exposing `reverse_affine_params()`, e.g. glow.ActNorm) into the
     #: FastFlowUnit that follows it in the reverse chain: one launch instead of two, same result
     fuse_affine = True
+    #: let the channel mix in front of a FastFlowUnit (reverse chain) apply the unit's blockdiag(Linv) as well
+    fuse_lead = True
 
     def _reverse_chain(self, input, context, fuse=None):
         fuse = self.fuse_affine if fuse is None else fuse
@@ -332,6 +353,19 @@ class FlowSequential(nn.Module):
                     input = fused
                     i += 2
                     continue
+            # channel mix -> [per-channel affine] -> unit: the mix also applies the unit's blockdiag(Linv), the unit's inverse
+            # runs without its z-term (full-chip problem sets only; otherwise the folds below)
+            if fuse and self.fuse_lead and hasattr(m, "reverse_premultiplied") and not torch.is_grad_enabled():
+                j, affine = i + 1, None
+                if j < len(mods) and hasattr(mods[j], "reverse_affine_params"):
+                    affine = mods[j].reverse_affine_params()
+                    j += 1
+                if j < len(mods) and isinstance(mods[j], FastFlowUnit) and (j == i + 1 or affine is not None):
+                    fused = mods[j].reverse_after_mix(input, m, affine)
+                    if fused is not None:
+                        input = fused
+                        i = j + 1
+                        continue
             # a channel mix followed by a per-channel affine layer that no FastFlowUnit takes: one mixing launch
             if (fuse and i + 1 < len(mods) and hasattr(m, "reverse_then_affine") and hasattr(mods[i + 1], "reverse_affine_params")
                     and not (i + 2 < len(mods) and isinstance(mods[i + 2], FastFlowUnit)) and not torch.is_grad_enabled()):

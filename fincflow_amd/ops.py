@@ -207,7 +207,7 @@ def inverse(input, kernel, output):
 
 class _DeviceBank:
     """What PackedWeights holds for ONE device."""
-    __slots__ = ("key", "w_canon", "packed_inv", "packed_fwd", "packed_aff", "aff_key", "packed_faff", "faff_key")
+    __slots__ = ("key", "w_canon", "packed_inv", "packed_fwd", "packed_aff", "aff_key", "packed_faff", "faff_key", "linv")
 
     def __init__(self):
         self.key = None
@@ -218,6 +218,7 @@ class _DeviceBank:
         self.aff_key = None
         self.packed_faff = None
         self.faff_key = None
+        self.linv = None
 
 
 class PackedWeights:
@@ -269,6 +270,7 @@ class PackedWeights:
             bank.packed_fwd = None
             bank.packed_aff = None
             bank.packed_faff = None
+            bank.linv = None
             bank.key = key
         return bank
 
@@ -349,6 +351,52 @@ class PackedWeights:
                                                            _stream_ptr(z)), "finc_pack_inverse_weights_f32")
             _lib.check(L.finc_inverse_packed_f32(z.data_ptr(), bank.packed_inv.data_ptr(), out.data_ptr(), B, G, Cq, H, W,
                                                  KH, KW, orient, _stream_ptr(z)), "finc_inverse_packed_f32")
+        return out
+
+    def lead_inverse(self, weights, G, orient):
+        """Linv_g = inverse of the unit lower triangular tap of the pixel itself (canonical tap [KH-1, KW-1],
+        layers/conv.py:63-70), [G, Cq, Cq] fp32 (solved in fp64), cached per weight version: what a channel mix in front of
+        the unit multiplies into its matrix so that `inverse_premultiplied` can skip the z-term."""
+        bank = self._get(weights, G, orient)
+        if bank.linv is None:
+            wc = bank.w_canon
+            Cq = wc.shape[1]
+            lead = wc.view(G, Cq, Cq, wc.shape[2], wc.shape[3])[:, :, :, -1, -1].double()
+            eye = torch.eye(Cq, dtype=torch.float64, device=wc.device).expand(G, Cq, Cq)
+            bank.linv = torch.linalg.solve_triangular(lead, eye, upper=False, unitriangular=True).float().contiguous()
+        return bank.linv
+
+    def premultiplied_supported(self, shape, weights, G, orient):
+        """Does `inverse_premultiplied` exist for activations of this shape (the helper-wave form of the inverse: a problem
+        set that fills the chip, W % 16 == 0)?"""
+        w_canon = self._get(weights, G, orient).w_canon
+        B, C, H, W = shape
+        Cq, KH, KW = w_canon.shape[1], w_canon.shape[2], w_canon.shape[3]
+        return C == G * Cq and bool(_lib.lib().finc_inverse_premultiplied_supported(B, G, Cq, H, W, KH, KW))
+
+    def inverse_premultiplied(self, zp, weights, G, orient, out=None):
+        """inverse(z) given zp = blockdiag(Linv) z (the channel mix in front of the unit applied Linv for free),
+        ONE launch without the z-term's MFMAs.  None when the shape has no such kernel or the activations are not 16-byte
+        aligned (the caller runs the plain chain)."""
+        bank = self._get(weights, G, orient)
+        w_canon = bank.w_canon
+        _require_device(zp, "input")
+        B, Cq, H, W, KH, KW = _dims(zp, w_canon, G)
+        L = _lib.lib()
+        if zp.numel() == 0 or not L.finc_inverse_premultiplied_supported(B, G, Cq, H, W, KH, KW):
+            return None
+        if out is None:
+            out = torch.empty_like(zp)
+        if (zp.data_ptr() | out.data_ptr()) & 15:
+            return None
+        with torch.cuda.device(zp.device):
+            if bank.packed_inv is None:
+                bank.packed_inv = torch.empty(L.finc_workspace_bytes(G, Cq, KH, KW), dtype=torch.uint8, device=zp.device)
+                _lib.check(L.finc_pack_inverse_weights_f32(w_canon.data_ptr(), bank.packed_inv.data_ptr(), G, Cq, KH, KW,
+                                                           _stream_ptr(zp)), "finc_pack_inverse_weights_f32")
+            _lib.check(L.finc_inverse_packed_premultiplied_f32(zp.data_ptr(), bank.packed_inv.data_ptr(), out.data_ptr(), B, G,
+                                                               Cq, H, W, KH, KW, orient, _stream_ptr(zp)),
+                       "finc_inverse_packed_premultiplied_f32")
         return out
 
     def inverse_affine(self, y, weights, G, orient, log_scale, translation, out=None):

@@ -155,6 +155,20 @@ int finc_inverse_packed_f32(const float *z, const void *packed, float *x, int B,
                             int KH, int KW, unsigned orient, finc_stream_t stream);
 int finc_forward_packed_f32(const float *x, const void *packed, float *z, int B, int G, int Cq, int H, int W,
                             int KH, int KW, unsigned orient, finc_stream_t stream);
+/*
+ * SURVEY 8 f3, second half -- the inverse of a unit whose input the caller has ALREADY multiplied by blockdiag(Linv_g),
+ * Linv_g = inverse(w_canon[g][:, :, KH-1, KW-1]) (the unit lower triangular tap of the pixel itself, layers/conv.py:63-70):
+ * in the reverse chain of a flow step (fastflow/fastflow_cifar.py:46-55: ... Conv1x1.reverse -> [ActNorm.reverse] ->
+ * FastFlowUnit.reverse) the channel mix in front of the unit is a dense C x C matrix product per pixel anyway, so
+ *     zp = finc_mix_f32(u, blockdiag(Linv) * diag(scale) * inverse(W), blockdiag(Linv) * shift)
+ * costs what the plain mix costs, and the unit's inverse starts every pixel from what it reads instead of spending 15 of
+ * its 162 MFMAs (c3) on Linv * z.  `packed` is the plain bank of finc_pack_inverse_weights_f32 (its z-term and folded
+ * shift are not used).  Exists for the problem sets that run the helper-wave form (a full chip; W % 16 == 0):
+ * finc_inverse_premultiplied_supported() == 1, else FINC_ERR_UNSUPPORTED and the caller keeps the two plain calls.
+ */
+int finc_inverse_premultiplied_supported(int B, int G, int Cq, int H, int W, int KH, int KW);
+int finc_inverse_packed_premultiplied_f32(const float *zp, const void *packed, float *x, int B, int G, int Cq, int H,
+                                          int W, int KH, int KW, unsigned orient, finc_stream_t stream);
 
 /*
  * Backward of the forward conv (replaces autograd through cuDNN,

@@ -44,8 +44,20 @@ for name, B, C, H, W in (("c3", 256, 96, 64, 64), ("c2", 64, 48, 32, 32), ("c4_L
         tan = timeit(lambda: an.reverse(y))
         tun = timeit(lambda: unit.reverse(y))
         tfu = timeit(lambda: unit.reverse_affine(y, an.log_scale, an.translation))
+        pre = {}
+        ws = unit._weights()
+        if unit._cache.premultiplied_supported((B, C, H, W), ws, 4, 0xE4):
+            lead = unit._cache.lead_inverse(ws, 4, 0xE4)
+            zp = c11.reverse_premultiplied(y, lead, an.log_scale, an.translation)
+            a = unit._cache.inverse_premultiplied(zp, ws, 4, 0xE4)
+            b = unit.reverse_affine(c11.reverse(y), an.log_scale, an.translation)
+            pre = {"mix_with_lead_and_actnorm_us": timeit(lambda: c11.reverse_premultiplied(y, lead, an.log_scale, an.translation)),
+                   "unit_reverse_premultiplied_us": timeit(lambda: unit._cache.inverse_premultiplied(zp, ws, 4, 0xE4)),
+                   "reverse_step_plain_us": timeit(lambda: unit.reverse_affine(c11.reverse(y), an.log_scale, an.translation)),
+                   "reverse_step_lead_folded_us": timeit(lambda: unit.reverse_after_mix(y, c11, (an.log_scale, an.translation))),
+                   "rel_err_between_the_two": float((a - b).abs().max() / b.abs().max())}
     E = B * C * H * W
-    out[name] = {"shape": [B, C, H, W], "conv1x1_reverse_us": t11, "conv1x1_reverse_miopen_us": tmi,
+    out[name] = {**pre, "shape": [B, C, H, W], "conv1x1_reverse_us": t11, "conv1x1_reverse_miopen_us": tmi,
                  "conv1x1_reverse_then_actnorm_one_launch_us": tfa, "actnorm_reverse_us": tan, "unit_reverse_us": tun,
                  "unit_reverse_with_actnorm_folded_us": tfu, "conv1x1_GBps": 8 * E / t11 / 1e3,
                  "bytes_moved_by_conv1x1": 8 * E}

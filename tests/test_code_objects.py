@@ -45,12 +45,12 @@ def test_asm_load_kernels_do_not_spill():
     md = kernel_metadata()
     wave = {k: v for k, v in md.items() if "finc_wave_kernel" in k}
     assert len(wave) > 50, "the inverse's instantiations were not found in the code objects"
-    # template tail ...ELb<SEC>ELi<NW>ELi<NPW>ELi<S64>ELi<HLP>EE: S64 != 0 (sector pairing) and HLP != 0 (helper waves) carry asm loads
-    asm_loads = {k: v for k, v in wave.items() if re.search(r"Lb1ELi\d+ELi\d+ELi[123]ELi[012]EE", k)}
+    # template tail ...ELb<SEC>ELi<NW>ELi<NPW>ELi<S64>ELi<HLP>ELb<ZPRE>EE: S64 != 0 (sector pairing) and HLP != 0 (helper waves) carry asm loads
+    asm_loads = {k: v for k, v in wave.items() if re.search(r"Lb1ELi\d+ELi\d+ELi[123]ELi[012]ELb[01]EE", k)}
     assert len(asm_loads) >= 10, sorted(wave)[:5]
     bad = {k: v for k, v in asm_loads.items() if v["vgpr_spills"] or v["scratch"]}
     assert not bad, f"kernels with hand-counted asm loads must not use scratch: {bad}"
-    helper = [k for k in asm_loads if re.search(r"ELi3ELi1EE", k)]
+    helper = [k for k in asm_loads if re.search(r"ELi3ELi1ELb[01]EE", k)]
     assert helper, "no helper-wave instantiation in the library"
     for k in helper:                       # two waves per SIMD: the 256-register budget
         assert asm_loads[k]["vgpr"] <= 256, (k, asm_loads[k])

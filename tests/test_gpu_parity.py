@@ -596,6 +596,69 @@ def test_affine_fold_into_the_inverse(shape, dev):
     assert rel_err(a2.cpu().numpy(), a.cpu().numpy()) > 1e-3
 
 
+# (B, C, H, W, K): problem sets the helper-wave form takes (B*4 > 256 -- > 512 on the 24-channel 3x3 bank, whose small-batch
+# variant comes first --, % 4 == 0, W % 16 == 0); C = 88 runs on the padded 24-channel bank (Cq = 22: the last group of four
+# carries two masked channels)
+PREMULTIPLIED_CASES = [(132, 96, 64, 64, 3), (72, 48, 32, 32, 3), (65, 64, 48, 48, 3), (130, 88, 20, 48, 3), (80, 32, 35, 16, 3),
+                       (70, 48, 33, 32, 2)]
+
+
+@pytest.mark.parametrize("shape", PREMULTIPLIED_CASES, ids=lambda c: "B%d_C%d_%dx%d_k%d" % c)
+def test_inverse_of_a_premultiplied_input(shape, dev):
+    """SURVEY 8 f3, second half: the channel mix in front of the unit applies blockdiag(Linv) and the inverse runs without
+    its z-term.  (a) the kernel alone: inverse_premultiplied(blockdiag(Linv) z) == inverse(z) == the oracle; (b) through
+    the container: [unit, ActNorm, Conv1x1] forward order -> the reverse chain takes the fused path by itself, gives what
+    the layer-by-layer chain gives, and follows in-place parameter updates."""
+    from fincflow_amd import FastFlowUnit, FlowSequential, glow, ops, _lib
+    from fincflow_amd.layers import StandardNormal
+    B, C, H, W, K = shape
+    torch.manual_seed(sum(shape))
+    unit = FastFlowUnit(C, C, K).to(dev)
+    ws = unit._weights()
+    assert _lib.lib().finc_inverse_premultiplied_supported(B, 4, C // 4, H, W, K, K) == 1
+    z = torch.randn(B, C, H, W, device=dev)
+    with torch.no_grad():
+        lead = unit._cache.lead_inverse(ws, 4, ORIENT_FASTFLOW)
+        zp = torch.einsum("gok,bgkhw->bgohw", lead.double(), z.view(B, 4, C // 4, H, W).double()).float().reshape(B, C, H, W).contiguous()
+        x_pre = unit._cache.inverse_premultiplied(zp, ws, 4, ORIENT_FASTFLOW)
+        x_ref = unit.reverse(z)
+    assert x_pre is not None
+    assert rel_err(x_pre.cpu().numpy(), x_ref.cpu().numpy()) <= TOL
+    if B * C * H * W <= 72 * 48 * 32 * 32:           # (the oracle on the big cases takes minutes: they are pinned through x_ref)
+        wco = oracle.canonicalize(torch.cat(ws).detach().cpu().numpy(), 4, ORIENT_FASTFLOW)
+        assert rel_err(x_pre.cpu().numpy(), oracle.inverse_via_f64(z.cpu().numpy(), wco)) <= TOL
+    assert _lib.hlp_timeouts() == 0
+    # a problem set the helper-wave form does not take: no such kernel, the caller keeps the plain chain
+    assert unit._cache.inverse_premultiplied(zp[:8].contiguous(), ws, 4, ORIENT_FASTFLOW) is None
+    if not ops.mix_supported(C):
+        return
+    an = glow.ActNorm(C).to(dev)
+    mix = glow.Conv1x1(C).to(dev)
+    with torch.no_grad():
+        an.log_scale.copy_(0.2 * torch.randn(C, device=dev))
+        an.translation.copy_(torch.randn(C, device=dev))
+        an.mark_initialized()
+    for layers in ([unit, mix], [unit, an, mix]):
+        seq = FlowSequential(StandardNormal((C, H, W)), *layers)
+        x = torch.randn(B, C, H, W, device=dev)
+        with torch.no_grad():
+            zz = seq(x)[0]
+            a = seq._reverse_chain(zz, None)
+            b = seq._reverse_chain(zz, None, fuse=False)
+            seq.fuse_lead = False
+            c = seq._reverse_chain(zz, None)
+            seq.fuse_lead = True
+        assert rel_err(a.cpu().numpy(), b.cpu().numpy()) <= TOL and rel_err(a.cpu().numpy(), c.cpu().numpy()) <= TOL
+        assert rel_err(a.cpu().numpy(), x.cpu().numpy()) <= 1e-4
+    with torch.no_grad():                             # in-place updates of the folded neighbours are picked up
+        an.translation.add_(0.5)
+        mix.W.mul_(1.01)
+        a2 = seq._reverse_chain(zz, None)
+        b2 = seq._reverse_chain(zz, None, fuse=False)
+    assert rel_err(a2.cpu().numpy(), b2.cpu().numpy()) <= TOL
+    assert _lib.hlp_timeouts() == 0
+
+
 @pytest.mark.parametrize("cfg", [(20, 3, 0.05), (28, 3, 0.04), (40, 3, 0.03), (64, 3, 0.02), (8, 2, 0.05), (12, 2, 0.05), (24, 2, 0.05),
                                  (32, 2, 0.05), (8, 5, 0.03), (12, 5, 0.03)])
 def test_wider_instantiation_table(cfg, dev):
