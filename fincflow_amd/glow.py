@@ -175,10 +175,11 @@ class Conv1x1(FlowLayer):
             return None
         from . import ops
         w_inv = self._inverse_matrix()
-        key = (lead.data_ptr(), lead._version) + (() if log_scale is None else
-                                                  (log_scale.data_ptr(), log_scale._version, translation.data_ptr(),
-                                                   translation._version))
-        if getattr(self, "_lead_key", None) != key or getattr(self, "_lead_inv", None) is not w_inv:
+        # (`lead` and `w_inv` are compared by identity and kept alive here: both are cache entries that are REPLACED when their
+        # weights change, and the address of a freed tensor is the first one the allocator hands out again)
+        key = () if log_scale is None else (log_scale.data_ptr(), log_scale._version, translation.data_ptr(), translation._version)
+        if (getattr(self, "_lead_key", None) != key or getattr(self, "_lead_inv", None) is not w_inv
+                or getattr(self, "_lead_obj", None) is not lead):
             with torch.no_grad():
                 m = w_inv.double()
                 b = None
@@ -188,7 +189,7 @@ class Conv1x1(FlowLayer):
                 blk = torch.block_diag(*lead.double().unbind(0))
                 self._m_lead = (blk @ m).float().contiguous()
                 self._b_lead = None if b is None else (blk @ b).float().contiguous()
-            self._lead_key, self._lead_inv = key, w_inv
+            self._lead_key, self._lead_inv, self._lead_obj = key, w_inv, lead
         return ops.finc_mix(z.contiguous(), self._m_lead, self._b_lead)
 
     def logdet(self, input, context=None):

@@ -161,4 +161,8 @@ def test_config4_exactly_as_benched():
         a = model._reverse_chain(z0, None, fuse=True)
         torch.manual_seed(11)
         a_true = model._reverse_chain(z0, None, fuse=False)
-        assert rel_err(a.cpu().numpy(), a_true.cpu().numpy()) <= 1e-4
+        # the chain ends in the dequantisation's floor (layers/dequantize.py): the two evaluations differ by fp32 rounding
+        # (the folds change the summation order), which may move a value across an integer -- a handful of pixels of the
+        # 393,216 differ by exactly one grey level, everything else is equal
+        d = (a - a_true).abs()
+        assert float(d.max()) <= 1.0 and float((d > 0).float().mean()) <= 1e-4, (float(d.max()), float((d > 0).float().mean()))
