@@ -119,14 +119,16 @@ __global__ __launch_bounds__((64 * WGW)) void finc_mix_kernel(const float *__res
         const int e = (mt * (NK + 1) + j) * 64;
         return ab[e / WIN][e % WIN];
     };
-    const int wave = blockIdx.x * WGW + (threadIdx.x >> 6), nwaves = gridDim.x * WGW;
+    // (readfirstlane: the wave index is uniform, but only this tells the compiler -- without it every buffer access of the loop is
+    // wrapped in a waterfall loop over its resource descriptor: 49 of them, C = 192: 676 -> 603 us, C = 96: 183 -> 178)
+    const int wave = blockIdx.x * WGW + __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), nwaves = gridDim.x * WGW;
     const unsigned img_bytes = (unsigned)C * (unsigned)HW * 4u;
     const unsigned rowpart = (unsigned)q * (unsigned)HW * 4u;        // lane part of an offset: channel q of a group of four
     // k-steps in blocks of at most KB (the operand registers of a block are all in flight together)
     constexpr int KB = PX == 4 ? (NK % 12 == 0 ? 12 : NK % 8 == 0 ? 8 : NK <= 8 ? NK : 4) : NK <= 32 ? NK : 24;
     static_assert(NK % KB == 0, "k-step blocks must tile the k-steps");
     for (int chunk = wave; chunk < total_chunks; chunk += nwaves) {
-        const int b = chunk / chunks_per_image, ci = chunk - b * chunks_per_image;
+        const int b = __builtin_amdgcn_readfirstlane(chunk / chunks_per_image), ci = chunk - b * chunks_per_image;   // (the small kernels divide on the VALU: say it again)
         const __amdgpu_buffer_rsrc_t rin =
             __builtin_amdgcn_make_buffer_rsrc((void *)(in + (size_t)b * C * HW), 0, (int)img_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t rout =

@@ -6,8 +6,10 @@ import torch
 from fincflow_amd import ops
 dev = torch.device("cuda:0")
 def timeit(fn, n=50):
-    for _ in range(5): fn()
-    torch.cuda.synchronize()
+    t_end = time.perf_counter() + 0.3        # clocks ramp up over the first tenths of a second of load
+    while time.perf_counter() < t_end:
+        for _ in range(5): fn()
+        torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for _ in range(n): fn()
