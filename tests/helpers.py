@@ -171,13 +171,18 @@ def split_problems(n):
 # ---------------------------------------------------------------------------
 def fuzz_case(rng, case):
     K = int(rng.choice([2, 3, 3, 3, 5]))
-    cq_opts = [1, 2, 3, 4, 6, 8, 12, 16, 20, 24, 28, 32, 40, 48, 64] if K == 3 else \
-        ([1, 3, 4, 8, 12, 13, 16, 24, 32] if K == 2 else [2, 4, 8, 12, 16, 32, 48])
+    # (channel counts between the compiled banks -- 22, 36, 44, 50 at 3x3, 20 at 5x5 -- run on the next larger bank)
+    cq_opts = [1, 2, 3, 4, 6, 8, 12, 16, 20, 22, 24, 28, 32, 36, 40, 44, 48, 50, 64] if K == 3 else \
+        ([1, 3, 4, 8, 12, 13, 16, 24, 32] if K == 2 else [2, 4, 8, 12, 16, 20, 32, 48])
     Cq = int(rng.choice(cq_opts))
     G = int(rng.choice([1, 4, 4, 4]))
     H = int(rng.integers(1, 41))
     W = int(rng.choice([rng.integers(1, 41), 4 * rng.integers(1, 12), 8 * rng.integers(1, 9), 16 * rng.integers(1, 5)]))   # W % 16 == 0: the staged forward
     B = int(rng.integers(1, 4))
+    if case % 5 == 4:          # every fifth case: more problems than compute units on a small map (the full-chip forms of the inverse)
+        B = int(rng.integers(65, 90)) * (4 if G == 1 else 1)
+        H = int(rng.integers(1, 20))
+        W = int(rng.choice([8, 12, 16, 16, 32]))
     orient = ORIENT_FASTFLOW if G == 4 else int(rng.integers(0, 4))
     std = (0.05 if K < 5 else 0.02) * min(1.0, (24.0 / Cq) ** 0.5)   # keep the operator norm of the bank roughly constant
     return dict(case=case, B=B, G=G, Cq=Cq, H=H, W=W, K=K, orient=orient, std=std)

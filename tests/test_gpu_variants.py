@@ -195,11 +195,11 @@ def test_c5_at_the_per_gpu_batch(dev):
     assert resid <= TOL and e_s <= TOL, (resid, e_s)
 
 
-@pytest.mark.parametrize("seed", [0, 1])
+@pytest.mark.parametrize("seed", [0, 1, 2])
 def test_bounded_fuzz_sweep(seed, dev):
     """scripts/fuzz_parity.py's generator, 40 cases per seed: random (B, G, Cq, H, W, K, orientation) through inverse
     auto/strict and the forward, against the oracle."""
-    from fincflow_amd import ops
+    from fincflow_amd import ops, _lib
     rng = np.random.default_rng(seed)
     worst = 0.0
     for case in range(40):
@@ -218,6 +218,16 @@ def test_bounded_fuzz_sweep(seed, dev):
         gap = rel_err(ref32, ref)
         tol = max(TOL, 2.0 * gap)
         e_inv, e_fwd = rel_err(auto, ref), rel_err(fwd, z)
+        if _lib.lib().finc_inverse_premultiplied_supported(B, G, Cq, H, W, K, K):   # the form without the z-term, where it exists
+            lead = np.linalg.inv(wco.reshape(G, Cq, Cq, K, K)[:, :, :, -1, -1].astype(np.float64))
+            zp = np.einsum("gok,bgkhw->bgohw", lead, z.reshape(B, G, Cq, H, W).astype(np.float64)).astype(np.float32).reshape(z.shape)
+            packed = torch.empty(_lib.lib().finc_workspace_bytes(G, Cq, K, K), dtype=torch.uint8, device=dev)
+            _lib.check(_lib.lib().finc_pack_inverse_weights_f32(wc.data_ptr(), packed.data_ptr(), G, Cq, K, K, None), "pack")
+            zpt, xo = t(zp, dev), torch.empty(z.shape, dtype=torch.float32, device=dev)
+            _lib.check(_lib.lib().finc_inverse_packed_premultiplied_f32(zpt.data_ptr(), packed.data_ptr(), xo.data_ptr(), B, G, Cq,
+                                                                         H, W, K, K, orient, None), "premultiplied")
+            torch.cuda.synchronize()
+            assert rel_err(xo.cpu().numpy(), ref) <= tol, (c, "premultiplied")
         report("fuzz", seed=seed, **c, err_max_norm=e_inv, err_elementwise=elem_rel_err(auto, ref), forward=e_fwd,
                reference_fp32_vs_fp64=gap, needed_more_than_1e5=bool(e_inv > TOL))
         assert np.array_equal(strict, ref32), c
