@@ -524,6 +524,10 @@ def bench_unit(args):
                          "traffic_measured_in_this_run": False,
                          "algorithmic_bytes_per_launch": alg_bytes, "launch_ms": inv_launch_ms,
                          "frac_fp32_peak": alg_flops / (inv_launch_ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS,
+                         # which of the two roofs is the lower one for this workload (time at the roof: bytes / HBM peak against
+                         # flops / fp32 MFMA peak); `frac` above stays the HBM figure so that rounds compare, `compute.frac` is
+                         # the fraction of the roof that binds when this says "mfma"
+                         "binding_roof": "mfma" if alg_flops / (FP32_PEAK_TFLOPS * 1e12) > alg_bytes / (HBM_PEAK_GBS * 1e9) else "hbm",
                          # the shape is compute-bound (K^2*Cq/4 flop/B against a ridge of ~20): the same launch against
                          # the ceiling that actually limits it, the dense fp32 MFMA peak
                          "compute": {"bound": "mfma", "achieved": alg_flops / (inv_launch_ms * 1e-3) / 1e12,
