@@ -1,0 +1,418 @@
+// Inverse for the BIG banks (gfx950 / CDNA4 only): 3x3 filters with 64 < Cq <= 96 -- CINCFlowUnit (fastflow/cinc_flow.py:9-30,
+// one group over all channels) at C = 96, FastFlowUnit at C = 260 .. 384 -- which no wave and no K-split of finc_mfma.hip can
+// hold: a 96-channel 3x3 bank is 1,296 16x16x4 fragments = 331 KB per group.
+//
+// M-split on the role-split kernel's machinery (finc_split.hip).  A workgroup of NWV = 8 waves solves one problem, lane p of
+// every wave owns the rows p, P+p, ... of the image and trails lane p-1 by one step (the reference's anti-diagonal order,
+// cinc_cuda_kernel_level2.cu:49-56,98-111, band by band).  Wave w owns the OUTPUT channels 12w .. 12w+11 -- three 4-row blocks
+// on v_mfma_f32_4x4x1_16B_f32 -- for ALL nine taps and all 24 k-steps: 9 x 24 x 3 = 648 block fragments, four to a register
+// (finc_tile.h) = 162 AGPRs, resident.  No wave keeps any operand history: the pixels solved in the last steps live in a shared
+// x ring in LDS ([k-step][time slot][lane]; a solved pixel's channels come out of the blocks' reduce in natural order, channel
+// 4j+q in k-slot q of k-step j, so wave w simply writes k-steps 3w .. 3w+2), tap (a,b) of step u reads the slot of step u-a-b at
+// lane p-a (the rows of the band above: the hand-over FIFO), a tap's column mask is applied to the address (an invalid lane
+// reads a zero word), and z waits in a shared z ring.  Nothing is exchanged but the 12 channels each wave publishes, and ONE
+// workgroup barrier per step orders it all: what step u reads was written in step u-1 or earlier.
+//
+// A step is 648 block MFMAs per wave (the z-term is computed in full although Linv is triangular: one code path for all
+// waves), two waves per SIMD: 10.4 k cycles of MFMA per step and SIMD, the floor of the shape.  A per-channel SCALE in front of
+// the inverse folds into the z-term as everywhere; a folded SHIFT is not supported here (no register left for it: the caller
+// keeps the affine layer as its own launch).  Each wave also owns the HBM side of its three k-steps:
+// 16-byte pieces, one window (4 steps) ahead -- a step lasts microseconds here -- landed in / collected from the rings.
+//
+// LDS (one workgroup per CU): per k-step the x ring (2 KB) and the FIFO block behind it (1,704 B: 53 slots), then the z ring
+// (3 KB per k-step): 24 x 6,824 = 163,776 of the 163,840 bytes: maps up to 64 wide.
+#include "finc_common.h"
+#include "finc_tile.h"
+
+#include <type_traits>
+#include <utility>
+
+namespace {
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+
+constexpr unsigned OFF_INVALID = 0x80000000u;     // voffset beyond any slab: buffer loads return 0, stores are dropped
+constexpr unsigned OFF_BAD_CHANNEL = 0x40000000u;  // added to a valid offset it still lands beyond the slab (< 1 GiB)
+
+template <int I>
+using IC = std::integral_constant<int, I>;
+#define FINC_SB() __builtin_amdgcn_sched_barrier(0)
+
+constexpr int XSLOTS = 8;        // x ring: the pixels of the last 8 steps (taps reach back KH + KW - 2 = 4, the stores 7)
+constexpr int RING_J = 2048;     // a k-step's x ring (8 slots x 64 lanes) ...
+constexpr int FIFO_J = 1704;     // ... and its FIFO block behind it: 53 slots x 32 bytes + the zero word (W <= 64)
+constexpr int JSTRIDE = RING_J + FIFO_J;   // bytes between the k-steps of BOTH: a lane's k-step stride is an immediate whichever it reads
+constexpr int ZJSTRIDE = 3072;   // bytes between the k-steps of the z ring (12 slots x 64 lanes)
+constexpr int UNROLL = 8;        // steps per iteration of the loop: two I/O windows
+
+template <int CQP, int KH, int KW, int NWV>
+struct BCfg {
+    static constexpr int NK = CQP / 4;                    // k-steps of an operand (k-slot q <-> channel 4j+q)
+    static constexpr int MO = CQP / NWV;                  // output channels of a wave
+    static constexpr int NB = MO / 4;                     // ... as 4-row blocks = the k-steps of the solved pixel it writes
+    static_assert(CQP % (4 * NWV) == 0, "every wave owns whole 4-row blocks");
+    static constexpr int NITEM = KH * KW;                 // item 0 = the z-term (tap (0,0): Linv), item a*KW+b = tap (a,b)
+    static constexpr int NFR = NITEM * NK * NB;           // block fragments of a wave
+    static constexpr int NREG = (NFR + 3) / 4;            // ... four to a register
+    static constexpr int JS = 4 * (KH - 1);               // FIFO: floats per slot and k-step (4 k-slots x (KH-1) lanes)
+    static constexpr int RING_B = 0, FIFO_B = RING_J, ZR_B = NK * JSTRIDE, LDS_BYTES = ZR_B + NK * ZJSTRIDE;
+    static_assert(LDS_BYTES <= 160 * 1024, "one workgroup per CU");
+    static_assert(ZR_B % 16 == 0 && NK % 2 == 0 && (NK / 2) * JSTRIDE < 65536 && (NK / 2) * ZJSTRIDE < 65536, "DS immediates reach half an operand");
+    // issue order of the items: the z-term, then the taps by falling a + b (oldest operand first) -- the two taps that need the
+    // pixel of the step before come last
+    static constexpr int order(int k)
+    {
+        if (k == 0) return 0;
+        int n = 0;
+        for (int sum = KH + KW - 2; sum >= 1; --sum)
+            for (int a = 0; a < KH; ++a)
+                for (int b = 0; b < KW; ++b)
+                    if (a + b == sum && ++n == k) return a * KW + b;
+        return 0;
+    }
+    static_assert(KH + KW - 2 <= XSLOTS - 1, "the x ring must reach back to the farthest tap");
+};
+
+// -----------------------------------------------------------------------------------------------
+// grid = B*G workgroups of NWV waves.  16 <= W <= 64, W % 4 == 0 (16-byte pieces); P = 16; DF slots of the FIFO.
+// -----------------------------------------------------------------------------------------------
+template <int CQP, int KH, int KW, int NWV>
+__global__ __launch_bounds__(64 * NWV) void finc_big_kernel(const float *__restrict__ in, const float *__restrict__ packed,
+                                                             float *__restrict__ out, int G, int CQ, int H, int W, int T,
+                                                             unsigned orient, int DF)
+{
+    using C = BCfg<CQP, KH, KW, NWV>;
+    constexpr int NK = C::NK, NB = C::NB, NJ = C::NB, JS = C::JS, P = 16;
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    char *const ldsb = reinterpret_cast<char *>(lds);
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const int q = lane >> 4, p = lane & 15;
+    const int bg = blockIdx.x, g = bg % G;
+    const unsigned o = finc_group_orient(orient, g);
+    const bool fh = (o & FINC_FLIP_H) != 0, fw = (o & FINC_FLIP_W) != 0;
+    const int HW = H * W;
+    const unsigned slab_bytes = (unsigned)CQ * (unsigned)HW * 4u;
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)(in + (size_t)bg * CQ * HW), 0, (int)slab_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void *)(out + (size_t)bg * CQ * HW), 0, (int)slab_bytes, 0x00020000);
+
+    for (int i = threadIdx.x; i < C::LDS_BYTES / 4; i += 64 * NWV) lds[i] = 0.f;
+
+    auto ld = [&](int byte_off) { return *reinterpret_cast<const float *>(ldsb + byte_off); };
+    auto st = [&](int byte_off, float v) { *reinterpret_cast<float *>(ldsb + byte_off) = v; };
+
+    // ---- this wave's fragments -> AGPRs (they are only ever MFMA A operands); the loads must have landed before the loop: all
+    // VMEM instructions of the loop are inline asm that the kernel counts itself
+    float fr[C::NREG];
+    {
+        const float *pk = packed + ((size_t)(g * NWV + wv) * C::NREG) * 64 + lane;
+#pragma unroll
+        for (int r = 0; r < C::NREG; ++r) fr[r] = pk[r * 64];
+        // (hipcc splits the 256 registers of a wave at two waves per SIMD 128 : 128 between VGPRs and AGPRs: the first 128
+        // fragment registers are pinned to AGPRs, the rest stay with the VGPRs)
+#pragma unroll
+        for (int r = 0; r < C::NREG; ++r) {
+            if (r < 128) asm volatile("" : "+a"(fr[r]));
+            else asm volatile("" : "+v"(fr[r]));
+        }
+    }
+    // fragment f = (item * NK + j) * NB + sb sits in register f >> 2 as ABID f & 3
+    auto mma = [&](v4f &acc, int f, float b) { finc_mma_small(acc, fr[f >> 2], b, f & 3); };
+
+    // ---- HBM side of this wave's k-steps JLO .. JLO+NJ-1 (finc_split.hip: 16-byte pieces = groups of 4 canonical columns of one
+    // row; group gi of lane p covers its positions n = 4gi .. 4gi+3, n = step - p; the z ring holds 3 groups, slot of position
+    // n = n mod 12, a W-flipped group is mirrored when it lands).  In window w (steps 4w .. 4w+3) a lane reads z of the groups
+    // w+f and w+f+1, f = floor(-p/4); it LANDS group w+f+2, requested ONE window earlier, and requests group w+f+3.  Stores: in
+    // window w the group w+fs, fs = floor((-3-p)/4), is collected from the x ring's time slots and leaves as one piece.
+    const int JLO = NJ * wv;
+    unsigned cmask[NJ];                        // (channel 4(JLO+j)+q: the natural order serves loads and stores alike)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) cmask[j] = (4 * (JLO + j) + q) < CQ ? (unsigned)((4 * (JLO + j) + q) * HW * 4) : OFF_BAD_CHANNEL;
+    const int f4 = -((p + 3) >> 2), fs4 = -((p + 3 + 3) >> 2);             // floor(-p / 4), floor((-3 - p) / 4)
+    const int dgrp = fw ? -16 : 16;                                        // bytes from a group to the next one of the row
+    const int drow = (fh ? -P : P) * W * 4 - (dgrp / 4) * W;               // ... and from the end of a row to the start of row + P
+    auto piece_off = [&](int row, int col0) { return ((fh ? H - 1 - row : row) * W + (fw ? W - 4 - col0 : col0)) * 4; };
+    int lcol = 4 * f4, lrow = p, loff = piece_off(p, 0) + f4 * dgrp;
+    int scol = 4 * fs4, srow = p, soff = piece_off(p, 0) + fs4 * dgrp;
+    v4f zin[NJ];                               // in flight HBM -> z ring
+    auto zreq = [&](v4f (&dst)[NJ]) {
+        const bool ok = lcol >= 0 && lrow < H;
+        const unsigned base = ok ? (unsigned)loff : OFF_INVALID;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(dst[j]) : "v"(base + cmask[j]), "s"(rin) : "memory");
+        lcol += 4; loff += dgrp;
+        if (lcol == W) { lcol = 0; lrow += P; loff += drow; }
+    };
+    int gland = ((f4 % 3) + 3) % 3;            // ring group of the next landing
+    const int zr_w = C::ZR_B + JLO * ZJSTRIDE + lane * 4;
+    const int e0 = fw ? 3 : 0, e1 = fw ? 2 : 1, e2 = fw ? 1 : 2, e3 = fw ? 0 : 3;
+    auto zland = [&](v4f (&src)[NJ], auto vm_c) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(decltype(vm_c)::value) : "memory");
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) asm volatile("" : "+v"(src[j]));      // (ties the reads below to the wait)
+        const int base = zr_w + gland * 1024;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const float v0 = src[j].x, v1 = src[j].y, v2 = src[j].z, v3 = src[j].w;
+            st(base + e0 * 256 + j * ZJSTRIDE, v0);
+            st(base + e1 * 256 + j * ZJSTRIDE, v1);
+            st(base + e2 * 256 + j * ZJSTRIDE, v2);
+            st(base + e3 * 256 + j * ZJSTRIDE, v3);
+        }
+        gland = gland == 2 ? 0 : gland + 1;
+    };
+    // stores: element k of the group was solved at step 4gs + k + p: time slot ((p + k) & 7) ^ (4 * (gs & 1))
+    const int xbase = C::RING_B + JLO * JSTRIDE;   // (not a multiple of 2 KB: the toggle below works on the slot part alone)
+    const int xs0 = (((p + e0) & 7) * 64 + lane) * 4, xs1 = (((p + e1) & 7) * 64 + lane) * 4;
+    const int xs2 = (((p + e2) & 7) * 64 + lane) * 4, xs3 = (((p + e3) & 7) * 64 + lane) * 4;
+    int stog = (fs4 & 1) * 1024;               // toggles with the group
+    auto xstore = [&]() {
+        const bool ok = scol >= 0 && srow < H;
+        const unsigned base = ok ? (unsigned)soff : OFF_INVALID;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            v4f v;
+            v.x = ld(xbase + (xs0 ^ stog) + j * JSTRIDE);
+            v.y = ld(xbase + (xs1 ^ stog) + j * JSTRIDE);
+            v.z = ld(xbase + (xs2 ^ stog) + j * JSTRIDE);
+            v.w = ld(xbase + (xs3 ^ stog) + j * JSTRIDE);
+            // (s_nop: a store of more than 8 bytes reads its data one wait state after issue, and the hazard recognizer does not
+            // see inline asm)
+            asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" ::"v"(v), "v"(base + cmask[j]), "s"(rout) : "memory");
+        }
+        stog ^= 1024;
+        scol += 4; soff += dgrp;
+        if (scol == W) { scol = 0; srow += P; soff += drow; }
+    };
+    {   // prologue: groups f, f+1 land now (window 0 reads them), f+2 waits in flight
+        v4f tmp0[NJ], tmp1[NJ];
+        zreq(tmp0); zreq(tmp1); zreq(zin);
+        zland(tmp0, IC<NJ>{}); zland(tmp1, IC<NJ>{});
+    }
+    int zn = ((-p) % 12 + 12) % 12;            // z read slot: position n mod 12 of this lane
+
+    // ---- operands of step u.  S_a(u-a-b): the x ring at lane p - a (lanes p >= a) / the FIFO (lanes p < a: the band above);
+    // a tap's column mask (b > 0: column c - b must exist) is applied to the ADDRESS -- the zero word of the k-step's FIFO block
+    int cb = 0 - p;                            // col of this lane at step u (negative: not started)
+    int fs2 = ((-2 - (W - P)) % DF + DF) % DF; // FIFO slot of the push of step u - 2 - (W - P)
+    int fpush = 0;                             // FIFO slot of this step's push
+    const bool pusher = p >= P - (KH - 1);
+    const int ring_w = C::RING_B + JLO * JSTRIDE + lane * 4;
+    const int push_w = C::FIFO_B + JLO * JSTRIDE + (q * (KH - 1) + (p - (P - (KH - 1)))) * 4;
+    auto item_addr = [&](auto item_c, int u) {
+        constexpr int item = decltype(item_c)::value;
+        constexpr int a = item / KW, b = item % KW;
+        if constexpr (item == 0) return C::ZR_B + zn * 256 + lane * 4;
+        const int tau = u - a - b;
+        int fs = fs2 - (a + b - 2);            // slot of push step tau - (W - P)
+        if (fs < 0) fs += DF;
+        if (fs >= DF) fs -= DF;
+        const int ring = C::RING_B + ((tau & (XSLOTS - 1)) * 64 + lane - a) * 4;
+        const int fifo = C::FIFO_B + (fs * JS + q * (KH - 1) + (KH - 1 - a + p)) * 4;
+        int addr = (a == 0 || p >= a) ? ring : fifo;
+        if constexpr (b > 0) addr = cb >= b ? addr : JSTRIDE - 4;          // (the zero word: the end of the k-step's FIFO block)
+        return addr;
+    };
+    __syncthreads();
+    // one step: pixel u of every lane.  Items in the order oldest operand first (the z-term, then the taps by falling a + b):
+    // the two taps that need the pixel of the step before come last.
+    constexpr int NITEM = C::NITEM;
+    constexpr int HALF = NK / 4;               // operands in batches of a quarter of an item, read one batch ahead of their MFMAs
+    constexpr int NBATCH = 4;
+    auto step = [&](auto k_c, int u) {
+        constexpr int KU = decltype(k_c)::value;                            // u % UNROLL
+        constexpr int PH = KU & 3;
+        // ---- HBM side of the window
+        if constexpr (PH == 0) {
+            if (u == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (no stores yet behind the first request)
+            zland(zin, IC<NJ>{});              // younger than the loads that land: the stores of the window in between
+            zreq(zin);
+        }
+        if constexpr (PH == 2) xstore();
+        v4f acc[NB];
+#pragma unroll
+        for (int sb = 0; sb < NB; ++sb) acc[sb] = (v4f){0.f, 0.f, 0.f, 0.f};
+        float v[2][HALF];
+        auto read_half = [&](auto i_c, auto h_c, float (&dst)[HALF]) {
+            constexpr int I = decltype(i_c)::value, HH = decltype(h_c)::value;
+            constexpr int item = C::order(I);
+            constexpr int SJ = item == 0 ? ZJSTRIDE : JSTRIDE;
+            const int addr = item_addr(IC<item>{}, u) + (HH / 2) * (NK / 2) * SJ;   // (one base per half: the immediates reach 64 KB)
+#pragma unroll
+            for (int j = 0; j < HALF; ++j) dst[j] = ld(addr + ((HH % 2) * HALF + j) * SJ);
+        };
+        auto mma_half = [&](auto i_c, auto h_c, const float (&src)[HALF]) {
+            constexpr int I = decltype(i_c)::value, HH = decltype(h_c)::value;
+            constexpr int item = C::order(I);
+#pragma unroll
+            for (int j = 0; j < HALF; ++j)
+#pragma unroll
+                for (int sb = 0; sb < NB; ++sb) mma(acc[sb], (item * NK + HH * HALF + j) * NB + sb, src[j]);
+        };
+        read_half(IC<0>{}, IC<0>{}, v[0]);
+        [&]<int... S>(std::integer_sequence<int, S...>) {
+            (([&] {
+                 constexpr int I = S / NBATCH, HH = S % NBATCH;             // batch S of the NBATCH * NITEM
+                 if constexpr (S + 1 < NBATCH * NITEM) read_half(IC<(S + 1) / NBATCH>{}, IC<(S + 1) % NBATCH>{}, v[(S + 1) & 1]);
+                 FINC_SB();
+                 mma_half(IC<I>{}, IC<HH>{}, v[S & 1]);
+                 FINC_SB();
+             }()), ...);
+        }(std::make_integer_sequence<int, NBATCH * NITEM>{});
+        // ---- the pixel: channel 4(JLO+sb)+q in lane row q; a lane that has not started yields exact zeros
+        float xq[NB];
+#pragma unroll
+        for (int sb = 0; sb < NB; ++sb) xq[sb] = finc_block_reduce(acc[sb]);
+        if (__builtin_expect(u < P - 1, 0)) {
+            const bool started = cb >= 0;
+#pragma unroll
+            for (int sb = 0; sb < NB; ++sb) xq[sb] = started ? xq[sb] : 0.f;
+        }
+        const int slot = u & (XSLOTS - 1);
+#pragma unroll
+        for (int sb = 0; sb < NB; ++sb) st(ring_w + slot * 256 + sb * JSTRIDE, xq[sb]);
+        if (pusher) {
+#pragma unroll
+            for (int sb = 0; sb < NB; ++sb) st(push_w + fpush * (JS * 4) + sb * JSTRIDE, xq[sb]);
+        }
+        ++cb; if (cb == W) cb = 0;
+        ++fs2; if (fs2 == DF) fs2 = 0;
+        ++fpush; if (fpush == DF) fpush = 0;
+        zn = zn == 11 ? 0 : zn + 1;
+        __syncthreads();
+    };
+    // steps u = 0 .. T, unrolled by UNROLL: the host rounds T up so that T + 1 is a multiple of it (the extra steps solve rows
+    // below the image: nothing is stored)
+    for (int u0 = 0; u0 <= T; u0 += UNROLL) {
+        [&]<int... K>(std::integer_sequence<int, K...>) { ((step(IC<K>{}, u0 + K)), ...); }(std::make_integer_sequence<int, UNROLL>{});
+    }
+}
+
+// -----------------------------------------------------------------------------------------------
+// Fragment packing (fp64 math, one workgroup per group): Linv = L^-1 by forward substitution;
+// item 0 (z-term) = Linv * diag(scale); item a*KW+b = -(Linv * Wc[:,:,KH-1-a,KW-1-b]).  Wave w, fragment f = (item*NK + j)*NB + sb: value (row i, k-slot q) = M_item[MO*w + 4sb + i][4j + q], in register
+// f >> 2, lane (q, 4*(f & 3) + i)  (finc_tile.h: four block fragments to a register).
+// -----------------------------------------------------------------------------------------------
+__global__ void big_pack_kernel(const float *__restrict__ wc, const float *__restrict__ scale, float *__restrict__ packed, int Cq, int KH, int KW, int NWV, int NK, int NB, int NREG)
+{
+    extern __shared__ __attribute__((aligned(16))) double sm[]; // Linv [Cq][Cq]
+    const int g = blockIdx.x;
+    const float *wg = wc + (size_t)g * Cq * Cq * KH * KW;
+    const int KK = KH * KW, MO = 4 * NB, NITEM = KK;
+    double *Linv = sm;
+    for (int j = threadIdx.x; j < Cq; j += blockDim.x) {      // column j of Linv: solve L y = e_j (L unit lower triangular)
+        for (int r = 0; r < Cq; ++r) {
+            double s = (r == j) ? 1.0 : 0.0;
+            for (int k = j; k < r; ++k) s -= (double)wg[((size_t)r * Cq + k) * KK + (KK - 1)] * Linv[k * Cq + j];
+            Linv[r * Cq + j] = (r < j) ? 0.0 : s;
+        }
+    }
+    __syncthreads();
+    const int total = NWV * NREG * 64;
+    for (int e = threadIdx.x; e < total; e += blockDim.x) {
+        const int lane = e & 63, r = (e >> 6) % NREG, w = e / (64 * NREG);
+        const int q = lane >> 4, a4 = (lane & 15) >> 2, i = lane & 3;
+        const int f = 4 * r + a4;
+        double v = 0.0;
+        if (f < NITEM * NK * NB) {
+            const int sb = f % NB;
+            const int row = MO * w + 4 * sb + i;
+            const int j = (f / NB) % NK, item = f / (NB * NK);
+            const int col = 4 * j + q;
+            if (row < Cq && col < Cq) {
+                if (item == 0) {
+                    v = Linv[row * Cq + col] * (scale ? (double)scale[g * Cq + col] : 1.0);
+                } else {
+                    const int a = item / KW, b = item % KW;
+                    const int widx = (KH - 1 - a) * KW + (KW - 1 - b);
+                    double s = 0.0;
+                    for (int k = 0; k <= row; ++k) s += Linv[row * Cq + k] * (double)wg[((size_t)k * Cq + col) * KK + widx];
+                    v = -s;
+                }
+            }
+        }
+        packed[((size_t)(g * NWV + w) * NREG + r) * 64 + lane] = (float)v;
+    }
+}
+
+typedef void (*big_fn)(const float *, const float *, float *, int, int, int, int, int, unsigned, int);
+struct BInst {
+    int cqp, kh, kw, nwv, nk, nb, nreg, lds_bytes;
+    big_fn fn;
+};
+template <int CQP, int KH, int KW, int NWV>
+constexpr BInst make_binst()
+{
+    using C = BCfg<CQP, KH, KW, NWV>;
+    return BInst{CQP, KH, KW, NWV, C::NK, C::NB, C::NREG, C::LDS_BYTES, finc_big_kernel<CQP, KH, KW, NWV>};
+}
+const BInst g_binsts[] = {make_binst<96, 3, 3, 8>()};
+
+// the big banks start where the wavefront kernel's table ends (finc_mfma.hip: 64 channels at 3x3)
+const BInst *find_binst(int Cq, int KH, int KW)
+{
+    for (const BInst &i : g_binsts)
+        if (i.kh == KH && i.kw == KW && Cq > 64 && Cq <= i.cqp) return &i;
+    return nullptr;
+}
+
+int big_fifo_depth(int W, int KH, int KW) { return W - 16 + KH + KW - 2 + 1; }   // (+1: a step pushes the slot its farthest tap read)
+
+} // namespace
+
+bool finc_big_bank(int Cq, int KH, int KW) { return find_binst(Cq, KH, KW) != nullptr; }
+
+bool finc_big_supported(int Cq, int H, int W, int KH, int KW)
+{
+    const BInst *i = find_binst(Cq, KH, KW);
+    if (!i || H < 1 || W < 16 || W % 4 != 0) return false;
+    if ((size_t)big_fifo_depth(W, KH, KW) * 4 * (KH - 1) * 4 > (size_t)FIFO_J - 4) return false;   // (+ the zero word)
+    return (size_t)Cq * H * W * 4 < ((size_t)1 << 30);                     // buffer-offset range marks (OFF_BAD_CHANNEL)
+}
+
+size_t finc_big_packed_bytes(int G, int Cq, int KH, int KW)
+{
+    const BInst *i = find_binst(Cq, KH, KW);
+    return i ? (size_t)G * i->nwv * i->nreg * 64 * sizeof(float) : 0;
+}
+
+int finc_big_pack(const float *wc, const float *scale, const float *shift, void *packed, int G, int Cq, int KH, int KW, hipStream_t st)
+{
+    const BInst *i = find_binst(Cq, KH, KW);
+    if (!i || shift) return FINC_ERR_UNSUPPORTED;              // (a folded shift: not in this kernel)
+    const size_t lds = sizeof(double) * (size_t)Cq * Cq;
+    if (int e = finc_ensure_dynamic_lds((const void *)big_pack_kernel, lds)) return e;
+    hipLaunchKernelGGL(big_pack_kernel, dim3(G), dim3(256), lds, st, wc, scale, (float *)packed, Cq, KH, KW, i->nwv, i->nk,
+                       i->nb, i->nreg);
+    FINC_CHECK_LAUNCH();
+    return FINC_OK;
+}
+
+int finc_big_info(const FincShape &s, int *waves, int *lds, int *cqp)
+{
+    const BInst *i = find_binst(s.Cq, s.KH, s.KW);
+    if (!i) return FINC_ERR_UNSUPPORTED;
+    *waves = i->nwv; *lds = i->lds_bytes; *cqp = i->cqp;
+    return FINC_OK;
+}
+
+int finc_big_launch(const float *in, const void *packed, float *out, const FincShape &s, hipStream_t st)
+{
+    const BInst *i = find_binst(s.Cq, s.KH, s.KW);
+    if (!i || !finc_big_supported(s.Cq, s.H, s.W, s.KH, s.KW)) return FINC_ERR_UNSUPPORTED;
+    if (((uintptr_t)in & 15u) || ((uintptr_t)out & 15u)) return FINC_ERR_ALIGNMENT;
+    const int P = 16;
+    // steps of one problem: NB*W + P - 1; the last group of lane P-1 leaves in window NB*W/4 + 4, at step NB*W + 18; the loop is
+    // unrolled by UNROLL and runs u = 0 .. Tr
+    const int T = ((s.H + P - 1) / P) * s.W + P - 1;
+    const int Tr = (T + 4 + UNROLL - 1) / UNROLL * UNROLL - 1;
+    const size_t lds = (size_t)i->lds_bytes;
+    if (int e = finc_ensure_dynamic_lds((const void *)i->fn, lds)) return e;
+    hipLaunchKernelGGL(i->fn, dim3(s.B * s.G), dim3(64 * i->nwv), lds, st, in, (const float *)packed, out, s.G, s.Cq, s.H, s.W, Tr,
+                       s.orient, big_fifo_depth(s.W, s.KH, s.KW));
+    FINC_CHECK_LAUNCH();
+    return FINC_OK;
+}
+
+unsigned finc_build_flags_big() { return FINC_BUILD_FLAGS; }

@@ -88,6 +88,14 @@ int finc_mfma_hlp_timeouts(unsigned *count);
 int finc_mfma_packed_cqp(int Cq, int KH, int KW);
 
 // ---- inverse for the under-filled chip, role-split kernel: finc_split.hip (same packed bank as the wavefront kernel) ----
+// finc_big.hip: 3x3 banks beyond the wavefront kernel's table (64 < Cq <= 96), 8 waves per problem, each owns 12 output channels
+bool finc_big_bank(int Cq, int KH, int KW);
+bool finc_big_supported(int Cq, int H, int W, int KH, int KW);
+size_t finc_big_packed_bytes(int G, int Cq, int KH, int KW);
+int finc_big_pack(const float *wc, const float *scale, const float *shift, void *packed, int G, int Cq, int KH, int KW, hipStream_t st);
+int finc_big_info(const FincShape &s, int *waves, int *lds_bytes, int *cqp);
+int finc_big_launch(const float *in, const void *packed, float *out, const FincShape &s, hipStream_t st);
+unsigned finc_build_flags_big();
 bool finc_split_takes(const FincShape &s);       // this problem set runs on the role-split kernel
 int finc_split_info(const FincShape &s, int *waves, int *lds_bytes, int *steps);
 int finc_split_launch(const float *in, const void *packed, float *out, const FincShape &s, hipStream_t st);

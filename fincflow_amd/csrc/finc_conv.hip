@@ -163,7 +163,7 @@ __global__ __launch_bounds__(64 * NW)
         // MFMA A operands: keep them out of the VGPRs.  With the 256-register budget of two waves per SIMD the files are
         // split 128 : 128, so a bank larger than that pins what fits and leaves the rest to the allocator.
         constexpr int NBIG = (NFRAG / MT) * MTB;
-        constexpr int NPIN = (NW == 1 && NBIG + NSR > 124 && NBIG + NSR <= 176) ? 124 - NSR : NBIG;
+        constexpr int NPIN = ((NW == 1 || NW >= 8) && NBIG + NSR > 124 && NBIG + NSR <= 176) ? 124 - NSR : NBIG;   // (NW >= 8: two waves per SIMD by the size of the workgroup)
         int pinned = 0;
 #pragma unroll
         for (int f = 0; f < NFRAG; ++f) {
@@ -595,7 +595,7 @@ constexpr ConvInst make_conv()
 }
 const ConvInst g_conv[] = {
     make_conv<4, 3, 3>(),  make_conv<8, 3, 3>(),  make_conv<12, 3, 3>(), make_conv<16, 3, 3>(), make_conv<20, 3, 3>(),
-    make_conv<24, 3, 3>(), make_conv<28, 3, 3>(), make_conv<32, 3, 3>(), make_conv<40, 3, 3, 2>(), make_conv<48, 3, 3, 2>(), make_conv<64, 3, 3, 4>(),
+    make_conv<24, 3, 3>(), make_conv<28, 3, 3>(), make_conv<32, 3, 3>(), make_conv<40, 3, 3, 2>(), make_conv<48, 3, 3, 2>(), make_conv<64, 3, 3, 4>(), make_conv<96, 3, 3, 8>(),
     make_conv<4, 2, 2>(),  make_conv<8, 2, 2>(),  make_conv<12, 2, 2>(), make_conv<16, 2, 2>(), make_conv<24, 2, 2>(),
     make_conv<32, 2, 2>(),
     make_conv<4, 5, 5>(),  make_conv<8, 5, 5>(),  make_conv<12, 5, 5>(), make_conv<16, 5, 5>(), make_conv<24, 5, 5, 2>(), make_conv<32, 5, 5, 4>(),

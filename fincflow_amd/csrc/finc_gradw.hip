@@ -538,7 +538,7 @@ constexpr GradwInst make_gradw()
 // the (Cq, K) pairs of finc_conv.hip's table
 const GradwInst g_gradw[] = {
     make_gradw<4, 3, 3>(),  make_gradw<8, 3, 3>(),  make_gradw<12, 3, 3>(), make_gradw<16, 3, 3>(), make_gradw<20, 3, 3>(),
-    make_gradw<24, 3, 3>(), make_gradw<28, 3, 3>(), make_gradw<32, 3, 3>(), make_gradw<40, 3, 3>(), make_gradw<48, 3, 3>(), make_gradw<64, 3, 3>(),
+    make_gradw<24, 3, 3>(), make_gradw<28, 3, 3>(), make_gradw<32, 3, 3>(), make_gradw<40, 3, 3>(), make_gradw<48, 3, 3>(), make_gradw<64, 3, 3>(), make_gradw<96, 3, 3>(),
     make_gradw<4, 2, 2>(),  make_gradw<8, 2, 2>(),  make_gradw<12, 2, 2>(), make_gradw<16, 2, 2>(), make_gradw<24, 2, 2>(),
     make_gradw<32, 2, 2>(),
     make_gradw<4, 5, 5>(),  make_gradw<8, 5, 5>(),  make_gradw<12, 5, 5>(), make_gradw<16, 5, 5>(), make_gradw<24, 5, 5>(), make_gradw<32, 5, 5>(),

@@ -1643,6 +1643,7 @@ int finc_mfma_hlp_timeouts(unsigned *count)
 
 bool finc_mfma_supported(int Cq, int H, int W, int KH, int KW)
 {
+    if (finc_big_bank(Cq, KH, KW)) return finc_big_supported(Cq, H, W, KH, KW);   // beyond this table: finc_big.hip
     if (W % 4 != 0 || W < 4 || H < 1) return false;
     const int P = W < 16 ? W : 16;
     if (P < KH - 1) return false;
@@ -1655,12 +1656,14 @@ bool finc_mfma_supported(int Cq, int H, int W, int KH, int KW)
 
 int finc_mfma_packed_cqp(int Cq, int KH, int KW)
 {
+    if (finc_big_bank(Cq, KH, KW)) { int w, l, c; return finc_big_info(FincShape{1, 1, Cq, 16, 16, KH, KW, 0}, &w, &l, &c) ? 0 : c; }
     const Inst *a = find_inst(Cq, KH, KW);
     return a ? a->cqp : 0;
 }
 
 size_t finc_mfma_packed_bytes(int G, int Cq, int KH, int KW)
 {
+    if (finc_big_bank(Cq, KH, KW)) return finc_big_packed_bytes(G, Cq, KH, KW);
     const Inst *a = find_inst(Cq, KH, KW);
     return a ? (size_t)(a->nfrag + 8 * a->mt) * 64 * sizeof(float) * (size_t)G : 0;
 }
@@ -1668,6 +1671,7 @@ size_t finc_mfma_packed_bytes(int G, int Cq, int KH, int KW)
 int finc_mfma_pack(const float *wc, const float *scale, const float *shift, void *packed, int G, int Cq, int KH, int KW,
                    hipStream_t st)
 {
+    if (finc_big_bank(Cq, KH, KW)) return finc_big_pack(wc, scale, shift, packed, G, Cq, KH, KW, st);
     const Inst *i = find_inst(Cq, KH, KW);
     if (!i) return FINC_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(pack_kernel, dim3(G), dim3(256), sizeof(double) * Cq * Cq, st, wc, scale, shift, (float *)packed, Cq,
@@ -1679,6 +1683,13 @@ int finc_mfma_pack(const float *wc, const float *scale, const float *shift, void
 int finc_mfma_variant(int B, int G, int Cq, int H, int W, int KH, int KW, int *info)
 {
     if (!finc_mfma_supported(Cq, H, W, KH, KW)) return FINC_ERR_UNSUPPORTED;
+    if (finc_big_bank(Cq, KH, KW)) {           // form 5: the big-bank kernel, one workgroup of info[1] waves per problem
+        int waves = 0, lds = 0, cqp = 0;
+        if (int e = finc_big_info(FincShape{B, G, Cq, H, W, KH, KW, 0}, &waves, &lds, &cqp)) return e;
+        info[0] = cqp; info[1] = waves; info[2] = 1; info[3] = 5; info[4] = lds; info[5] = B * G;
+        info[6] = -2; info[7] = (int)(sizeof(g_insts) / sizeof(g_insts[0]));
+        return FINC_OK;
+    }
     const Inst *i = find_inst(Cq, KH, KW, (long long)B * G, W);
     if (!i) return FINC_ERR_UNSUPPORTED;
     const int P = W < 16 ? W : 16;
@@ -1728,6 +1739,7 @@ int finc_mfma_launch(const float *in, const void *packed, float *out, const Finc
     if (!finc_mfma_supported(s.Cq, s.H, s.W, s.KH, s.KW)) return FINC_ERR_UNSUPPORTED;
     if (zpre && !finc_mfma_zpre_takes(s)) return FINC_ERR_UNSUPPORTED;
     if (int e = finc_fault_gate(false)) return e;          // an earlier launch on this device gave up a protocol wait
+    if (finc_big_bank(s.Cq, s.KH, s.KW)) return finc_big_launch(in, packed, out, s, st);   // beyond this table (finc_big.hip)
     if (finc_split_takes(s)) return finc_split_launch(in, packed, out, s, st);   // the under-filled chip (finc_split.hip)
     const Inst *i = find_inst(s.Cq, s.KH, s.KW, (long long)s.B * s.G, s.W);
     if (!i) return FINC_ERR_UNSUPPORTED;

@@ -420,10 +420,13 @@ class PackedWeights:
                 shift = translation.detach().float().contiguous()
                 if scale.numel() != G * Cq or shift.numel() != G * Cq:
                     raise ValueError("affine parameters must have one entry per channel")
-                bank.packed_aff = torch.empty(L.finc_workspace_bytes(G, Cq, KH, KW), dtype=torch.uint8, device=y.device)
-                _lib.check(L.finc_pack_inverse_weights_affine_f32(w_canon.data_ptr(), scale.data_ptr(), shift.data_ptr(),
-                                                                  bank.packed_aff.data_ptr(), G, Cq, KH, KW, _stream_ptr(y)),
-                           "finc_pack_inverse_weights_affine_f32")
+                packed = torch.empty(L.finc_workspace_bytes(G, Cq, KH, KW), dtype=torch.uint8, device=y.device)
+                st = L.finc_pack_inverse_weights_affine_f32(w_canon.data_ptr(), scale.data_ptr(), shift.data_ptr(), packed.data_ptr(),
+                                                            G, Cq, KH, KW, _stream_ptr(y))
+                if st == 3:        # FINC_ERR_UNSUPPORTED: a bank whose kernel cannot carry the shift (the big banks, finc_big.hip)
+                    return None
+                _lib.check(st, "finc_pack_inverse_weights_affine_f32")
+                bank.packed_aff = packed
                 bank.aff_key = key
             _lib.check(L.finc_inverse_packed_f32(y.data_ptr(), bank.packed_aff.data_ptr(), out.data_ptr(), B, G, Cq, H, W,
                                                  KH, KW, orient, _stream_ptr(y)), "finc_inverse_packed_f32")
