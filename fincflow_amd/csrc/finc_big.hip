@@ -57,7 +57,12 @@ struct BCfg {
     static constexpr int JS = 4 * (KH - 1);               // FIFO: floats per slot and k-step (4 k-slots x (KH-1) lanes)
     static constexpr int RING_B = 0, FIFO_B = RING_J, ZR_B = NK * JSTRIDE, LDS_BYTES = ZR_B + NK * ZJSTRIDE;
     static_assert(LDS_BYTES <= 160 * 1024, "one workgroup per CU");
-    static_assert(ZR_B % 16 == 0 && NK % 2 == 0 && (NK / 2) * JSTRIDE < 65536 && (NK / 2) * ZJSTRIDE < 65536, "DS immediates reach half an operand");
+    // operands are read in batches of BS k-steps, one batch ahead of their MFMAs; a DS immediate reaches 64 KB: a second base
+    // register for the upper half of an operand that is longer
+    static constexpr int BS = NK % 6 == 0 ? 6 : NK % 4 == 0 ? 4 : NK;
+    static constexpr int NBAT = NK / BS;
+    static_assert(NK % BS == 0 && BS <= 8, "batches tile the k-steps");
+    static_assert(NK * ZJSTRIDE < 65536 || (NK % 2 == 0 && (NK / 2) % BS == 0 && (NK / 2) * JSTRIDE < 65536), "DS immediates reach half an operand");
     // issue order of the items: the z-term, then the taps by falling a + b (oldest operand first) -- the two taps that need the
     // pixel of the step before come last
     static constexpr int order(int k)
@@ -218,8 +223,7 @@ __global__ __launch_bounds__(64 * NWV) void finc_big_kernel(const float *__restr
     // one step: pixel u of every lane.  Items in the order oldest operand first (the z-term, then the taps by falling a + b):
     // the two taps that need the pixel of the step before come last.
     constexpr int NITEM = C::NITEM;
-    constexpr int HALF = NK / 4;               // operands in batches of a quarter of an item, read one batch ahead of their MFMAs
-    constexpr int NBATCH = 4;
+    constexpr int HALF = C::BS, NBATCH = C::NBAT;   // (batch size, batches per item)
     auto step = [&](auto k_c, int u) {
         constexpr int KU = decltype(k_c)::value;                            // u % UNROLL
         constexpr int PH = KU & 3;
@@ -238,9 +242,11 @@ __global__ __launch_bounds__(64 * NWV) void finc_big_kernel(const float *__restr
             constexpr int I = decltype(i_c)::value, HH = decltype(h_c)::value;
             constexpr int item = C::order(I);
             constexpr int SJ = item == 0 ? ZJSTRIDE : JSTRIDE;
-            const int addr = item_addr(IC<item>{}, u) + (HH / 2) * (NK / 2) * SJ;   // (one base per half: the immediates reach 64 KB)
+            constexpr bool FAR = NK * SJ > 65535;
+            constexpr int J0 = FAR && HH * HALF >= NK / 2 ? NK / 2 : 0;    // (k-step of the base register)
+            const int addr = item_addr(IC<item>{}, u) + J0 * SJ;
 #pragma unroll
-            for (int j = 0; j < HALF; ++j) dst[j] = ld(addr + ((HH % 2) * HALF + j) * SJ);
+            for (int j = 0; j < HALF; ++j) dst[j] = ld(addr + (HH * HALF + j - J0) * SJ);
         };
         auto mma_half = [&](auto i_c, auto h_c, const float (&src)[HALF]) {
             constexpr int I = decltype(i_c)::value, HH = decltype(h_c)::value;
@@ -349,7 +355,10 @@ constexpr BInst make_binst()
 }
 const BInst g_binsts[] = {make_binst<96, 3, 3, 8>()};
 
-// the big banks start where the wavefront kernel's table ends (finc_mfma.hip: 64 channels at 3x3)
+// the big banks start where the wavefront kernel's table ends (finc_mfma.hip: 64 channels at 3x3).  (The same kernel on the
+// SMALL banks -- <24,3,3> as 6 waves, <12,3,3> as 3 -- was measured against the role-split kernel for the under-filled chip:
+// 0.93 against 0.60 us per step at c3, 0.59 against 0.47 at c2: a step is then its fixed costs, not its MFMAs.
+// profiles/r03/notes/msplit_on_small_banks.txt)
 const BInst *find_binst(int Cq, int KH, int KW)
 {
     for (const BInst &i : g_binsts)
