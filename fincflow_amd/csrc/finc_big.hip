@@ -24,6 +24,8 @@
 #include "finc_common.h"
 #include "finc_tile.h"
 
+#include <stdlib.h>
+
 #include <type_traits>
 #include <utility>
 
@@ -342,16 +344,177 @@ __global__ void big_pack_kernel(const float *__restrict__ wc, const float *__res
     }
 }
 
+// -----------------------------------------------------------------------------------------------
+// The FORWARD (and grad-input: the same kernel on transposed fragments and the toggled orientation) of the big banks, on the same
+// split.  A workgroup of NWV waves walks one strip of 16 canonical columns of one (image, group) row by row; wave w owns the
+// output channels MO*w .. MO*w + MO-1 (NB blocks) for all taps and k-steps, fragments resident as above.  The input rows are
+// shared: a ring of 4 rows in LDS, [slot][k-step][column 0..19][k-slot] -- the strip's 16 columns behind 4 columns of halo --, so
+// that the B operand of tap (a,b) is one conflict-free ds_read_b32 (lane (q,p) <- row h-a, column p-b, channel 4j+q).  Every
+// wave fetches the NEXT row of its own NB k-steps (4*NB channel rows x 5 pieces of 16 bytes: one dwordx4 of the first lanes)
+// while it multiplies the current one, and writes it into the ring behind the MFMAs; one barrier per row.  The outputs leave as
+// one dword per lane (16 lanes = 64 contiguous bytes of a channel row).  W % 16 == 0.
+// An affine map behind the conv (the ActNorm that follows the unit in the model: layers/actnorm.py:39-46) folds in as everywhere:
+// the scale in the fragments' rows, the shift added to the finished pixel.
+// -----------------------------------------------------------------------------------------------
+template <int CQP, int KH, int KW, int NWV>
+__global__ __launch_bounds__(64 * NWV) void finc_bigfwd_kernel(const float *__restrict__ in, const float *__restrict__ packed,
+                                                                const float *__restrict__ shift, float *__restrict__ out, int G,
+                                                                int CQ, int H, int W, int NS, unsigned orient)
+{
+    using C = BCfg<CQP, KH, KW, NWV>;
+    constexpr int NK = C::NK, NB = C::NB, NITEM = C::NITEM, BS = C::BS, NBAT = C::NBAT;
+    constexpr int COLS = 20, KSTEP_B = COLS * 16, SLOT_B = NK * KSTEP_B, NSLOT = 4;   // bytes
+    static_assert(KH <= NSLOT - 1 && KW - 1 <= 4, "the ring holds the rows of a filter plus the one being fetched; the halo is one piece");
+    static_assert(4 * NB * 5 <= 64, "one dwordx4 per lane fetches a wave's share of a row");
+    __shared__ __attribute__((aligned(16))) float lds[NSLOT * SLOT_B / 4];
+    char *const ldsb = reinterpret_cast<char *>(lds);
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int lane = threadIdx.x & 63;
+    const int q = lane >> 4, p = lane & 15;
+    const int strip = blockIdx.x % NS, bg = blockIdx.x / NS, g = bg % G;
+    const unsigned o = finc_group_orient(orient, g);
+    const bool fh = (o & FINC_FLIP_H) != 0, fw = (o & FINC_FLIP_W) != 0;
+    const int HW = H * W;
+    const unsigned slab_bytes = (unsigned)CQ * (unsigned)HW * 4u;
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)(in + (size_t)bg * CQ * HW), 0, (int)slab_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void *)(out + (size_t)bg * CQ * HW), 0, (int)slab_bytes, 0x00020000);
+    for (int i = threadIdx.x; i < NSLOT * SLOT_B / 4; i += 64 * NWV) lds[i] = 0.f;
+
+    float fr[C::NREG];
+    {
+        const float *pk = packed + ((size_t)(g * NWV + wv) * C::NREG) * 64 + lane;
+#pragma unroll
+        for (int r = 0; r < C::NREG; ++r) fr[r] = pk[r * 64];
+#pragma unroll
+        for (int r = 0; r < C::NREG; ++r) {
+            if (r < 128) asm volatile("" : "+a"(fr[r]));
+            else asm volatile("" : "+v"(fr[r]));
+        }
+    }
+    auto mma = [&](v4f &acc, int f, float b) { finc_mma_small(acc, fr[f >> 2], b, f & 3); };
+    // the finished pixel of block sb: channel MO*w + 4sb + q in lane row q
+    float sh[NB];
+    unsigned ochan[NB];
+#pragma unroll
+    for (int sb = 0; sb < NB; ++sb) {
+        const int ch = C::MO * wv + 4 * sb + q;
+        sh[sb] = (shift && ch < CQ) ? shift[g * CQ + ch] : 0.f;
+        ochan[sb] = ch < CQ ? (unsigned)(ch * HW * 4) : OFF_BAD_CHANNEL;
+    }
+    // ---- the fetch of one row: lane l < 20*NB takes piece l % 5 (canonical columns 16*strip - 4 + 4*piece ..) of channel row
+    // l / 5 of this wave's 4*NB input channels
+    const int fpiece = lane % 5, frow = lane / 5;                           // frow = 4 * (k-step of the wave) + k-slot
+    const bool fetcher = lane < 20 * NB;
+    const int fch = 4 * NB * wv + frow;                                    // input channel: k-step NB*wv + frow/4, k-slot frow%4
+    const int fcol = 16 * strip - 4 + 4 * fpiece;                          // first canonical column of the piece
+    const bool fok = fetcher && fch < CQ && fcol >= 0;
+    const unsigned fbase = fok ? (unsigned)(fch * HW * 4 + (fw ? W - 4 - fcol : fcol) * 4) : OFF_INVALID;
+    const int fdst = ((NB * wv + frow / 4) * COLS + 4 * fpiece) * 16 + (frow % 4) * 4;    // [k-step][column][k-slot] of the piece's first column
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    auto fetch = [&](int h) {
+        const bool ok = h < H;
+        const unsigned off = ok ? fbase + (unsigned)((fh ? H - 1 - h : h) * W * 4) : OFF_INVALID;
+        return __builtin_amdgcn_raw_buffer_load_b128(rin, fok ? off : OFF_INVALID, 0, 0);
+    };
+    auto land = [&](const v4u &v, int h) {
+        if (fetcher) {
+            char *d = ldsb + (h & (NSLOT - 1)) * SLOT_B + fdst;
+            const unsigned e0 = fw ? v.w : v.x, e1 = fw ? v.z : v.y, e2 = fw ? v.y : v.z, e3 = fw ? v.x : v.w;
+            *reinterpret_cast<unsigned *>(d + 0) = e0;
+            *reinterpret_cast<unsigned *>(d + 16) = e1;
+            *reinterpret_cast<unsigned *>(d + 32) = e2;
+            *reinterpret_cast<unsigned *>(d + 48) = e3;
+        }
+    };
+    __syncthreads();
+    land(fetch(0), 0);
+    __syncthreads();
+    const int rd = ((p + 4) * 4 + q) * 4;                                  // this lane's operand of tap (a, 0): column p, k-slot q
+    const unsigned ocol = (unsigned)((fw ? W - 1 - (16 * strip + p) : 16 * strip + p) * 4);
+    for (int h = 0; h < H; ++h) {
+        const v4u nxt = fetch(h + 1);
+        v4f acc[NB];
+#pragma unroll
+        for (int sb = 0; sb < NB; ++sb) acc[sb] = (v4f){0.f, 0.f, 0.f, 0.f};
+        float v[2][BS];
+        auto read_b = [&](auto i_c, auto h_c, float (&dst)[BS]) {
+            constexpr int item = decltype(i_c)::value, HH = decltype(h_c)::value;
+            constexpr int a = item / KW, b = item % KW;
+            // row h - a: above the image the ring still holds zeros only for h < a at the start -- mask by address: slot of a
+            // row that does not exist reads the zeroed slot NSLOT-1 of the prologue?  No: rows -1, -2 map to slots 3, 2, which the
+            // zero fill left untouched until rows 3, 2 land -- and those land after rows 1, 0 are done with them.
+            const int base = ((h - a) & (NSLOT - 1)) * SLOT_B + rd - b * 16 + HH * BS * KSTEP_B;
+#pragma unroll
+            for (int j = 0; j < BS; ++j) dst[j] = *reinterpret_cast<const float *>(ldsb + base + j * KSTEP_B);
+        };
+        auto mma_b = [&](auto i_c, auto h_c, const float (&src)[BS]) {
+            constexpr int item = decltype(i_c)::value, HH = decltype(h_c)::value;
+#pragma unroll
+            for (int j = 0; j < BS; ++j)
+#pragma unroll
+                for (int sb = 0; sb < NB; ++sb) mma(acc[sb], (item * NK + HH * BS + j) * NB + sb, src[j]);
+        };
+        read_b(IC<0>{}, IC<0>{}, v[0]);
+        [&]<int... S>(std::integer_sequence<int, S...>) {
+            (([&] {
+                 constexpr int I = S / NBAT, HH = S % NBAT;
+                 if constexpr (S + 1 < NBAT * NITEM) read_b(IC<(S + 1) / NBAT>{}, IC<(S + 1) % NBAT>{}, v[(S + 1) & 1]);
+                 FINC_SB();
+                 mma_b(IC<I>{}, IC<HH>{}, v[S & 1]);
+                 FINC_SB();
+             }()), ...);
+        }(std::make_integer_sequence<int, NBAT * NITEM>{});
+        const unsigned orow = (unsigned)((fh ? H - 1 - h : h) * W * 4) + ocol;
+#pragma unroll
+        for (int sb = 0; sb < NB; ++sb) {
+            const float zq = finc_block_reduce(acc[sb]) + sh[sb];
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, zq), rout, orow + ochan[sb], 0, 0);
+        }
+        land(nxt, h + 1);
+        __syncthreads();
+    }
+}
+
+// forward bank of a wave: fragment f = (item*NK + j)*NB + sb, value (row i, k-slot q) = scale[row] * Wc[row][4j+q][KH-1-a][KW-1-b]
+// (transpose: Wc[4j+q][row], the grad-input's bank), row = MO*w + 4sb + i; four block fragments to a register
+__global__ void bigfwd_pack_kernel(const float *__restrict__ wc, const float *__restrict__ scale, float *__restrict__ packed,
+                                   int Cq, int KH, int KW, int NWV, int NK, int NB, int NREG, int transpose)
+{
+    const int g = blockIdx.y;
+    const float *wg = wc + (size_t)g * Cq * Cq * KH * KW;
+    const int KK = KH * KW, MO = 4 * NB;
+    const int total = NWV * NREG * 64;
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+        const int lane = e & 63, r = (e >> 6) % NREG, w = e / (64 * NREG);
+        const int q = lane >> 4, a4 = (lane & 15) >> 2, i = lane & 3;
+        const int f = 4 * r + a4;
+        float v = 0.f;
+        if (f < KK * NK * NB) {
+            const int sb = f % NB, j = (f / NB) % NK, item = f / (NB * NK);
+            const int row = MO * w + 4 * sb + i, col = 4 * j + q;
+            if (row < Cq && col < Cq) {
+                const int a = item / KW, b = item % KW;
+                const int oc = transpose ? col : row, ic = transpose ? row : col;
+                v = wg[((size_t)oc * Cq + ic) * KK + (KH - 1 - a) * KW + (KW - 1 - b)];
+                if (scale) v *= scale[g * Cq + row];
+            }
+        }
+        packed[((size_t)(g * NWV + w) * NREG + r) * 64 + lane] = v;
+    }
+}
+
 typedef void (*big_fn)(const float *, const float *, float *, int, int, int, int, int, unsigned, int);
+typedef void (*bigfwd_fn)(const float *, const float *, const float *, float *, int, int, int, int, int, unsigned);
 struct BInst {
     int cqp, kh, kw, nwv, nk, nb, nreg, lds_bytes;
     big_fn fn;
+    bigfwd_fn fwd;
 };
 template <int CQP, int KH, int KW, int NWV>
 constexpr BInst make_binst()
 {
     using C = BCfg<CQP, KH, KW, NWV>;
-    return BInst{CQP, KH, KW, NWV, C::NK, C::NB, C::NREG, C::LDS_BYTES, finc_big_kernel<CQP, KH, KW, NWV>};
+    return BInst{CQP, KH, KW, NWV, C::NK, C::NB, C::NREG, C::LDS_BYTES, finc_big_kernel<CQP, KH, KW, NWV>, finc_bigfwd_kernel<CQP, KH, KW, NWV>};
 }
 const BInst g_binsts[] = {make_binst<96, 3, 3, 8>()};
 
@@ -420,6 +583,50 @@ int finc_big_launch(const float *in, const void *packed, float *out, const FincS
     if (int e = finc_ensure_dynamic_lds((const void *)i->fn, lds)) return e;
     hipLaunchKernelGGL(i->fn, dim3(s.B * s.G), dim3(64 * i->nwv), lds, st, in, (const float *)packed, out, s.G, s.Cq, s.H, s.W, Tr,
                        s.orient, big_fifo_depth(s.W, s.KH, s.KW));
+    FINC_CHECK_LAUNCH();
+    return FINC_OK;
+}
+
+// ---- forward / grad-input of the big banks: the bank sits behind the strip kernel's in the packed buffer (finc_conv.hip), with
+// the G*Cq shifts of a folded affine map behind it
+size_t finc_bigfwd_packed_bytes(int G, int Cq, int KH, int KW)
+{
+    const BInst *i = find_binst(Cq, KH, KW);
+    return i ? ((size_t)G * i->nwv * i->nreg * 64 + (size_t)G * Cq) * sizeof(float) : 0;
+}
+
+bool finc_bigfwd_takes(const float *in, const float *out, const FincShape &s)
+{
+    static const bool off = getenv("FINC_NO_BIGFWD") != nullptr;           // A/B switch: the 8-wave K-split row of the strip kernel
+    const BInst *i = find_binst(s.Cq, s.KH, s.KW);
+    if (!i || off || s.W % 16 != 0 || s.H < 1) return false;
+    if (((uintptr_t)in | (uintptr_t)out) & 15u) return false;
+    return (size_t)s.Cq * s.H * s.W * 4 < ((size_t)1 << 30);
+}
+
+int finc_bigfwd_pack(const float *wc, void *packed, int G, int Cq, int KH, int KW, bool transpose, hipStream_t st, const float *scale,
+                     const float *shift)
+{
+    const BInst *i = find_binst(Cq, KH, KW);
+    if (!i) return FINC_ERR_UNSUPPORTED;
+    const int total = i->nwv * i->nreg * 64;
+    hipLaunchKernelGGL(bigfwd_pack_kernel, dim3((total + 255) / 256, G), dim3(256), 0, st, wc, scale, (float *)packed, Cq, KH, KW, i->nwv,
+                       i->nk, i->nb, i->nreg, transpose ? 1 : 0);
+    FINC_CHECK_LAUNCH();
+    float *sh = (float *)packed + (size_t)G * i->nwv * i->nreg * 64;
+    if (shift) FINC_HIP_TRY(hipMemcpyAsync(sh, shift, sizeof(float) * (size_t)G * Cq, hipMemcpyDeviceToDevice, st));
+    else FINC_HIP_TRY(hipMemsetAsync(sh, 0, sizeof(float) * (size_t)G * Cq, st));
+    return FINC_OK;
+}
+
+int finc_bigfwd_launch(const float *in, const void *packed, float *out, const FincShape &s, hipStream_t st)
+{
+    const BInst *i = find_binst(s.Cq, s.KH, s.KW);
+    if (!i || !finc_bigfwd_takes(in, out, s)) return FINC_ERR_UNSUPPORTED;
+    const int NS = s.W / 16;
+    const float *sh = (const float *)packed + (size_t)s.G * i->nwv * i->nreg * 64;
+    hipLaunchKernelGGL(i->fwd, dim3(s.B * s.G * NS), dim3(64 * i->nwv), 0, st, in, (const float *)packed, sh, out, s.G, s.Cq, s.H, s.W,
+                       NS, s.orient);
     FINC_CHECK_LAUNCH();
     return FINC_OK;
 }

@@ -95,6 +95,11 @@ size_t finc_big_packed_bytes(int G, int Cq, int KH, int KW);
 int finc_big_pack(const float *wc, const float *scale, const float *shift, void *packed, int G, int Cq, int KH, int KW, hipStream_t st);
 int finc_big_info(const FincShape &s, int *waves, int *lds_bytes, int *cqp);
 int finc_big_launch(const float *in, const void *packed, float *out, const FincShape &s, hipStream_t st);
+size_t finc_bigfwd_packed_bytes(int G, int Cq, int KH, int KW);         // 0: no big-bank forward for this bank
+bool finc_bigfwd_takes(const float *in, const float *out, const FincShape &s);
+int finc_bigfwd_pack(const float *wc, void *packed, int G, int Cq, int KH, int KW, bool transpose, hipStream_t st, const float *scale,
+                     const float *shift);
+int finc_bigfwd_launch(const float *in, const void *packed, float *out, const FincShape &s, hipStream_t st);
 unsigned finc_build_flags_big();
 bool finc_split_takes(const FincShape &s);       // this problem set runs on the role-split kernel
 int finc_split_info(const FincShape &s, int *waves, int *lds_bytes, int *steps);

@@ -510,6 +510,8 @@ def test_big_banks_run_on_mfma(case, dev):
     assert L.finc_inverse_algo_for(Cq, H, W, 3, 3) == _lib.ALGO["mfma"] and L.finc_forward_algo_for(Cq, H, W, 3, 3) == _lib.ALGO["mfma"]
     v = _lib.inverse_variant(B, G, Cq, H, W, 3, 3)
     assert v["sec"] == 5 and v["nw"] == 8 and v["cqp"] == 96 and v["workgroups"] == B * G, v
+    # forward: the M-split of finc_big.hip on whole 16-column strips, the 8-wave K-split row of the strip kernel otherwise
+    assert _lib.backward_variant(B, G, Cq, H, W, 3, 3)["conv_form"] == ("msplit" if W % 16 == 0 else "strip")
     ws = oracle.make_stored_weights(G, Cq, 3, 3, orient=ori, seed=Cq + H, std=0.05 * (24.0 / Cq) ** 0.5)
     wco = oracle.canonicalize(ws, G, ori)
     x = np.random.default_rng(H * W).standard_normal((B, G * Cq, H, W)).astype(np.float32)
@@ -524,6 +526,18 @@ def test_big_banks_run_on_mfma(case, dev):
     assert e <= max(TOL, 2.0 * rel_err(ref32, ref)), e
     strict = ops.finc_inverse(t(z, dev), wc, G, ori, algo="strict").cpu().numpy()
     assert np.array_equal(strict, ref32)
+    # the affine map behind the conv (ActNorm.forward folded into the forward bank): scale in the fragments, shift on the pixel
+    C = G * Cq
+    scale = torch.exp(0.3 * torch.randn(C, device=dev)).contiguous()
+    shift = torch.randn(C, device=dev).contiguous()
+    packed = torch.empty(L.finc_workspace_bytes(G, Cq, 3, 3), dtype=torch.uint8, device=dev)
+    _lib.check(L.finc_pack_forward_weights_affine_f32(wc.data_ptr(), scale.data_ptr(), shift.data_ptr(), packed.data_ptr(), G, Cq, 3, 3,
+                                                      None), "pack")
+    xo, zo = t(x, dev), torch.empty(x.shape, dtype=torch.float32, device=dev)
+    _lib.check(L.finc_forward_packed_f32(xo.data_ptr(), packed.data_ptr(), zo.data_ptr(), B, G, Cq, H, W, 3, 3, ori, None), "fwd")
+    torch.cuda.synchronize()
+    want = z * scale.cpu().numpy().reshape(1, C, 1, 1) + shift.cpu().numpy().reshape(1, C, 1, 1)
+    assert rel_err(zo.cpu().numpy(), want) <= TOL
     # a map the big-bank kernel does not take (wider than 64 / narrower than 16): the strict kernel, same answer
     for Wx in (12, 68):
         assert L.finc_inverse_algo_for(Cq, 4, Wx, 3, 3) == _lib.ALGO["strict"]
