@@ -365,7 +365,7 @@ __global__ __launch_bounds__(64 * NWV) void finc_bigfwd_kernel(const float *__re
     constexpr int NK = C::NK, NB = C::NB, NITEM = C::NITEM, BS = C::BS, NBAT = C::NBAT;
     constexpr int COLS = 20, KSTEP_B = COLS * 16, SLOT_B = NK * KSTEP_B, NSLOT = 4;   // bytes
     static_assert(KH <= NSLOT - 1 && KW - 1 <= 4, "the ring holds the rows of a filter plus the one being fetched; the halo is one piece");
-    static_assert(4 * NB * 5 <= 64, "one dwordx4 per lane fetches a wave's share of a row");
+    constexpr int NF = (20 * NB + 63) / 64;    // dwordx4 loads per lane that fetch a wave's share of a row (20 * NB pieces)
     __shared__ __attribute__((aligned(16))) float lds[NSLOT * SLOT_B / 4];
     char *const ldsb = reinterpret_cast<char *>(lds);
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -403,27 +403,43 @@ __global__ __launch_bounds__(64 * NWV) void finc_bigfwd_kernel(const float *__re
     }
     // ---- the fetch of one row: lane l < 20*NB takes piece l % 5 (canonical columns 16*strip - 4 + 4*piece ..) of channel row
     // l / 5 of this wave's 4*NB input channels
-    const int fpiece = lane % 5, frow = lane / 5;                           // frow = 4 * (k-step of the wave) + k-slot
-    const bool fetcher = lane < 20 * NB;
-    const int fch = 4 * NB * wv + frow;                                    // input channel: k-step NB*wv + frow/4, k-slot frow%4
-    const int fcol = 16 * strip - 4 + 4 * fpiece;                          // first canonical column of the piece
-    const bool fok = fetcher && fch < CQ && fcol >= 0;
-    const unsigned fbase = fok ? (unsigned)(fch * HW * 4 + (fw ? W - 4 - fcol : fcol) * 4) : OFF_INVALID;
-    const int fdst = ((NB * wv + frow / 4) * COLS + 4 * fpiece) * 16 + (frow % 4) * 4;    // [k-step][column][k-slot] of the piece's first column
     typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    struct Row { v4u v[NF]; };
+    bool fetcher[NF];
+    unsigned fbase[NF];
+    int fdst[NF];
+#pragma unroll
+    for (int r = 0; r < NF; ++r) {
+        const int idx = lane + 64 * r;
+        const int fpiece = idx % 5, frow = idx / 5;                        // frow = 4 * (k-step of the wave) + k-slot
+        fetcher[r] = idx < 20 * NB;
+        const int fch = 4 * NB * wv + frow;                                // input channel: k-step NB*wv + frow/4, k-slot frow%4
+        const int fcol = 16 * strip - 4 + 4 * fpiece;                      // first canonical column of the piece
+        const bool fok = fetcher[r] && fch < CQ && fcol >= 0;
+        fbase[r] = fok ? (unsigned)(fch * HW * 4 + (fw ? W - 4 - fcol : fcol) * 4) : OFF_INVALID;
+        fdst[r] = ((NB * wv + frow / 4) * COLS + 4 * fpiece) * 16 + (frow % 4) * 4;   // [k-step][column][k-slot] of the piece's first column
+    }
     auto fetch = [&](int h) {
-        const bool ok = h < H;
-        const unsigned off = ok ? fbase + (unsigned)((fh ? H - 1 - h : h) * W * 4) : OFF_INVALID;
-        return __builtin_amdgcn_raw_buffer_load_b128(rin, fok ? off : OFF_INVALID, 0, 0);
+        Row row;
+#pragma unroll
+        for (int r = 0; r < NF; ++r) {
+            const unsigned off = (h < H && fbase[r] != OFF_INVALID) ? fbase[r] + (unsigned)((fh ? H - 1 - h : h) * W * 4) : OFF_INVALID;
+            row.v[r] = __builtin_amdgcn_raw_buffer_load_b128(rin, off, 0, 0);
+        }
+        return row;
     };
-    auto land = [&](const v4u &v, int h) {
-        if (fetcher) {
-            char *d = ldsb + (h & (NSLOT - 1)) * SLOT_B + fdst;
-            const unsigned e0 = fw ? v.w : v.x, e1 = fw ? v.z : v.y, e2 = fw ? v.y : v.z, e3 = fw ? v.x : v.w;
-            *reinterpret_cast<unsigned *>(d + 0) = e0;
-            *reinterpret_cast<unsigned *>(d + 16) = e1;
-            *reinterpret_cast<unsigned *>(d + 32) = e2;
-            *reinterpret_cast<unsigned *>(d + 48) = e3;
+    auto land = [&](const Row &row, int h) {
+#pragma unroll
+        for (int r = 0; r < NF; ++r) {
+            if (fetcher[r]) {
+                char *d = ldsb + (h & (NSLOT - 1)) * SLOT_B + fdst[r];
+                const v4u v = row.v[r];
+                const unsigned e0 = fw ? v.w : v.x, e1 = fw ? v.z : v.y, e2 = fw ? v.y : v.z, e3 = fw ? v.x : v.w;
+                *reinterpret_cast<unsigned *>(d + 0) = e0;
+                *reinterpret_cast<unsigned *>(d + 16) = e1;
+                *reinterpret_cast<unsigned *>(d + 32) = e2;
+                *reinterpret_cast<unsigned *>(d + 48) = e3;
+            }
         }
     };
     __syncthreads();
@@ -432,7 +448,7 @@ __global__ __launch_bounds__(64 * NWV) void finc_bigfwd_kernel(const float *__re
     const int rd = ((p + 4) * 4 + q) * 4;                                  // this lane's operand of tap (a, 0): column p, k-slot q
     const unsigned ocol = (unsigned)((fw ? W - 1 - (16 * strip + p) : 16 * strip + p) * 4);
     for (int h = 0; h < H; ++h) {
-        const v4u nxt = fetch(h + 1);
+        const Row nxt = fetch(h + 1);
         v4f acc[NB];
 #pragma unroll
         for (int sb = 0; sb < NB; ++sb) acc[sb] = (v4f){0.f, 0.f, 0.f, 0.f};
@@ -508,16 +524,36 @@ typedef void (*bigfwd_fn)(const float *, const float *, const float *, float *, 
 struct BInst {
     int cqp, kh, kw, nwv, nk, nb, nreg, lds_bytes;
     big_fn fn;
-    bigfwd_fn fwd;
 };
 template <int CQP, int KH, int KW, int NWV>
 constexpr BInst make_binst()
 {
     using C = BCfg<CQP, KH, KW, NWV>;
-    return BInst{CQP, KH, KW, NWV, C::NK, C::NB, C::NREG, C::LDS_BYTES, finc_big_kernel<CQP, KH, KW, NWV>, finc_bigfwd_kernel<CQP, KH, KW, NWV>};
+    return BInst{CQP, KH, KW, NWV, C::NK, C::NB, C::NREG, C::LDS_BYTES, finc_big_kernel<CQP, KH, KW, NWV>};
 }
 const BInst g_binsts[] = {make_binst<96, 3, 3, 8>()};
 
+// the forward's own table: (cq_lo, cqp] = the channel counts a row serves
+struct BFInst {
+    int cqp, kh, kw, nwv, nk, nb, nreg, cq_lo;
+    bigfwd_fn fn;
+};
+template <int CQP, int KH, int KW, int NWV, int CQLO>
+constexpr BFInst make_bfinst()
+{
+    using C = BCfg<CQP, KH, KW, NWV>;
+    return BFInst{CQP, KH, KW, NWV, C::NK, C::NB, C::NREG, CQLO, finc_bigfwd_kernel<CQP, KH, KW, NWV>};
+}
+// (The same kernel on the mid-size banks -- <64,3,3> and <48,3,3> as 4 waves -- was measured against the strip kernel's K-split
+// rows: 104 against 99 TFLOP/s at Cq = 64, 108 against 112 at Cq = 48, 77 against 96 at Cq = 40 on the 48-channel bank: no case
+// for a second path there.  profiles/r03/notes/msplit_forward_on_mid_banks.txt)
+const BFInst g_bfinsts[] = {make_bfinst<96, 3, 3, 8, 64>()};
+const BFInst *find_bfinst(int Cq, int KH, int KW)
+{
+    for (const BFInst &i : g_bfinsts)
+        if (i.kh == KH && i.kw == KW && Cq > i.cq_lo && Cq <= i.cqp) return &i;
+    return nullptr;
+}
 // the big banks start where the wavefront kernel's table ends (finc_mfma.hip: 64 channels at 3x3).  (The same kernel on the
 // SMALL banks -- <24,3,3> as 6 waves, <12,3,3> as 3 -- was measured against the role-split kernel for the under-filled chip:
 // 0.93 against 0.60 us per step at c3, 0.59 against 0.47 at c2: a step is then its fixed costs, not its MFMAs.
@@ -591,14 +627,14 @@ int finc_big_launch(const float *in, const void *packed, float *out, const FincS
 // the G*Cq shifts of a folded affine map behind it
 size_t finc_bigfwd_packed_bytes(int G, int Cq, int KH, int KW)
 {
-    const BInst *i = find_binst(Cq, KH, KW);
+    const BFInst *i = find_bfinst(Cq, KH, KW);
     return i ? ((size_t)G * i->nwv * i->nreg * 64 + (size_t)G * Cq) * sizeof(float) : 0;
 }
 
 bool finc_bigfwd_takes(const float *in, const float *out, const FincShape &s)
 {
     static const bool off = getenv("FINC_NO_BIGFWD") != nullptr;           // A/B switch: the 8-wave K-split row of the strip kernel
-    const BInst *i = find_binst(s.Cq, s.KH, s.KW);
+    const BFInst *i = find_bfinst(s.Cq, s.KH, s.KW);
     if (!i || off || s.W % 16 != 0 || s.H < 1) return false;
     if (((uintptr_t)in | (uintptr_t)out) & 15u) return false;
     return (size_t)s.Cq * s.H * s.W * 4 < ((size_t)1 << 30);
@@ -607,7 +643,7 @@ bool finc_bigfwd_takes(const float *in, const float *out, const FincShape &s)
 int finc_bigfwd_pack(const float *wc, void *packed, int G, int Cq, int KH, int KW, bool transpose, hipStream_t st, const float *scale,
                      const float *shift)
 {
-    const BInst *i = find_binst(Cq, KH, KW);
+    const BFInst *i = find_bfinst(Cq, KH, KW);
     if (!i) return FINC_ERR_UNSUPPORTED;
     const int total = i->nwv * i->nreg * 64;
     hipLaunchKernelGGL(bigfwd_pack_kernel, dim3((total + 255) / 256, G), dim3(256), 0, st, wc, scale, (float *)packed, Cq, KH, KW, i->nwv,
@@ -621,11 +657,11 @@ int finc_bigfwd_pack(const float *wc, void *packed, int G, int Cq, int KH, int K
 
 int finc_bigfwd_launch(const float *in, const void *packed, float *out, const FincShape &s, hipStream_t st)
 {
-    const BInst *i = find_binst(s.Cq, s.KH, s.KW);
+    const BFInst *i = find_bfinst(s.Cq, s.KH, s.KW);
     if (!i || !finc_bigfwd_takes(in, out, s)) return FINC_ERR_UNSUPPORTED;
     const int NS = s.W / 16;
     const float *sh = (const float *)packed + (size_t)s.G * i->nwv * i->nreg * 64;
-    hipLaunchKernelGGL(i->fwd, dim3(s.B * s.G * NS), dim3(64 * i->nwv), 0, st, in, (const float *)packed, sh, out, s.G, s.Cq, s.H, s.W,
+    hipLaunchKernelGGL(i->fn, dim3(s.B * s.G * NS), dim3(64 * i->nwv), 0, st, in, (const float *)packed, sh, out, s.G, s.Cq, s.H, s.W,
                        NS, s.orient);
     FINC_CHECK_LAUNCH();
     return FINC_OK;
