@@ -172,7 +172,8 @@ def split_problems(n):
 def fuzz_case(rng, case):
     K = int(rng.choice([2, 3, 3, 3, 5]))
     # (channel counts between the compiled banks -- 22, 36, 44, 50 at 3x3, 20 at 5x5 -- run on the next larger bank)
-    cq_opts = [1, 2, 3, 4, 6, 8, 12, 16, 20, 22, 24, 28, 32, 36, 40, 44, 48, 50, 64] if K == 3 else \
+    # (72, 96: the big banks of finc_big.hip)
+    cq_opts = [1, 2, 3, 4, 6, 8, 12, 16, 20, 22, 24, 28, 32, 36, 40, 44, 48, 50, 64, 72, 96] if K == 3 else \
         ([1, 3, 4, 8, 12, 13, 16, 24, 32] if K == 2 else [2, 4, 8, 12, 16, 20, 32, 48])
     Cq = int(rng.choice(cq_opts))
     G = int(rng.choice([1, 4, 4, 4]))
