@@ -43,12 +43,14 @@ using IC = std::integral_constant<int, I>;
 constexpr int XSLOTS = 8;        // x ring: the pixels of the last 8 steps (taps reach back KH + KW - 2 = 4, the stores 7)
 constexpr int RING_J = 2048;     // a k-step's x ring (8 slots x 64 lanes) ...
 constexpr int FIFO_J = 1704;     // ... and its FIFO block behind it: 53 slots x 32 bytes + the zero word (W <= 64)
-constexpr int JSTRIDE = RING_J + FIFO_J;   // bytes between the k-steps of BOTH: a lane's k-step stride is an immediate whichever it reads
+constexpr int ABOVE_J = 516;     // ... or, for wider maps, 16 slots of the rows above re-read from the OUTPUT + the zero word
 constexpr int ZJSTRIDE = 3072;   // bytes between the k-steps of the z ring (12 slots x 64 lanes)
 constexpr int UNROLL = 8;        // steps per iteration of the loop: two I/O windows
 
-template <int CQP, int KH, int KW, int NWV>
+template <int CQP, int KH, int KW, int NWV, bool HBMF = false>
 struct BCfg {
+    // bytes between the k-steps of the x ring AND of the block behind it: a lane's k-step stride is an immediate whichever it reads
+    static constexpr int JSTRIDE = RING_J + (HBMF ? ABOVE_J : FIFO_J);
     static constexpr int NK = CQP / 4;                    // k-steps of an operand (k-slot q <-> channel 4j+q)
     static constexpr int MO = CQP / NWV;                  // output channels of a wave
     static constexpr int NB = MO / 4;                     // ... as 4-row blocks = the k-steps of the solved pixel it writes
@@ -61,7 +63,8 @@ struct BCfg {
     static_assert(LDS_BYTES <= 160 * 1024, "one workgroup per CU");
     // operands are read in batches of BS k-steps, one batch ahead of their MFMAs; a DS immediate reaches 64 KB: a second base
     // register for the upper half of an operand that is longer
-    static constexpr int BS = NK % 6 == 0 ? 6 : NK % 4 == 0 ? 4 : NK;
+    // (HBMF: the stream of the rows above costs a few registers more than the FIFO's bookkeeping: smaller batches pay for them)
+    static constexpr int BS = HBMF && NK % 8 == 0 ? 4 : NK % 6 == 0 ? 6 : NK % 4 == 0 ? 4 : NK;
     static constexpr int NBAT = NK / BS;
     static_assert(NK % BS == 0 && BS <= 8, "batches tile the k-steps");
     static_assert(NK * ZJSTRIDE < 65536 || (NK % 2 == 0 && (NK / 2) % BS == 0 && (NK / 2) * JSTRIDE < 65536), "DS immediates reach half an operand");
@@ -81,15 +84,24 @@ struct BCfg {
 };
 
 // -----------------------------------------------------------------------------------------------
-// grid = B*G workgroups of NWV waves.  16 <= W <= 64, W % 4 == 0 (16-byte pieces); P = 16; DF slots of the FIFO.
+// grid = B*G workgroups of NWV waves.  W % 4 == 0 (16-byte pieces); P = 16.
+//   HBMF = false: 16 <= W <= 64; the last KH-1 rows of a band wait for the band below in the FIFO (DF slots).
+//   HBMF = true ("hand-over through memory"): W >= 48, any width.  Two rows of a 256-wide map are 96 KB at 48 channels -- no
+//          FIFO in LDS holds that -- but they are in the OUTPUT: the band below re-reads them from there, where this very
+//          workgroup stored them W - P steps (hundreds of microseconds) earlier.  Each wave fetches, for its own k-steps, the
+//          16-byte pieces of those two rows that lane 0 reaches two windows later (lanes (q, r): k-slot q, row P-2+r) -- with
+//          sc0 sc1, past the vector cache: a cached line would also hold columns that are not stored yet -- and lands them in a
+//          ring of 16 positions where the FIFO block used to be, indexed by lane 0's position (= its step): tap (a,b) of a
+//          lane p < a reads position u - p - b.  The pieces ride in the registers of the z pieces, alternating with them: z is
+//          requested at step 0 of a window and lands at step 2, the rows above are requested at step 2 and land at step 0.
 // -----------------------------------------------------------------------------------------------
-template <int CQP, int KH, int KW, int NWV>
+template <int CQP, int KH, int KW, int NWV, bool HBMF>
 __global__ __launch_bounds__(64 * NWV) void finc_big_kernel(const float *__restrict__ in, const float *__restrict__ packed,
                                                              float *__restrict__ out, int G, int CQ, int H, int W, int T,
                                                              unsigned orient, int DF)
 {
-    using C = BCfg<CQP, KH, KW, NWV>;
-    constexpr int NK = C::NK, NB = C::NB, NJ = C::NB, JS = C::JS, P = 16;
+    using C = BCfg<CQP, KH, KW, NWV, HBMF>;
+    constexpr int NK = C::NK, NB = C::NB, NJ = C::NB, JS = C::JS, P = 16, JSTRIDE = C::JSTRIDE;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     char *const ldsb = reinterpret_cast<char *>(lds);
     const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -132,9 +144,27 @@ __global__ __launch_bounds__(64 * NWV) void finc_big_kernel(const float *__restr
     // w+f and w+f+1, f = floor(-p/4); it LANDS group w+f+2, requested ONE window earlier, and requests group w+f+3.  Stores: in
     // window w the group w+fs, fs = floor((-3-p)/4), is collected from the x ring's time slots and leaves as one piece.
     const int JLO = NJ * wv;
-    unsigned cmask[NJ];                        // (channel 4(JLO+j)+q: the natural order serves loads and stores alike)
+    // channel 4(JLO+j)+q: the natural order serves loads and stores alike.  (HBMF: recomputed at every use -- three times per
+    // window -- instead of kept: the variant is three registers short, and a spill is not an option beside hand-counted loads)
+    unsigned cmask_k[HBMF ? 1 : NJ];
+    if constexpr (!HBMF) {
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) cmask[j] = (4 * (JLO + j) + q) < CQ ? (unsigned)((4 * (JLO + j) + q) * HW * 4) : OFF_BAD_CHANNEL;
+        for (int j = 0; j < NJ; ++j) cmask_k[j] = (4 * (JLO + j) + q) < CQ ? (unsigned)((4 * (JLO + j) + q) * HW * 4) : OFF_BAD_CHANNEL;
+    }
+    struct CMask { unsigned v[NJ]; };
+    auto cmask_now = [&]() {
+        CMask c;
+        if constexpr (HBMF) {
+            int l = lane;
+            asm volatile("" : "+v"(l));        // (opaque: keeps the computation here instead of hoisted out of the loop)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) c.v[j] = (4 * (JLO + j) + (l >> 4)) < CQ ? (unsigned)((4 * (JLO + j) + (l >> 4)) * HW * 4) : OFF_BAD_CHANNEL;
+        } else {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) c.v[j] = cmask_k[j];
+        }
+        return c;
+    };
     const int f4 = -((p + 3) >> 2), fs4 = -((p + 3 + 3) >> 2);             // floor(-p / 4), floor((-3 - p) / 4)
     const int dgrp = fw ? -16 : 16;                                        // bytes from a group to the next one of the row
     const int drow = (fh ? -P : P) * W * 4 - (dgrp / 4) * W;               // ... and from the end of a row to the start of row + P
@@ -145,9 +175,10 @@ __global__ __launch_bounds__(64 * NWV) void finc_big_kernel(const float *__restr
     auto zreq = [&](v4f (&dst)[NJ]) {
         const bool ok = lcol >= 0 && lrow < H;
         const unsigned base = ok ? (unsigned)loff : OFF_INVALID;
+        const CMask cmask = cmask_now();
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
-            asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(dst[j]) : "v"(base + cmask[j]), "s"(rin) : "memory");
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(dst[j]) : "v"(base + cmask.v[j]), "s"(rin) : "memory");
         lcol += 4; loff += dgrp;
         if (lcol == W) { lcol = 0; lrow += P; loff += drow; }
     };
@@ -171,12 +202,14 @@ __global__ __launch_bounds__(64 * NWV) void finc_big_kernel(const float *__restr
     };
     // stores: element k of the group was solved at step 4gs + k + p: time slot ((p + k) & 7) ^ (4 * (gs & 1))
     const int xbase = C::RING_B + JLO * JSTRIDE;   // (not a multiple of 2 KB: the toggle below works on the slot part alone)
-    const int xs0 = (((p + e0) & 7) * 64 + lane) * 4, xs1 = (((p + e1) & 7) * 64 + lane) * 4;
-    const int xs2 = (((p + e2) & 7) * 64 + lane) * 4, xs3 = (((p + e3) & 7) * 64 + lane) * 4;
-    int stog = (fs4 & 1) * 1024;               // toggles with the group
+    // (the lane's share of the toggle -- the parity of its first group -- sits in the constants: what toggles is wave-uniform)
+    const int xs0 = ((((p + e0) & 7) * 64 + lane) * 4) ^ ((fs4 & 1) * 1024), xs1 = ((((p + e1) & 7) * 64 + lane) * 4) ^ ((fs4 & 1) * 1024);
+    const int xs2 = ((((p + e2) & 7) * 64 + lane) * 4) ^ ((fs4 & 1) * 1024), xs3 = ((((p + e3) & 7) * 64 + lane) * 4) ^ ((fs4 & 1) * 1024);
+    int stog = 0;                              // toggles with the group
     auto xstore = [&]() {
         const bool ok = scol >= 0 && srow < H;
         const unsigned base = ok ? (unsigned)soff : OFF_INVALID;
+        const CMask cmask = cmask_now();
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             v4f v;
@@ -186,17 +219,52 @@ __global__ __launch_bounds__(64 * NWV) void finc_big_kernel(const float *__restr
             v.w = ld(xbase + (xs3 ^ stog) + j * JSTRIDE);
             // (s_nop: a store of more than 8 bytes reads its data one wait state after issue, and the hazard recognizer does not
             // see inline asm)
-            asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" ::"v"(v), "v"(base + cmask[j]), "s"(rout) : "memory");
+            asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" ::"v"(v), "v"(base + cmask.v[j]), "s"(rout) : "memory");
         }
         stog ^= 1024;
         scol += 4; soff += dgrp;
         if (scol == W) { scol = 0; srow += P; soff += drow; }
     };
-    {   // prologue: groups f, f+1 land now (window 0 reads them), f+2 waits in flight
+    {   // prologue: groups f, f+1 land now (window 0 reads them); f+2 waits in flight (HBMF: is requested in window 0)
         v4f tmp0[NJ], tmp1[NJ];
-        zreq(tmp0); zreq(tmp1); zreq(zin);
-        zland(tmp0, IC<NJ>{}); zland(tmp1, IC<NJ>{});
+        zreq(tmp0); zreq(tmp1);
+        if constexpr (!HBMF) zreq(zin);
+        zland(tmp0, IC<HBMF ? 0 : NJ>{}); zland(tmp1, IC<HBMF ? 0 : NJ>{});
     }
+    // ---- HBMF: the rows above the band, re-read from the output.  Piece ww covers lane 0's positions 4ww .. 4ww+3 (band
+    // abnd = position / W, columns acol ..): requested in window ww - 2, landed in window ww - 1, read from window ww on.
+    int acol = 8 % W, abnd = 8 / W;            // (the first request, in window 0, is piece 2: positions 8 .. 11)
+    int aslot = 2;                             // ring group (piece & 3) of the next landing
+    auto areq = [&](v4f (&dst)[NJ]) {
+        const int row = P * abnd - (KH - 1) + p;                           // lanes p < KH-1: rows P-2, P-1 of the band above
+        const bool ok = abnd >= 1 && p < KH - 1 && row < H;
+        const unsigned base = ok ? (unsigned)piece_off(row, acol) : OFF_INVALID;
+        const CMask cmask = cmask_now();
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen sc0 sc1" : "=v"(dst[j]) : "v"(base + cmask.v[j]), "s"(rout) : "memory");
+        acol += 4;
+        if (acol >= W) { acol -= W; ++abnd; }
+    };
+    auto aland = [&](v4f (&src)[NJ]) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) asm volatile("" : "+v"(src[j]));
+        if (p < KH - 1) {
+            int l = lane;                      // (recomputed here, once per window: hoisted out of the loop the address costs a register
+            asm volatile("" : "+v"(l));        // the kernel does not have -- it would be spilled)
+            const int base = C::FIFO_B + JLO * JSTRIDE + ((l >> 4) * (KH - 1) + (l & 15)) * 4 + aslot * (4 * JS * 4);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const float v0 = src[j].x, v1 = src[j].y, v2 = src[j].z, v3 = src[j].w;
+                st(base + e0 * (JS * 4) + j * JSTRIDE, v0);
+                st(base + e1 * (JS * 4) + j * JSTRIDE, v1);
+                st(base + e2 * (JS * 4) + j * JSTRIDE, v2);
+                st(base + e3 * (JS * 4) + j * JSTRIDE, v3);
+            }
+        }
+        aslot = (aslot + 1) & 3;
+    };
     int zn = ((-p) % 12 + 12) % 12;            // z read slot: position n mod 12 of this lane
 
     // ---- operands of step u.  S_a(u-a-b): the x ring at lane p - a (lanes p >= a) / the FIFO (lanes p < a: the band above);
@@ -216,7 +284,7 @@ __global__ __launch_bounds__(64 * NWV) void finc_big_kernel(const float *__restr
         if (fs < 0) fs += DF;
         if (fs >= DF) fs -= DF;
         const int ring = C::RING_B + ((tau & (XSLOTS - 1)) * 64 + lane - a) * 4;
-        const int fifo = C::FIFO_B + (fs * JS + q * (KH - 1) + (KH - 1 - a + p)) * 4;
+        const int fifo = C::FIFO_B + ((HBMF ? ((u - p - b) & 15) : fs) * JS + q * (KH - 1) + (KH - 1 - a + p)) * 4;
         int addr = (a == 0 || p >= a) ? ring : fifo;
         if constexpr (b > 0) addr = cb >= b ? addr : JSTRIDE - 4;          // (the zero word: the end of the k-step's FIFO block)
         return addr;
@@ -230,12 +298,24 @@ __global__ __launch_bounds__(64 * NWV) void finc_big_kernel(const float *__restr
         constexpr int KU = decltype(k_c)::value;                            // u % UNROLL
         constexpr int PH = KU & 3;
         // ---- HBM side of the window
-        if constexpr (PH == 0) {
-            if (u == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (no stores yet behind the first request)
-            zland(zin, IC<NJ>{});              // younger than the loads that land: the stores of the window in between
-            zreq(zin);
+        if constexpr (!HBMF) {
+            if constexpr (PH == 0) {
+                if (u == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (no stores yet behind the first request)
+                zland(zin, IC<NJ>{});          // younger than the loads that land: the stores of the window in between
+                zreq(zin);
+            }
+            if constexpr (PH == 2) xstore();
+        } else {
+            if constexpr (PH == 0) {
+                if (u != 0) aland(zin);        // the rows above, requested two steps ago (everything older is complete)
+                zreq(zin);
+            }
+            if constexpr (PH == 2) {
+                zland(zin, IC<0>{});
+                xstore();
+                areq(zin);
+            }
         }
-        if constexpr (PH == 2) xstore();
         v4f acc[NB];
 #pragma unroll
         for (int sb = 0; sb < NB; ++sb) acc[sb] = (v4f){0.f, 0.f, 0.f, 0.f};
@@ -280,9 +360,11 @@ __global__ __launch_bounds__(64 * NWV) void finc_big_kernel(const float *__restr
         const int slot = u & (XSLOTS - 1);
 #pragma unroll
         for (int sb = 0; sb < NB; ++sb) st(ring_w + slot * 256 + sb * JSTRIDE, xq[sb]);
-        if (pusher) {
+        if constexpr (!HBMF) {
+            if (pusher) {
 #pragma unroll
-            for (int sb = 0; sb < NB; ++sb) st(push_w + fpush * (JS * 4) + sb * JSTRIDE, xq[sb]);
+                for (int sb = 0; sb < NB; ++sb) st(push_w + fpush * (JS * 4) + sb * JSTRIDE, xq[sb]);
+            }
         }
         ++cb; if (cb == W) cb = 0;
         ++fs2; if (fs2 == DF) fs2 = 0;
@@ -522,16 +604,23 @@ __global__ void bigfwd_pack_kernel(const float *__restrict__ wc, const float *__
 typedef void (*big_fn)(const float *, const float *, float *, int, int, int, int, int, unsigned, int);
 typedef void (*bigfwd_fn)(const float *, const float *, const float *, float *, int, int, int, int, int, unsigned);
 struct BInst {
-    int cqp, kh, kw, nwv, nk, nb, nreg, lds_bytes;
-    big_fn fn;
+    int cqp, cq_lo, kh, kw, nwv, nk, nb, nreg, lds_bytes, lds_bytes_wide;   // serves cq_lo < Cq <= cqp
+    big_fn fn;       // FIFO in LDS: 16 <= W <= 64
+    big_fn fn_wide;  // hand-over through memory: W >= 48
 };
-template <int CQP, int KH, int KW, int NWV>
+template <int CQP, int KH, int KW, int NWV, int CQLO, bool NARROW = true>
 constexpr BInst make_binst()
 {
-    using C = BCfg<CQP, KH, KW, NWV>;
-    return BInst{CQP, KH, KW, NWV, C::NK, C::NB, C::NREG, C::LDS_BYTES, finc_big_kernel<CQP, KH, KW, NWV>};
+    using C = BCfg<CQP, KH, KW, NWV, false>;
+    using CW = BCfg<CQP, KH, KW, NWV, true>;
+    big_fn narrow = nullptr;
+    if constexpr (NARROW) narrow = finc_big_kernel<CQP, KH, KW, NWV, false>;
+    return BInst{CQP, CQLO, KH, KW, NWV, C::NK, C::NB, C::NREG, C::LDS_BYTES, CW::LDS_BYTES, narrow, finc_big_kernel<CQP, KH, KW, NWV, true>};
 }
-const BInst g_binsts[] = {make_binst<96, 3, 3, 8>()};
+// <96>: the banks beyond the wavefront kernel's table, any width.  <64>: the banks of 33 .. 64 channels on maps too WIDE for
+// the wavefront kernel's K-split forms (their FIFOs: from about 130 columns at 64 channels, 250 at 48 -- the reference's
+// shape sweep has a 50-channel 256 x 256 layer, fastflow/test_examples.py:218-222), hand-over through memory only.
+const BInst g_binsts[] = {make_binst<96, 3, 3, 8, 64>(), make_binst<64, 3, 3, 8, 32, false>()};
 
 // the forward's own table: (cq_lo, cqp] = the channel counts a row serves
 struct BFInst {
@@ -561,7 +650,7 @@ const BFInst *find_bfinst(int Cq, int KH, int KW)
 const BInst *find_binst(int Cq, int KH, int KW)
 {
     for (const BInst &i : g_binsts)
-        if (i.kh == KH && i.kw == KW && Cq > 64 && Cq <= i.cqp) return &i;
+        if (i.kh == KH && i.kw == KW && Cq > i.cq_lo && Cq <= i.cqp) return &i;
     return nullptr;
 }
 
@@ -569,13 +658,33 @@ int big_fifo_depth(int W, int KH, int KW) { return W - 16 + KH + KW - 2 + 1; }  
 
 } // namespace
 
-bool finc_big_bank(int Cq, int KH, int KW) { return find_binst(Cq, KH, KW) != nullptr; }
+// the banks this file owns outright (no row in the wavefront kernel's table) ...
+bool finc_big_bank(int Cq, int KH, int KW)
+{
+    const BInst *i = find_binst(Cq, KH, KW);
+    return i && i->fn != nullptr;
+}
+// ... and the ones it takes over from that table on maps too wide for it (their bank rides behind the wavefront kernel's)
+bool finc_big_wide_bank(int Cq, int KH, int KW)
+{
+    const BInst *i = find_binst(Cq, KH, KW);
+    return i && i->fn == nullptr;
+}
+
+// maps up to 64 wide keep the hand-over rows in LDS; wider ones re-read them from the output (FINC_BIG_WIDE=1: from 48 columns
+// on, so that both forms can be compared on one shape)
+static bool big_wide(int W, int KH, int KW)
+{
+    static const bool force = getenv("FINC_BIG_WIDE") != nullptr;
+    const bool fits = (size_t)big_fifo_depth(W, KH, KW) * 4 * (KH - 1) * 4 <= (size_t)FIFO_J - 4;   // (+ the zero word)
+    return !fits || (force && W >= 48);
+}
 
 bool finc_big_supported(int Cq, int H, int W, int KH, int KW)
 {
     const BInst *i = find_binst(Cq, KH, KW);
     if (!i || H < 1 || W < 16 || W % 4 != 0) return false;
-    if ((size_t)big_fifo_depth(W, KH, KW) * 4 * (KH - 1) * 4 > (size_t)FIFO_J - 4) return false;   // (+ the zero word)
+    if (!i->fn && W < 48) return false;                                    // (a wide-only row)
     return (size_t)Cq * H * W * 4 < ((size_t)1 << 30);                     // buffer-offset range marks (OFF_BAD_CHANNEL)
 }
 
@@ -601,7 +710,7 @@ int finc_big_info(const FincShape &s, int *waves, int *lds, int *cqp)
 {
     const BInst *i = find_binst(s.Cq, s.KH, s.KW);
     if (!i) return FINC_ERR_UNSUPPORTED;
-    *waves = i->nwv; *lds = i->lds_bytes; *cqp = i->cqp;
+    *waves = i->nwv; *lds = (big_wide(s.W, s.KH, s.KW) || !i->fn) ? i->lds_bytes_wide : i->lds_bytes; *cqp = i->cqp;
     return FINC_OK;
 }
 
@@ -615,9 +724,11 @@ int finc_big_launch(const float *in, const void *packed, float *out, const FincS
     // unrolled by UNROLL and runs u = 0 .. Tr
     const int T = ((s.H + P - 1) / P) * s.W + P - 1;
     const int Tr = (T + 4 + UNROLL - 1) / UNROLL * UNROLL - 1;
-    const size_t lds = (size_t)i->lds_bytes;
-    if (int e = finc_ensure_dynamic_lds((const void *)i->fn, lds)) return e;
-    hipLaunchKernelGGL(i->fn, dim3(s.B * s.G), dim3(64 * i->nwv), lds, st, in, (const float *)packed, out, s.G, s.Cq, s.H, s.W, Tr,
+    const bool wide = big_wide(s.W, s.KH, s.KW) || !i->fn;
+    const big_fn fn = wide ? i->fn_wide : i->fn;
+    const size_t lds = (size_t)(wide ? i->lds_bytes_wide : i->lds_bytes);
+    if (int e = finc_ensure_dynamic_lds((const void *)fn, lds)) return e;
+    hipLaunchKernelGGL(fn, dim3(s.B * s.G), dim3(64 * i->nwv), lds, st, in, (const float *)packed, out, s.G, s.Cq, s.H, s.W, Tr,
                        s.orient, big_fifo_depth(s.W, s.KH, s.KW));
     FINC_CHECK_LAUNCH();
     return FINC_OK;

@@ -90,6 +90,7 @@ int finc_mfma_packed_cqp(int Cq, int KH, int KW);
 // ---- inverse for the under-filled chip, role-split kernel: finc_split.hip (same packed bank as the wavefront kernel) ----
 // finc_big.hip: 3x3 banks beyond the wavefront kernel's table (64 < Cq <= 96), 8 waves per problem, each owns 12 output channels
 bool finc_big_bank(int Cq, int KH, int KW);
+bool finc_big_wide_bank(int Cq, int KH, int KW);   // a bank of the wavefront kernel's table that finc_big.hip takes over on maps too wide for it
 bool finc_big_supported(int Cq, int H, int W, int KH, int KW);
 size_t finc_big_packed_bytes(int G, int Cq, int KH, int KW);
 int finc_big_pack(const float *wc, const float *scale, const float *shift, void *packed, int G, int Cq, int KH, int KW, hipStream_t st);

@@ -1648,8 +1648,8 @@ bool finc_mfma_supported(int Cq, int H, int W, int KH, int KW)
     const int P = W < 16 ? W : 16;
     if (P < KH - 1) return false;
     // the shape is supported if a variant exists that takes ANY problem count (a huge odd one rules out the packed and
-    // the small-batch variants) and whose rings fit the LDS at this width
-    if (!find_inst(Cq, KH, KW, (1LL << 40) + 1, W)) return false;
+    // the small-batch variants) and whose rings fit the LDS at this width -- or, on maps too wide for that, finc_big.hip does
+    if (!find_inst(Cq, KH, KW, (1LL << 40) + 1, W)) return finc_big_wide_bank(Cq, KH, KW) && finc_big_supported(Cq, H, W, KH, KW);
     if ((size_t)Cq * H * W * 4 >= ((size_t)1 << 30)) return false; // buffer-offset range marks (OFF_BAD_CHANNEL)
     return true;
 }
@@ -1661,11 +1661,24 @@ int finc_mfma_packed_cqp(int Cq, int KH, int KW)
     return a ? a->cqp : 0;
 }
 
+// bytes of this table's own bank (behind it: the bank of finc_big.hip for the banks it takes over on wide maps)
+static size_t wave_bank_bytes(int G, int Cq, int KH, int KW)
+{
+    const Inst *a = find_inst(Cq, KH, KW);
+    return a ? (size_t)(a->nfrag + 8 * a->mt) * 64 * sizeof(float) * (size_t)G : 0;
+}
+// (which problem sets of such a bank go to finc_big.hip: those no variant of this table can hold)
+static bool wide_takeover(const FincShape &s)
+{
+    return finc_big_wide_bank(s.Cq, s.KH, s.KW) && !find_inst(s.Cq, s.KH, s.KW, (1LL << 40) + 1, s.W) &&
+           finc_big_supported(s.Cq, s.H, s.W, s.KH, s.KW);
+}
+
 size_t finc_mfma_packed_bytes(int G, int Cq, int KH, int KW)
 {
     if (finc_big_bank(Cq, KH, KW)) return finc_big_packed_bytes(G, Cq, KH, KW);
-    const Inst *a = find_inst(Cq, KH, KW);
-    return a ? (size_t)(a->nfrag + 8 * a->mt) * 64 * sizeof(float) * (size_t)G : 0;
+    const size_t own = wave_bank_bytes(G, Cq, KH, KW);
+    return own && finc_big_wide_bank(Cq, KH, KW) ? own + finc_big_packed_bytes(G, Cq, KH, KW) : own;
 }
 
 int finc_mfma_pack(const float *wc, const float *scale, const float *shift, void *packed, int G, int Cq, int KH, int KW,
@@ -1677,13 +1690,19 @@ int finc_mfma_pack(const float *wc, const float *scale, const float *shift, void
     hipLaunchKernelGGL(pack_kernel, dim3(G), dim3(256), sizeof(double) * Cq * Cq, st, wc, scale, shift, (float *)packed, Cq,
                        KH, KW, i->mt, i->nkz, i->nkd, i->mtb, i->nfrag);
     FINC_CHECK_LAUNCH();
+    // (a folded shift is the one thing finc_big.hip does not carry: such a bank simply has no wide-map form -- zeros there)
+    if (finc_big_wide_bank(Cq, KH, KW)) {
+        char *behind = (char *)packed + wave_bank_bytes(G, Cq, KH, KW);
+        if (shift) FINC_HIP_TRY(hipMemsetAsync(behind, 0, finc_big_packed_bytes(G, Cq, KH, KW), st));
+        else return finc_big_pack(wc, scale, nullptr, behind, G, Cq, KH, KW, st);
+    }
     return FINC_OK;
 }
 
 int finc_mfma_variant(int B, int G, int Cq, int H, int W, int KH, int KW, int *info)
 {
     if (!finc_mfma_supported(Cq, H, W, KH, KW)) return FINC_ERR_UNSUPPORTED;
-    if (finc_big_bank(Cq, KH, KW)) {           // form 5: the big-bank kernel, one workgroup of info[1] waves per problem
+    if (finc_big_bank(Cq, KH, KW) || wide_takeover(FincShape{B, G, Cq, H, W, KH, KW, 0})) {   // form 5: the big-bank kernel, one workgroup of info[1] waves per problem
         int waves = 0, lds = 0, cqp = 0;
         if (int e = finc_big_info(FincShape{B, G, Cq, H, W, KH, KW, 0}, &waves, &lds, &cqp)) return e;
         info[0] = cqp; info[1] = waves; info[2] = 1; info[3] = 5; info[4] = lds; info[5] = B * G;
@@ -1740,6 +1759,8 @@ int finc_mfma_launch(const float *in, const void *packed, float *out, const Finc
     if (zpre && !finc_mfma_zpre_takes(s)) return FINC_ERR_UNSUPPORTED;
     if (int e = finc_fault_gate(false)) return e;          // an earlier launch on this device gave up a protocol wait
     if (finc_big_bank(s.Cq, s.KH, s.KW)) return finc_big_launch(in, packed, out, s, st);   // beyond this table (finc_big.hip)
+    if (wide_takeover(s))                                                                  // too wide for this table's forms
+        return finc_big_launch(in, (const char *)packed + wave_bank_bytes(s.G, s.Cq, s.KH, s.KW), out, s, st);
     if (finc_split_takes(s)) return finc_split_launch(in, packed, out, s, st);   // the under-filled chip (finc_split.hip)
     const Inst *i = find_inst(s.Cq, s.KH, s.KW, (long long)s.B * s.G, s.W);
     if (!i) return FINC_ERR_UNSUPPORTED;

@@ -12,7 +12,9 @@ from oracle import oracle
 dev = torch.device("cuda:0")
 rng = np.random.default_rng(0)
 # (B, G, Cq, H, W, orient)
-CASES = [(2, 1, 96, 16, 16, 0), (1, 1, 96, 40, 32, 3), (2, 4, 72, 20, 16, None), (1, 1, 65, 33, 64, 1), (3, 1, 96, 7, 20, 2)]
+CASES = [(2, 1, 96, 16, 16, 0), (1, 1, 96, 40, 32, 3), (2, 4, 72, 20, 16, None), (1, 1, 65, 33, 64, 1), (3, 1, 96, 7, 20, 2),
+         (1, 1, 96, 40, 48, 0), (1, 1, 96, 40, 80, 3), (1, 4, 72, 20, 128, None), (1, 1, 65, 33, 96, 1), (2, 1, 96, 50, 68, 2),
+         (1, 1, 50, 40, 256, 0), (1, 1, 64, 20, 160, 3), (1, 4, 48, 18, 256, None), (1, 1, 36, 35, 512, 1), (1, 1, 50, 256, 256, 2)]
 for B, G, Cq, H, W, orient in CASES:
     ori = 0xE4 if orient is None else orient
     ws = oracle.make_stored_weights(G, Cq, 3, 3, orient=ori, seed=Cq + H, std=0.05 * (24.0 / Cq) ** 0.5)
@@ -25,11 +27,12 @@ for B, G, Cq, H, W, orient in CASES:
     out = ops.finc_inverse(torch.from_numpy(z).to(dev), wc, G, ori, algo="auto").cpu().numpy()
     err = np.abs(out - ref).max() / np.abs(ref).max()
     bad = np.argwhere(np.abs(out - ref) > 1e-4 * np.abs(ref).max())
-    print(f"B{B} G{G} Cq{Cq} {H}x{W} orient {orient}: form {v['sec'] if v else None}, rel err {err:.2e}, bad entries {len(bad)}"
+    print(f"B{B} G{G} Cq{Cq} {H}x{W} orient {orient}: form {v['sec'] if v else None} cqp {v['cqp'] if v else None}, rel err {err:.2e}, bad entries {len(bad)}"
           + (f", first {bad[0].tolist()} last {bad[-1].tolist()}" if len(bad) else ""), flush=True)
 
 if len(sys.argv) > 1 and sys.argv[1] == "time":
-    for B, G, Cq, H, W in ((256, 1, 96, 64, 64), (256, 1, 96, 32, 32), (64, 4, 96, 32, 32), (256, 1, 80, 64, 64)):
+    for B, G, Cq, H, W in ((256, 1, 96, 64, 64), (256, 1, 96, 32, 32), (64, 4, 96, 32, 32), (256, 1, 80, 64, 64), (256, 1, 96, 64, 128),
+                           (100, 1, 50, 256, 256), (64, 4, 64, 64, 256)):
         ws = oracle.make_stored_weights(G, Cq, 3, 3, orient=0xE4 if G == 4 else 0, seed=1, std=0.025)
         wc = ops.canonicalize(torch.from_numpy(ws).to(dev), G, 0xE4 if G == 4 else 0)
         z = torch.randn(B, G * Cq, H, W, device=dev)

@@ -363,7 +363,7 @@ def test_grad_weight_mfma(shape, dev):
     B, C, H, W, K = shape
     L = _lib.lib()
     Cq = C // 4
-    assert L.finc_backward_workspace_bytes(B, 4, Cq, H, W, K, K) > L.finc_workspace_bytes(4, Cq, K, K)  # MFMA grad_w exists
+    assert _lib.backward_variant(B, 4, Cq, H, W, K, K)["gradw"] != "direct"      # an MFMA grad_w kernel exists for this shape
     torch.manual_seed(sum(shape))
     wc = canon(oracle.make_stored_weights(4, Cq, K, K), 4, ORIENT_FASTFLOW, dev)
     x = torch.randn(B, C, H, W, device=dev)
@@ -538,9 +538,52 @@ def test_big_banks_run_on_mfma(case, dev):
     torch.cuda.synchronize()
     want = z * scale.cpu().numpy().reshape(1, C, 1, 1) + shift.cpu().numpy().reshape(1, C, 1, 1)
     assert rel_err(zo.cpu().numpy(), want) <= TOL
-    # a map the big-bank kernel does not take (wider than 64 / narrower than 16): the strict kernel, same answer
-    for Wx in (12, 68):
-        assert L.finc_inverse_algo_for(Cq, 4, Wx, 3, 3) == _lib.ALGO["strict"]
+    # a map the big-bank kernel does not take (narrower than 16 columns): the strict kernel
+    assert L.finc_inverse_algo_for(Cq, 4, 12, 3, 3) == _lib.ALGO["strict"]
+
+
+# (B, G, Cq, H, W, orient, bank): maps too wide for an LDS hand-over -- the big banks beyond 64 columns, and the 33 .. 64 channel
+# banks from the width at which the wavefront kernel's K-split forms no longer fit (fastflow/test_examples.py:218-222 has a
+# 50-channel 256 x 256 layer) -- re-read the rows above a band from the output (finc_big.hip, HBMF)
+WIDE_MAP_CASES = [(1, 1, 96, 40, 80, 3, 96), (1, 4, 72, 20, 128, None, 96), (2, 1, 96, 50, 68, 2, 96), (1, 1, 50, 40, 256, 0, 64),
+                  (1, 1, 64, 20, 160, 3, 64), (1, 4, 48, 18, 256, None, 64), (1, 1, 36, 35, 512, 1, 64), (1, 1, 50, 256, 256, 2, 64)]
+
+
+@pytest.mark.parametrize("case", WIDE_MAP_CASES, ids=lambda c: "B%d_G%d_Cq%d_%dx%d_o%s_bank%d" % c)
+def test_wide_maps_hand_over_through_memory(case, dev):
+    """`(50, 3x3, 256^2)` and its like ran the scalar kernel because two rows of such a map do not fit any
+    FIFO in LDS.  They are in the output: the band below re-reads them from there.  Inverse against the oracle, the library's
+    answer about the kernel asserted; the forward of the same shapes never had the problem and is checked beside it."""
+    from fincflow_amd import ops, _lib
+    B, G, Cq, H, W, orient, bank = case
+    ori = ORIENT_FASTFLOW if orient is None else orient
+    L = _lib.lib()
+    assert L.finc_inverse_algo_for(Cq, H, W, 3, 3) == _lib.ALGO["mfma"]
+    v = _lib.inverse_variant(B, G, Cq, H, W, 3, 3)
+    assert v["sec"] == 5 and v["cqp"] == bank and v["nw"] == 8, v
+    ws = oracle.make_stored_weights(G, Cq, 3, 3, orient=ori, seed=Cq + H, std=0.05 * min(1.0, (24.0 / Cq) ** 0.5))
+    wco = oracle.canonicalize(ws, G, ori)
+    x = np.random.default_rng(H + W).standard_normal((B, G * Cq, H, W)).astype(np.float32)
+    z = oracle.forward_f32(x, wco, G, ori, nthreads=8)
+    wc = canon(ws, G, ori, dev)
+    assert rel_err(ops.finc_forward(t(x, dev), wc, G, ori).cpu().numpy(), z) <= TOL
+    inv = ops.finc_inverse(t(z, dev), wc, G, ori, algo="auto").cpu().numpy()
+    ref = oracle.inverse_via_f64(z, wco, G, ori, nthreads=8)
+    e = rel_err(inv, ref)
+    report("wide_map", B=B, G=G, Cq=Cq, H=H, W=W, err_max_norm=e, err_elementwise=elem_rel_err(inv, ref))
+    assert e <= max(TOL, 2.0 * rel_err(oracle.inverse_f32(z, wco, G, ori, nthreads=8), ref)), e
+    if bank == 64:      # the same bank on a map the wavefront kernel holds: its own kernel -- and ONE packed buffer serves both
+        v2 = _lib.inverse_variant(B, G, Cq, 16, 64, 3, 3)
+        assert v2 is not None and v2["sec"] != 5, v2
+        cache = ops.PackedWeights()
+        wst = [t(ws, dev)]                 # (the stored weights of all groups as one tensor: canonicalize splits them)
+        got_wide = cache.inverse(t(z, dev), wst, G, ori).cpu().numpy()
+        assert rel_err(got_wide, ref) <= max(TOL, 2.0 * rel_err(inv, ref))
+        zn = np.ascontiguousarray(z[:, :, :16, :64])
+        xn = np.ascontiguousarray(x[:, :, :16, :64])
+        zn = oracle.forward_f32(xn, wco, G, ori)
+        got_narrow = cache.inverse(t(zn, dev), wst, G, ori).cpu().numpy()
+        assert rel_err(got_narrow, oracle.inverse_via_f64(zn, wco, G, ori)) <= TOL
 
 
 def test_cincflowunit_at_96_channels(dev):
