@@ -15,6 +15,12 @@ for w in c2 c5 c3_share8; do
 done
 python3 bench.py --workload c4 --steps 20 --warmup 3 --no-cpu > gpurun_out/${TAG}_bench_c4.json 2>> gpurun_out/${TAG}_bench.err
 echo "bench c4 done"
+python3 scripts/f3_measure.py > gpurun_out/${TAG}_f3.json 2>> gpurun_out/${TAG}_bench.err
+echo "f3 done"
+python3 scripts/debug_big.py time > gpurun_out/${TAG}_big_banks.txt 2>> gpurun_out/${TAG}_bench.err
+echo "big banks done"
+python3 scripts/time_small.py > gpurun_out/${TAG}_small_batch.txt 2>> gpurun_out/${TAG}_bench.err
+echo "small batch done"
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/${TAG}_prof_c3 -- python3 $ROOT/bench.py --no-cpu --no-share > $ROOT/gpurun_out/${TAG}_bench_c3_under_rocprof.json 2> $ROOT/gpurun_out/${TAG}_prof_c3.err
 echo "rocprof c3 done"
@@ -31,6 +37,6 @@ cp $(find gpurun_out/${TAG}_prof_c3 -name "*kernel_stats.csv" | head -1) gpurun_
 cp $(find gpurun_out/${TAG}_prof_share8 -name "*kernel_stats.csv" | head -1) gpurun_out/${TAG}/c3_share8_kernel_stats.csv
 cp gpurun_out/pmc_${TAG}_c3/summary.json gpurun_out/${TAG}/c3_pmc_summary.json
 cp gpurun_out/pmc_${TAG}_share8/summary.json gpurun_out/${TAG}/c3_share8_pmc_summary.json
-mv gpurun_out/${TAG}_bench_*.json gpurun_out/${TAG}/
+mv gpurun_out/${TAG}_bench_*.json gpurun_out/${TAG}_f3.json gpurun_out/${TAG}_big_banks.txt gpurun_out/${TAG}_small_batch.txt gpurun_out/${TAG}/
 rm -rf gpurun_out/${TAG}_prof_c3 gpurun_out/${TAG}_prof_share8 gpurun_out/pmc_${TAG}_c3 gpurun_out/pmc_${TAG}_share8
 ls -la gpurun_out/${TAG}
