@@ -152,8 +152,13 @@ __global__ __launch_bounds__(64) void finc_gradw_kernel(const float *__restrict_
 //     tile reads, and the accumulator keeps, per lane row q, the partial sum over the pixels == q (mod 4); the 4x4
 //     transpose-reduce runs ONCE, before the partials are written (c3: 48 instead of 64 MFMA cycles per tap, i tile and
 //     4 pixels).  SMALL = false keeps the padded tile where 4-row blocks would need too many accumulators.
+//   * INPUT CHANNELS (FLAT, round 3): the B operand's 16 columns need not be 16 channels of ONE tap.  The KW taps of a filter
+//     row times the Cq channels are laid side by side -- column j = b * Cq + i -- and cut into tiles of 16: ceil(KW*Cq/16)
+//     tiles per filter row instead of KW * ceil(Cq/16) (c3: 5 instead of 6, Cq = 20: 4 instead of 6, Cq = 8: 2 instead of 3).
+//     A lane simply reads its own (channel, shifted column) from the LDS tile; the partial tiles are written back in the old
+//     (tap, o tile, i tile) layout, so gradw_reduce_kernel does not notice.
 // -----------------------------------------------------------------------------------------------
-template <int CQP, int KH, int KW, bool SMALL>
+template <int CQP, int KH, int KW, bool SMALL, bool FLAT = false>
 __global__ __launch_bounds__(64) void finc_gradw_staged_kernel(const float *__restrict__ gz, const float *__restrict__ x,
                                                                float *__restrict__ part, int G, int CQ, int H, int W, int NS,
                                                                int B, int WPG, unsigned orient)
@@ -162,6 +167,9 @@ __global__ __launch_bounds__(64) void finc_gradw_staged_kernel(const float *__re
     constexpr int MTB = SMALL ? CQP / 16 : MT;                          // full 16-row tiles of output channels
     constexpr int NSM = SMALL ? (CQP % 16) / 4 : 0;                     // 4-row blocks behind them
     constexpr int MTBD = MTB > 0 ? MTB : 1, NSMD = NSM > 0 ? NSM : 1;
+    constexpr int ROWJ = KW * CQP;                                      // FLAT: columns (b, i) of one filter row ...
+    constexpr int NIT = FLAT ? (ROWJ + 15) / 16 : KW * MT;              // ... and the B tiles of a filter row (else: tap b, i tile mi)
+    static_assert(!FLAT || CQP % 16 != 0, "FLAT reads its zeros from the channel rows behind the bank");
     constexpr int XP = 24, GP = 20;                                     // tile pitches (floats): [channel][4 halo + 16], [channel][16]
     constexpr int NXI = (5 * CQP + 63) / 64, NGI = (4 * CQP + 63) / 64; // dwordx4 loads per row
     static_assert(KW <= 5, "the halo is one 16-byte piece");
@@ -178,25 +186,34 @@ __global__ __launch_bounds__(64) void finc_gradw_staged_kernel(const float *__re
     for (int i = lane; i < 16 * MT * XP + 4; i += 64) xt[i] = 0.f;      // channel rows >= CQP are never written: they stay 0
     for (int i = lane; i < 16 * MT * GP + 4; i += 64) gt[i] = 0.f;
 
-    v4f acc[NTAP][MTBD][MT], accs[NTAP][NSMD][MT];
+    // accumulators: [filter row a][B tile of the row][o tile / o block]  (not FLAT: B tile = b * MT + mi)
+    v4f acc[KH][NIT][MTBD], accs[KH][NIT][NSMD];
 #pragma unroll
-    for (int t = 0; t < NTAP; ++t)
+    for (int a = 0; a < KH; ++a)
 #pragma unroll
-        for (int mi = 0; mi < MT; ++mi) {
+        for (int it = 0; it < NIT; ++it) {
 #pragma unroll
-            for (int mo = 0; mo < MTBD; ++mo) acc[t][mo][mi] = (v4f){0.f, 0.f, 0.f, 0.f};
+            for (int mo = 0; mo < MTBD; ++mo) acc[a][it][mo] = (v4f){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int sb = 0; sb < NSMD; ++sb) accs[t][sb][mi] = (v4f){0.f, 0.f, 0.f, 0.f};
+            for (int sb = 0; sb < NSMD; ++sb) accs[a][it][sb] = (v4f){0.f, 0.f, 0.f, 0.f};
         }
     // read positions of lane (q,m): canonical column c of the strip sits at tile column (fw ? 15 - c : c) (+4: the halo piece
     // comes first in memory order when the strip is not mirrored; mirrored, it comes last and the index runs down)
-    int xrd[KW][4], grd[4];
+    int xrd[FLAT ? NIT : KW][4], grd[4];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
         const int c = 4 * kk + q;
         grd[kk] = m * GP + (fw ? 15 - c : c);
+        if constexpr (FLAT) {       // column j = 16 it + m of the filter row = tap b = j / CQP, channel i = j % CQP; past the end: a zero row
 #pragma unroll
-        for (int bb = 0; bb < KW; ++bb) xrd[bb][kk] = m * XP + (fw ? 15 - (c - bb) : 4 + (c - bb));
+            for (int it = 0; it < NIT; ++it) {
+                const int j = 16 * it + m, bb = j / CQP, ic = j % CQP;
+                xrd[it][kk] = j < ROWJ ? ic * XP + (fw ? 15 - (c - bb) : 4 + (c - bb)) : CQP * XP + 4;
+            }
+        } else {
+#pragma unroll
+            for (int bb = 0; bb < KW; ++bb) xrd[bb][kk] = m * XP + (fw ? 15 - (c - bb) : 4 + (c - bb));
+        }
     }
     const int gsm = (16 * MTB + (m & 3)) * GP - m * GP;                 // 4-row block operand: channel base + (m & 3) instead of m
 
@@ -251,15 +268,13 @@ __global__ __launch_bounds__(64) void finc_gradw_staged_kernel(const float *__re
             for (int i = 0; i < NGI; ++i) LG[PAR][i] = __builtin_amdgcn_raw_buffer_load_b128(rg, lvg[i], ro, 0);
         };
         float GA[2][MTBD][4], GS[2][NSMD][4];                           // gz operands: [arriving / current]
-        float XB[RS][KW][MT][4];                                        // x operands by row slot
+        float XB[RS][NIT][4];                                           // x operands by row slot and B tile of the row
 #pragma unroll
         for (int sl = 0; sl < RS; ++sl)
 #pragma unroll
-            for (int bb = 0; bb < KW; ++bb)
+            for (int it = 0; it < NIT; ++it)
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) XB[sl][bb][mt][kk] = 0.f;
+                for (int kk = 0; kk < 4; ++kk) XB[sl][it][kk] = 0.f;
         // stage(row): its pieces (asked for two steps ago) go registers -> tiles -> operand registers of the row's slot, and
         // row + 2 is asked for
         auto stage = [&](auto sn_c, auto pn_c, int row) {
@@ -275,10 +290,15 @@ __global__ __launch_bounds__(64) void finc_gradw_staged_kernel(const float *__re
                 for (int mo = 0; mo < MTB; ++mo) GA[PN][mo][kk] = gt[grd[kk] + 16 * mo * GP];
 #pragma unroll
                 for (int sb = 0; sb < NSM; ++sb) GS[PN][sb][kk] = gt[grd[kk] + gsm + 4 * sb * GP];
+                if constexpr (FLAT) {
 #pragma unroll
-                for (int bb = 0; bb < KW; ++bb)
+                    for (int it = 0; it < NIT; ++it) XB[SN][it][kk] = xt[xrd[it][kk]];
+                } else {
 #pragma unroll
-                    for (int mi = 0; mi < MT; ++mi) XB[SN][bb][mi][kk] = xt[xrd[bb][kk] + 16 * mi * XP];
+                    for (int bb = 0; bb < KW; ++bb)
+#pragma unroll
+                        for (int mi = 0; mi < MT; ++mi) XB[SN][bb * MT + mi][kk] = xt[xrd[bb][kk] + 16 * mi * XP];
+                }
             }
         };
         // step of row h (slot h % RS, gz buffer h & 1): row h+1 is staged (it lands during the MFMAs), then the MFMAs of row h
@@ -290,19 +310,17 @@ __global__ __launch_bounds__(64) void finc_gradw_staged_kernel(const float *__re
 #pragma unroll
             for (int a = 0; a < KH; ++a)
 #pragma unroll
-                for (int bb = 0; bb < KW; ++bb)
+                for (int it = 0; it < NIT; ++it)
 #pragma unroll
-                    for (int mi = 0; mi < MT; ++mi)
+                    for (int kk = 0; kk < 4; ++kk) {
+                        const float xb = XB[(SC + RS - a) % RS][it][kk];
 #pragma unroll
-                        for (int kk = 0; kk < 4; ++kk) {
-                            const float xb = XB[(SC + RS - a) % RS][bb][mi][kk];
+                        for (int mo = 0; mo < MTB; ++mo)
+                            acc[a][it][mo] = __builtin_amdgcn_mfma_f32_16x16x4f32(GA[PC][mo][kk], xb, acc[a][it][mo], 0, 0, 0);
 #pragma unroll
-                            for (int mo = 0; mo < MTB; ++mo)
-                                acc[a * KW + bb][mo][mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(GA[PC][mo][kk], xb, acc[a * KW + bb][mo][mi], 0, 0, 0);
-#pragma unroll
-                            for (int sb = 0; sb < NSM; ++sb)
-                                accs[a * KW + bb][sb][mi] = __builtin_amdgcn_mfma_f32_4x4x1f32(GS[PC][sb][kk], xb, accs[a * KW + bb][sb][mi], 0, 0, 0);
-                        }
+                        for (int sb = 0; sb < NSM; ++sb)
+                            accs[a][it][sb] = __builtin_amdgcn_mfma_f32_4x4x1f32(GS[PC][sb][kk], xb, accs[a][it][sb], 0, 0, 0);
+                    }
             __builtin_amdgcn_sched_barrier(0);
         };
         issue(IC<0>{}, 0);
@@ -318,22 +336,33 @@ __global__ __launch_bounds__(64) void finc_gradw_staged_kernel(const float *__re
     // partial tiles, D layout for gradw_reduce_kernel: part[((g*WPG + wslot)*NTAP*MT*MT + tile)*256 + r*64 + lane]
     float *dst = part + (size_t)blockIdx.x * (NTAP * MT * MT) * 256;
 #pragma unroll
-    for (int t = 0; t < NTAP; ++t)
+    for (int a = 0; a < KH; ++a)
 #pragma unroll
-        for (int mi = 0; mi < MT; ++mi) {
+        for (int it = 0; it < NIT; ++it) {
+            // column m of this B tile in the partial layout: tap t, i tile mi, column n (FLAT: a lane's own; columns past the
+            // end of the filter row belong to nothing -- the positions they would fill hold channels >= Cq, which the reduce skips)
+            int t, mi, n;
+            bool live = true;
+            if constexpr (FLAT) {
+                const int j = 16 * it + m;
+                live = j < ROWJ;
+                t = a * KW + j / CQP; mi = (j % CQP) >> 4; n = (j % CQP) & 15;
+            } else {
+                t = a * KW + it / MT; mi = it % MT; n = m;
+            }
 #pragma unroll
             for (int mo = 0; mo < MTB; ++mo) {
-                const v4f v = acc[t][mo][mi];
+                const v4f v = acc[a][it][mo];
                 const float v0 = v.x, v1 = v.y, v2 = v.z, v3 = v.w;
-                float *d = dst + ((t * MT + mo) * MT + mi) * 256 + lane;
-                d[0] = v0; d[64] = v1; d[128] = v2; d[192] = v3;
+                float *d = dst + ((t * MT + mo) * MT + mi) * 256 + q * 16 + n;
+                if (live) { d[0] = v0; d[64] = v1; d[128] = v2; d[192] = v3; }
             }
             // a reduced block leaves channel 16*MTB + 4sb + q in lane row q: in the D layout of tile mo = MTB that is
             // register q of lane (sb, n)
 #pragma unroll
             for (int sb = 0; sb < NSM; ++sb) {
-                const float v = finc_block_reduce(accs[t][sb][mi]);
-                dst[((t * MT + MTB) * MT + mi) * 256 + q * 64 + sb * 16 + m] = v;
+                const float v = finc_block_reduce(accs[a][it][sb]);
+                if (live) dst[((t * MT + MTB) * MT + mi) * 256 + q * 64 + sb * 16 + n] = v;
             }
         }
 }
@@ -523,8 +552,11 @@ constexpr gradw_fn gradw_staged_fn()
     // 4-row blocks for the channels behind the last full 16 where their accumulators fit beside the operand slots
     constexpr int ACC_SMALL = NTAP * (CQP / 16 + (CQP % 16) / 4) * MTG * 4;
     if constexpr (KW > 5 || NTAP * MTG * MTG * 4 > 200) return nullptr;
-    else if constexpr (CQP % 16 != 0 && ACC_SMALL <= 224) return finc_gradw_staged_kernel<CQP, KH, KW, true>;
-    else return finc_gradw_staged_kernel<CQP, KH, KW, false>;
+    else if constexpr (CQP % 16 != 0 && ACC_SMALL <= 224) {
+        // the taps of a filter row side by side in the B tiles, where that saves tiles (FLAT)
+        if constexpr ((KW * CQP + 15) / 16 < KW * MTG) return finc_gradw_staged_kernel<CQP, KH, KW, true, true>;
+        else return finc_gradw_staged_kernel<CQP, KH, KW, true>;
+    } else return finc_gradw_staged_kernel<CQP, KH, KW, false>;
 }
 template <int CQP, int KH, int KW>
 constexpr GradwInst make_gradw()
