@@ -434,7 +434,7 @@ __global__ void big_pack_kernel(const float *__restrict__ wc, const float *__res
 // that the B operand of tap (a,b) is one conflict-free ds_read_b32 (lane (q,p) <- row h-a, column p-b, channel 4j+q).  Every
 // wave fetches the NEXT row of its own NB k-steps (4*NB channel rows x 5 pieces of 16 bytes: one dwordx4 of the first lanes)
 // while it multiplies the current one, and writes it into the ring behind the MFMAs; one barrier per row.  The outputs leave as
-// one dword per lane (16 lanes = 64 contiguous bytes of a channel row).  W % 16 == 0.
+// one dword per lane (16 lanes = 64 contiguous bytes of a channel row).  W % 4 == 0 (16-byte pieces; the last strip may be partial).
 // An affine map behind the conv (the ActNorm that follows the unit in the model: layers/actnorm.py:39-46) folds in as everywhere:
 // the scale in the fragments' rows, the shift added to the finished pixel.
 // -----------------------------------------------------------------------------------------------
@@ -497,7 +497,7 @@ __global__ __launch_bounds__(64 * NWV) void finc_bigfwd_kernel(const float *__re
         fetcher[r] = idx < 20 * NB;
         const int fch = 4 * NB * wv + frow;                                // input channel: k-step NB*wv + frow/4, k-slot frow%4
         const int fcol = 16 * strip - 4 + 4 * fpiece;                      // first canonical column of the piece
-        const bool fok = fetcher[r] && fch < CQ && fcol >= 0;
+        const bool fok = fetcher[r] && fch < CQ && fcol >= 0 && fcol < W;    // (W % 4 == 0: a piece is inside the row or outside)
         fbase[r] = fok ? (unsigned)(fch * HW * 4 + (fw ? W - 4 - fcol : fcol) * 4) : OFF_INVALID;
         fdst[r] = ((NB * wv + frow / 4) * COLS + 4 * fpiece) * 16 + (frow % 4) * 4;   // [k-step][column][k-slot] of the piece's first column
     }
@@ -528,7 +528,8 @@ __global__ __launch_bounds__(64 * NWV) void finc_bigfwd_kernel(const float *__re
     land(fetch(0), 0);
     __syncthreads();
     const int rd = ((p + 4) * 4 + q) * 4;                                  // this lane's operand of tap (a, 0): column p, k-slot q
-    const unsigned ocol = (unsigned)((fw ? W - 1 - (16 * strip + p) : 16 * strip + p) * 4);
+    // (the last strip of a row that is not a multiple of 16 wide: its columns >= W are computed from zeros and not stored)
+    const unsigned ocol = 16 * strip + p < W ? (unsigned)((fw ? W - 1 - (16 * strip + p) : 16 * strip + p) * 4) : OFF_INVALID;
     for (int h = 0; h < H; ++h) {
         const Row nxt = fetch(h + 1);
         v4f acc[NB];
@@ -746,7 +747,7 @@ bool finc_bigfwd_takes(const float *in, const float *out, const FincShape &s)
 {
     static const bool off = getenv("FINC_NO_BIGFWD") != nullptr;           // A/B switch: the 8-wave K-split row of the strip kernel
     const BFInst *i = find_bfinst(s.Cq, s.KH, s.KW);
-    if (!i || off || s.W % 16 != 0 || s.H < 1) return false;
+    if (!i || off || s.W % 4 != 0 || s.W < 4 || s.H < 1) return false;       // (16-byte pieces)
     if (((uintptr_t)in | (uintptr_t)out) & 15u) return false;
     return (size_t)s.Cq * s.H * s.W * 4 < ((size_t)1 << 30);
 }
@@ -770,7 +771,7 @@ int finc_bigfwd_launch(const float *in, const void *packed, float *out, const Fi
 {
     const BFInst *i = find_bfinst(s.Cq, s.KH, s.KW);
     if (!i || !finc_bigfwd_takes(in, out, s)) return FINC_ERR_UNSUPPORTED;
-    const int NS = s.W / 16;
+    const int NS = (s.W + 15) / 16;
     const float *sh = (const float *)packed + (size_t)s.G * i->nwv * i->nreg * 64;
     hipLaunchKernelGGL(i->fn, dim3(s.B * s.G * NS), dim3(64 * i->nwv), 0, st, in, (const float *)packed, sh, out, s.G, s.Cq, s.H, s.W,
                        NS, s.orient);

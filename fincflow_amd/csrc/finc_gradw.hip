@@ -141,7 +141,7 @@ __global__ __launch_bounds__(64) void finc_gradw_kernel(const float *__restrict_
 }
 
 // -----------------------------------------------------------------------------------------------
-// grad_w, staged form (W % 16 == 0, 16-byte aligned activations).  Same strip walk, same partial tiles for
+// grad_w, staged form (W % 4 == 0 -- the last strip of a row may be partial --, 16-byte aligned activations).  Same strip walk, same partial tiles for
 // gradw_reduce_kernel, two differences:
 //   * MEMORY: a row of gz and of x arrives as 16-byte pieces (lane = (channel, piece); the columns left of the strip are
 //     one more piece per x channel, as in the staged forward), is parked in an LDS tile and read back as MFMA operands
@@ -234,7 +234,8 @@ __global__ __launch_bounds__(64) void finc_gradw_staged_kernel(const float *__re
             lwx[i] = 16 * MT * XP;                                      // scratch piece behind the tile
             if (t < 4 * CQP) {
                 const int c = t >> 2, k = t & 3;
-                if (c < CQ) lvx[i] = (unsigned)c * HW * 4u + (unsigned)(ms + 4 * k) * 4u;
+                // (W % 4 == 0: a piece is inside the row or outside -- the last strip of a row that is not a multiple of 16 wide)
+                if (c < CQ && ms + 4 * k >= 0 && ms + 4 * k < W) lvx[i] = (unsigned)c * HW * 4u + (unsigned)(ms + 4 * k) * 4u;
                 lwx[i] = c * XP + (fw ? 0 : 4) + 4 * k;
             } else if (t < 5 * CQP) {
                 const int c = t - 4 * CQP;
@@ -249,7 +250,7 @@ __global__ __launch_bounds__(64) void finc_gradw_staged_kernel(const float *__re
             lwg[i] = 16 * MT * GP;
             if (t < 4 * CQP) {
                 const int c = t >> 2, k = t & 3;
-                if (c < CQ) lvg[i] = (unsigned)c * HW * 4u + (unsigned)(ms + 4 * k) * 4u;
+                if (c < CQ && ms + 4 * k >= 0 && ms + 4 * k < W) lvg[i] = (unsigned)c * HW * 4u + (unsigned)(ms + 4 * k) * 4u;
                 lwg[i] = c * GP + 4 * k;
             }
         }
@@ -427,7 +428,7 @@ __global__ __launch_bounds__(64) void finc_gradw_tiled_kernel(const float *__res
             lwx[i] = 16 * XP;                                           // scratch piece behind the tile
             if (t < 64) {
                 const int c = t >> 2, k = t & 3;
-                if (cx + c < CQ) lvx[i] = (unsigned)(cx + c) * HW * 4u + (unsigned)(ms + 4 * k) * 4u;
+                if (cx + c < CQ && ms + 4 * k >= 0 && ms + 4 * k < W) lvx[i] = (unsigned)(cx + c) * HW * 4u + (unsigned)(ms + 4 * k) * 4u;
                 lwx[i] = c * XP + (fw ? 0 : 4) + 4 * k;
             } else if (t < 80) {
                 const int c = t - 64;
@@ -437,7 +438,7 @@ __global__ __launch_bounds__(64) void finc_gradw_tiled_kernel(const float *__res
         }
         {
             const int c = lane >> 2, k = lane & 3;
-            lvg = cg + c < CQ ? (unsigned)(cg + c) * HW * 4u + (unsigned)(ms + 4 * k) * 4u : OFF_BAD_CHANNEL;
+            lvg = (cg + c < CQ && ms + 4 * k >= 0 && ms + 4 * k < W) ? (unsigned)(cg + c) * HW * 4u + (unsigned)(ms + 4 * k) * 4u : OFF_BAD_CHANNEL;
             lwg = c * GP + 4 * k;
         }
         auto rowbytes = [&](int h) { return (unsigned)((fh ? H - 1 - h : h) * W) * 4u; };
@@ -542,7 +543,7 @@ struct GradwInst {
     int cqp, kh, kw;
     int mtg;            // ceil(Cq/16) tiles in both dimensions of the partial layout
     gradw_fn gw;        // dword loads, any W (nullptr: NTAP*MT*MT accumulators would not fit)
-    gradw_fn gw_staged; // W % 16 == 0, 16-byte aligned activations (nullptr: none)
+    gradw_fn gw_staged; // W % 4 == 0, 16-byte aligned activations (nullptr: none)
     gradw_tiled_fn gw_tiled;   // one (o, i) tile pair per workgroup, same conditions: for the banks gw cannot hold (nullptr: KW > 5)
 };
 template <int CQP, int KH, int KW>
@@ -602,7 +603,7 @@ static int gradw_wpg_tiled(const FincShape &s, int mtt)
     if (w > 256) w = 256;
     return units < w ? units : w;
 }
-static bool gradw_use_tiled(const GradwInst *i, const FincShape &s) { return i && !i->gw && i->gw_tiled && s.W % 16 == 0; }
+static bool gradw_use_tiled(const GradwInst *i, const FincShape &s) { return i && !i->gw && i->gw_tiled && s.W % 4 == 0; }
 
 size_t finc_gradw_workspace_bytes(const FincShape &s)
 {
@@ -630,7 +631,7 @@ int finc_gradw_launch(const float *gz, const float *x, float *gw, void *workspac
         if (!i->gw) return FINC_ERR_UNSUPPORTED;
         WPG = gradw_wpg(s);
         static const bool no_staged = getenv("FINC_GRADW_NO_STAGED") != nullptr;   // experiment switch
-        const gradw_fn fn = (i->gw_staged && s.W % 16 == 0 && aligned16 && !no_staged) ? i->gw_staged : i->gw;
+        const gradw_fn fn = (i->gw_staged && s.W % 4 == 0 && aligned16 && !no_staged) ? i->gw_staged : i->gw;
         hipLaunchKernelGGL(fn, dim3(s.G * WPG), dim3(64), 0, st, gz, x, (float *)workspace, s.G, s.Cq, s.H, s.W, NS, s.B,
                            WPG, s.orient);
     }
@@ -652,7 +653,7 @@ int finc_gradw_variant(const FincShape &s)
     if (gradw_use_tiled(i, s)) return 3;
     if (!i->gw) return 0;
     static const bool no_staged = getenv("FINC_GRADW_NO_STAGED") != nullptr;
-    return (i->gw_staged && s.W % 16 == 0 && !no_staged) ? 2 : 1;
+    return (i->gw_staged && s.W % 4 == 0 && !no_staged) ? 2 : 1;
 }
 
 unsigned finc_build_flags_gradw() { return FINC_BUILD_FLAGS; }

@@ -253,7 +253,10 @@ BACKWARD_CASES = [
     # (B, C, H, W, K, grad-weight kernel, grad-input waves per strip): every MFMA backward kernel, named -- the staged and the
     # tiled grad-weight kernels (c3's and c5's), the dword one, and the K-split grad-input
     (3, 96, 12, 32, 3, "staged", 1),       # c3's bank, W % 16 == 0: finc_gradw_staged_kernel
-    (2, 96, 9, 24, 3, "dword", 1),         # same bank, W % 16 != 0: finc_gradw_kernel
+    (2, 96, 9, 18, 3, "dword", 1),         # same bank, W % 4 != 0: finc_gradw_kernel (dword loads)
+    (2, 96, 9, 24, 3, "staged", 1),        # W % 4 == 0 but not % 16: the staged kernel with a partial last strip
+    (3, 96, 7, 44, 3, "staged", 1),        # ... three strips, the last one 12 columns
+    (2, 192, 10, 20, 3, "tiled", 2),       # the tiled kernel with a partial last strip
     (2, 192, 10, 16, 3, "tiled", 2),       # Cq = 48 3x3: finc_gradw_tiled_kernel, K-split grad-input (2 waves per strip)
     (2, 192, 7, 32, 5, "tiled", 4),        # Cq = 48 5x5 (the c5 bank): tiled grad-weight, K-split grad-input (4 waves)
     (2, 128, 9, 16, 3, "staged", 1),       # Cq = 32 3x3: staged grad-weight
@@ -511,7 +514,7 @@ def test_big_banks_run_on_mfma(case, dev):
     v = _lib.inverse_variant(B, G, Cq, H, W, 3, 3)
     assert v["sec"] == 5 and v["nw"] == 8 and v["cqp"] == 96 and v["workgroups"] == B * G, v
     # forward: the M-split of finc_big.hip on whole 16-column strips, the 8-wave K-split row of the strip kernel otherwise
-    assert _lib.backward_variant(B, G, Cq, H, W, 3, 3)["conv_form"] == ("msplit" if W % 16 == 0 else "strip")
+    assert _lib.backward_variant(B, G, Cq, H, W, 3, 3)["conv_form"] == "msplit"
     ws = oracle.make_stored_weights(G, Cq, 3, 3, orient=ori, seed=Cq + H, std=0.05 * (24.0 / Cq) ** 0.5)
     wco = oracle.canonicalize(ws, G, ori)
     x = np.random.default_rng(H * W).standard_normal((B, G * Cq, H, W)).astype(np.float32)
@@ -584,6 +587,22 @@ def test_wide_maps_hand_over_through_memory(case, dev):
         zn = oracle.forward_f32(xn, wco, G, ori)
         got_narrow = cache.inverse(t(zn, dev), wst, G, ori).cpu().numpy()
         assert rel_err(got_narrow, oracle.inverse_via_f64(zn, wco, G, ori)) <= TOL
+
+
+def test_big_bank_forward_on_an_odd_width(dev):
+    """W % 4 != 0 has no 16-byte pieces: the forward of a big bank then runs the 8-wave K-split row of the strip kernel (dword
+    loads), the inverse a zero-padded copy on the M-split kernel -- both against the oracle."""
+    from fincflow_amd import ops, _lib
+    B, G, Cq, H, W = 2, 1, 96, 9, 18
+    assert _lib.backward_variant(B, G, Cq, H, W, 3, 3)["conv_form"] == "strip"
+    ws = oracle.make_stored_weights(G, Cq, 3, 3, orient=1, seed=5, std=0.025)
+    wco = oracle.canonicalize(ws, G, 1)
+    x = np.random.default_rng(1).standard_normal((B, G * Cq, H, W)).astype(np.float32)
+    z = oracle.forward_f32(x, wco, G, 1)
+    wc = canon(ws, G, 1, dev)
+    assert rel_err(ops.finc_forward(t(x, dev), wc, G, 1).cpu().numpy(), z) <= TOL
+    inv = ops.finc_inverse(t(z, dev), wc, G, 1, algo="auto").cpu().numpy()
+    assert rel_err(inv, oracle.inverse_via_f64(z, wco, G, 1)) <= TOL
 
 
 def test_cincflowunit_at_96_channels(dev):
