@@ -327,8 +327,11 @@ __global__ __launch_bounds__(64 * NWV) void finc_big_kernel(const float *__restr
             constexpr bool FAR = NK * SJ > 65535;
             constexpr int J0 = FAR && HH * HALF >= NK / 2 ? NK / 2 : 0;    // (k-step of the base register)
             const int addr = item_addr(IC<item>{}, u) + J0 * SJ;
+#ifndef FINC_BIG_ABLATE   // timing-only bit mask (experiment builds): 1 = the operands are not read from LDS; results wrong
+#define FINC_BIG_ABLATE 0
+#endif
 #pragma unroll
-            for (int j = 0; j < HALF; ++j) dst[j] = ld(addr + (HH * HALF + j - J0) * SJ);
+            for (int j = 0; j < HALF; ++j) dst[j] = (FINC_BIG_ABLATE & 1) ? __builtin_bit_cast(float, addr + j) : ld(addr + (HH * HALF + j - J0) * SJ);
         };
         auto mma_half = [&](auto i_c, auto h_c, const float (&src)[HALF]) {
             constexpr int I = decltype(i_c)::value, HH = decltype(h_c)::value;

@@ -15,13 +15,13 @@
     X(FINC_SAMEBUF, 6) X(FINC_HLP_NOWAIT, 7) X(FINC_S64_ABLATE, 8) X(FINC_FIFO_EXEC, 9) X(FINC_HLP_PRIO, 10)            \
     X(FINC_ZREP, 11) X(FINC_S64_MODE, 12) X(FINC_HLP_MODE, 13) X(FINC_ONLY_C3, 14) X(FINC_CONV_ABLATE, 15)              \
     X(FINC_CONV_2W_MAX, 16) X(FINC_SPLIT_STAMP, 17) X(FINC_HLP_INJECT_TIMEOUT, 18) X(FINC_HLP_BUDGET_LOG2, 19)    \
-    X(FINC_WINO_ABLATE, 20)
+    X(FINC_WINO_ABLATE, 20) X(FINC_BIG_ABLATE, 21)
 
 #if defined(FINC_ABLATE) || defined(FINC_ABLATE_IO) || defined(FINC_LD_AUX) || defined(FINC_ST_AUX) || defined(FINC_STAMP) ||    \
     defined(FINC_HLP_COUNT) || defined(FINC_SAMEBUF) || defined(FINC_HLP_NOWAIT) || defined(FINC_S64_ABLATE) ||                  \
     defined(FINC_FIFO_EXEC) || defined(FINC_HLP_PRIO) || defined(FINC_ZREP) || defined(FINC_S64_MODE) || defined(FINC_HLP_MODE) || \
     defined(FINC_ONLY_C3) || defined(FINC_CONV_ABLATE) || defined(FINC_CONV_2W_MAX) || defined(FINC_SPLIT_STAMP) ||              \
-    defined(FINC_HLP_INJECT_TIMEOUT) || defined(FINC_HLP_BUDGET_LOG2) || defined(FINC_WINO_ABLATE)
+    defined(FINC_HLP_INJECT_TIMEOUT) || defined(FINC_HLP_BUDGET_LOG2) || defined(FINC_WINO_ABLATE) || defined(FINC_BIG_ABLATE)
 #ifndef FINC_EXPERIMENT
 #error "a measurement knob (finc_experiment.h) is set without -DFINC_EXPERIMENT: this would build a library that computes wrong results"
 #endif
@@ -136,6 +136,11 @@
 #else
 #define FINC_BF_20 0u
 #endif
+#ifdef FINC_BIG_ABLATE
+#define FINC_BF_21 1u
+#else
+#define FINC_BF_21 0u
+#endif
 #ifdef FINC_EXPERIMENT
 #define FINC_BF_31 1u
 #else
@@ -145,4 +150,4 @@
     ((FINC_BF_0 << 0) | (FINC_BF_1 << 1) | (FINC_BF_2 << 2) | (FINC_BF_3 << 3) | (FINC_BF_4 << 4) | (FINC_BF_5 << 5) |   \
      (FINC_BF_6 << 6) | (FINC_BF_7 << 7) | (FINC_BF_8 << 8) | (FINC_BF_9 << 9) | (FINC_BF_10 << 10) | (FINC_BF_11 << 11) | \
      (FINC_BF_12 << 12) | (FINC_BF_13 << 13) | (FINC_BF_14 << 14) | (FINC_BF_15 << 15) | (FINC_BF_16 << 16) |           \
-     (FINC_BF_17 << 17) | (FINC_BF_18 << 18) | (FINC_BF_19 << 19) | (FINC_BF_20 << 20) | (FINC_BF_31 << 31))
+     (FINC_BF_17 << 17) | (FINC_BF_18 << 18) | (FINC_BF_19 << 19) | (FINC_BF_20 << 20) | (FINC_BF_21 << 21) | (FINC_BF_31 << 31))
