@@ -13,6 +13,8 @@ for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursiv
             k = "forward"
         elif "finc_wino_kernel" in k:
             k = "forward_wino"
+        elif "finc_gradw_staged_kernel" in k:
+            k = "gradw_staged"
         else:
             continue
         acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
