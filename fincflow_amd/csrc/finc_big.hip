@@ -104,7 +104,11 @@ __global__ __launch_bounds__(64 * NWV) void finc_big_kernel(const float *__restr
     constexpr int NK = C::NK, NB = C::NB, NJ = C::NB, JS = C::JS, P = 16, JSTRIDE = C::JSTRIDE;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     char *const ldsb = reinterpret_cast<char *>(lds);
-    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    // wave -> the block of MO output channels it owns.  Linv is lower triangular: block c needs the z-term's k-steps up to
+    // NJ*c + NJ-1 only, so the low blocks have fewer MFMAs.  The waves w and w + NWV/2 share a SIMD (dispatch order): pairing
+    // block c with block NWV-1-c gives every SIMD the same load
+    const int wvid = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int wv = wvid < NWV / 2 ? wvid : NWV + NWV / 2 - 1 - wvid;
     const int lane = threadIdx.x & 63;
     const int q = lane >> 4, p = lane & 15;
     const int bg = blockIdx.x, g = bg % G;
@@ -144,6 +148,7 @@ __global__ __launch_bounds__(64 * NWV) void finc_big_kernel(const float *__restr
     // w+f and w+f+1, f = floor(-p/4); it LANDS group w+f+2, requested ONE window earlier, and requests group w+f+3.  Stores: in
     // window w the group w+fs, fs = floor((-3-p)/4), is collected from the x ring's time slots and leaves as one piece.
     const int JLO = NJ * wv;
+    const int zlast = NJ * wv + NJ - 1;        // last k-step of the z-term with a nonzero fragment in this wave's rows
     // channel 4(JLO+j)+q: the natural order serves loads and stores alike.  (HBMF: recomputed at every use -- three times per
     // window -- instead of kept: the variant is three registers short, and a spill is not an option beside hand-counted loads)
     unsigned cmask_k[HBMF ? 1 : NJ];
@@ -347,7 +352,8 @@ __global__ __launch_bounds__(64 * NWV) void finc_big_kernel(const float *__restr
                  constexpr int I = S / NBATCH, HH = S % NBATCH;             // batch S of the NBATCH * NITEM
                  if constexpr (S + 1 < NBATCH * NITEM) read_half(IC<(S + 1) / NBATCH>{}, IC<(S + 1) % NBATCH>{}, v[(S + 1) & 1]);
                  FINC_SB();
-                 mma_half(IC<I>{}, IC<HH>{}, v[S & 1]);
+                 // (z-term: a batch whose k-steps all lie right of this wave's rows multiplies zeros -- skipped, wave-uniformly)
+                 if (C::order(I) != 0 || HH * HALF <= zlast) mma_half(IC<I>{}, IC<HH>{}, v[S & 1]);
                  FINC_SB();
              }()), ...);
         }(std::make_integer_sequence<int, NBATCH * NITEM>{});
