@@ -688,7 +688,7 @@ int finc_conv_variant(int B, int G, int Cq, int H, int W, int KH, int KW, int *i
     info[1] = (i->fn_wide && W % 16 == 0 && !no_wide) ? 1 : 0;
     info[2] = (W + 15) / 16;
     const FincShape s{B, G, Cq, H, W, KH, KW, 0};
-    if (finc_wino_packed_bytes(G, Cq, KH, KW) && finc_wino_takes(nullptr, nullptr, s)) info[1] = 2;   // (2: the Winograd kernel)
+    if (finc_wino_packed_bytes(G, Cq, KH, KW) && finc_wino_takes(nullptr, nullptr, s)) info[1] = finc_wino_form(s) == 4 ? 4 : 2;   // (2: Winograd F(2,3), 4: F(4,3))
     if (finc_bigfwd_packed_bytes(G, Cq, KH, KW) && finc_bigfwd_takes(nullptr, nullptr, s)) info[1] = 3;   // (3: the big banks' M-split)
     return FINC_OK;
 }

@@ -711,10 +711,10 @@ __global__ __launch_bounds__(HLP ? 512 : 64 * NW * NPW) void finc_wave_kernel(co
                     w.y = __builtin_bit_cast(unsigned, e1);
                     w.z = __builtin_bit_cast(unsigned, e2);
                     w.w = __builtin_bit_cast(unsigned, e3);
-                    __builtin_amdgcn_raw_buffer_store_b128(w, rout, vo2, uni, FINC_ST_AUX);
+                    __builtin_amdgcn_raw_buffer_store_b128(w, rout, vo2 + (unsigned)uni, 0, FINC_ST_AUX);   // (offset in the vector operand: scripts/check_store_hazard.py)
                 }
             }
-            __builtin_amdgcn_raw_buffer_store_b128(v, rout, vo, uni, FINC_ST_AUX);
+            __builtin_amdgcn_raw_buffer_store_b128(v, rout, vo + (unsigned)uni, 0, FINC_ST_AUX);     // (offset in the vector operand: scripts/check_store_hazard.py)
         }
         if constexpr (S64S) {
             if (spark) {                       // (divergent) park this window's lower piece where the upper one will find it
@@ -799,7 +799,7 @@ __global__ __launch_bounds__(HLP ? 512 : 64 * NW * NPW) void finc_wave_kernel(co
             v.y = __builtin_bit_cast(unsigned, sv[j][1]);
             v.z = __builtin_bit_cast(unsigned, sv[j][2]);
             v.w = __builtin_bit_cast(unsigned, sv[j][3]);
-            __builtin_amdgcn_raw_buffer_store_b128(v, rout, vo, uni, FINC_ST_AUX);
+            __builtin_amdgcn_raw_buffer_store_b128(v, rout, vo + (unsigned)uni, 0, FINC_ST_AUX);     // (offset in the vector operand: scripts/check_store_hazard.py)
         }
     };
     // the window's HBM work, spread over its 4 steps: step 0 reads the x ring; steps 1-3 store a third of the registers

@@ -45,10 +45,10 @@ using IC = std::integral_constant<int, I>;
 #define FINC_WINO_ABLATE 0
 #endif
 
-template <int CQP>
+template <int CQP, int MO = 2>                                    // MO outputs per tile: F(2,3) or F(4,3)
 struct WCfg {
     static constexpr int MTB = CQP / 16, NSM = (CQP % 16) / 4, MT = MTB + NSM, NK = CQP / 4;
-    static constexpr int NA = 3, NF = 4;                          // row taps, frequencies
+    static constexpr int NA = 3, NF = MO + 2;                     // row taps, frequencies
     static constexpr int NFRAG = NA * NF * NK * MT;               // fragment (a, f, j, mt) at ((a*NF + f)*NK + j)*MT + mt
     static constexpr int NPACK = NFRAG + 4 * MT;                  // + the output shift in accumulator layout (finc_conv.hip)
 };
@@ -289,16 +289,256 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void fi
 }
 
 // -----------------------------------------------------------------------------------------------
+// F(4,3) along W: FOUR neighbouring outputs of a row share six inputs -- 6 multiplies per (o, i, row tap) instead of 12 (2x
+// fewer MFMAs than the direct sum, 1.33x fewer than F(2,3)).  Interpolation points 0, +-1, +-2, infinity (Lavin & Gray):
+//
+//     d[m] = x[i, h-a, wt-2+m], m = 0..5        the six columns the outputs wt .. wt+3 of row tap a read
+//     V = B^T d   = (4d0-5d2+d4, (d4-4d2)+(d3-4d1), (d4-4d2)-(d3-4d1), (d4-d2)+2(d3-d1), (d4-d2)-2(d3-d1), 4d1-5d3+d5)
+//     U = G g     = (g0/4, -(g0+g1+g2)/6, -(g0-g1+g2)/6, g0/24+g1/12+g2/6, g0/24-g1/12+g2/6, g2)       (pack kernel, fp64)
+//     y = A^T M   : y0 = M0+(M1+M2)+(M3+M4), y1 = (M1-M2)+2(M3-M4), y2 = (M1+M2)+4(M3+M4), y3 = (M1-M2)+8(M3-M4)+M5
+//
+// The constants cost accuracy: 1.5e-6 of the largest output against 3e-7 for F(2,3) and 5e-7 for the direct fp32 sum at the c3
+// bank (numpy model of this exact arithmetic; the GPU tests hold the kernel to 1e-5).  Mapping: one wavefront owns 16 column
+// QUADS = 64 columns of one (image, group) slab -- the whole width at 64x64 --, lane (q,p) = quad p, k-slot q; one wave per SIMD
+// (162 bank registers + 72 accumulators at Cq = 24).  A row arrives as one dwordx4 (the lane's own quad) + one dwordx2 (the pair
+// left of it: the neighbour's bytes, an L1 hit; the zero padding for the first quad of a row) per lane and k-step and leaves
+// as one dwordx4 per output register (16 lanes = 256 contiguous bytes).  Rows h-1, h-2 wait transformed in LDS as before.
+// -----------------------------------------------------------------------------------------------
+template <int CQP, bool FW>
+__device__ __forceinline__ void wino4_walk(const __amdgpu_buffer_rsrc_t rin, const __amdgpu_buffer_rsrc_t rout,
+                                           const float *__restrict__ packed, float *__restrict__ vlds, int g, int CQ, int H, int W,
+                                           int strip, int RC, bool fh)
+{
+    using C = WCfg<CQP, 4>;
+    constexpr int MT = C::MT, MTB = C::MTB, NSM = C::NSM, NK = C::NK, NF = C::NF, NFRAG = C::NFRAG;
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    const int lane = threadIdx.x & 63;
+    const int q = lane >> 4, p = lane & 15;
+    const int HW = H * W;
+
+    // ---- the bank (as in wino_walk: 16-row-tile fragments one register each, 4-row-block fragments four to a register)
+    constexpr int NGRP = NFRAG / MT;                      // (a, f, j) triples
+    constexpr int NSMALL = NGRP * NSM, NSR = (NSMALL + 3) / 4;
+    float af[NGRP * (MTB > 0 ? MTB : 1)];
+    float afs[NSR > 0 ? NSR : 1];
+    {
+        const float *pk = packed + (size_t)g * C::NPACK * 64 + lane;
+#pragma unroll
+        for (int t = 0; t < NGRP; ++t)
+#pragma unroll
+            for (int mt = 0; mt < MTB; ++mt) af[t * MTB + mt] = pk[(t * MT + mt) * 64];
+        const int quad = (lane & 15) >> 2;
+#pragma unroll
+        for (int r = 0; r < NSR; ++r) {
+            int gi = 0;
+#pragma unroll
+            for (int a = 3; a >= 0; --a) {
+                constexpr int NSMD = NSM > 0 ? NSM : 1;
+                const int sfr = 4 * r + a < NSMALL ? 4 * r + a : NSMALL - 1;
+                const int ga = (sfr / NSMD) * MT + MTB + sfr % NSMD;
+                gi = (a == 3 || quad == a) ? ga : gi;
+            }
+            afs[r] = pk[gi * 64];
+        }
+#pragma unroll
+        for (int t = 0; t < NGRP * MTB; ++t) asm volatile("" : "+a"(af[t]));
+#pragma unroll
+        for (int r = 0; r < NSR; ++r) asm volatile("" : "+a"(afs[r]));
+    }
+    auto mma = [&](v4f &acc_, int t, int mt, float b) {   // t = (a*NF + f)*NK + j
+        if (mt < MTB) acc_ = __builtin_amdgcn_mfma_f32_16x16x4f32(af[t * MTB + mt], b, acc_, 0, 0, 0);
+        else {
+            const int sfr = t * NSM + (mt - MTB);
+            finc_mma_small(acc_, afs[sfr >> 2], b, sfr & 3);
+        }
+    };
+    // LDS of this wave: frequencies 0..3 of the rows h-1, h-2 as 16-byte cells [slot][j][lane], frequencies 4, 5 as 8-byte
+    // cells behind them (a lane reads back only what it wrote: no barrier), then the output shift in accumulator layout
+    v4f *const vA = reinterpret_cast<v4f *>(vlds);
+    v2f *const vB = reinterpret_cast<v2f *>(vlds + 2 * NK * 64 * 4);
+    float *const blds = vlds + 2 * NK * 64 * 6;
+    {
+        const float *pb = packed + ((size_t)g * C::NPACK + NFRAG) * 64 + lane;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+            *reinterpret_cast<v4f *>(blds + (mt * 64 + lane) * 4) =
+                (v4f){pb[(4 * mt + 0) * 64], pb[(4 * mt + 1) * 64], pb[(4 * mt + 2) * 64], pb[(4 * mt + 3) * 64]};
+    }
+
+    // ---- addressing (wino_walk's scheme).  W % 4 == 0: a quad never straddles the right edge
+    const int wt = strip * 64 + 4 * p;                    // canonical columns wt .. wt+3 of this lane's quad
+    const bool colok = wt < W, leftok = colok && wt > 0;  // (left of the first quad: the zero padding of layers/conv.py:41-55)
+    const unsigned coff = (unsigned)(FW ? W - 4 - wt : wt) * 4u;
+    const unsigned loff = (unsigned)(FW ? W - wt : wt - 2) * 4u;          // the pair wt-2, wt-1 (mirrored: wt-1 first)
+    const unsigned qoff = (unsigned)q * HW * 4u;
+    const bool lastok = 4 * (NK - 1) + q < CQ;
+    const unsigned lin0 = colok ? coff + qoff : OFF_BAD_CHANNEL, lin1 = (colok && lastok) ? coff + qoff : OFF_BAD_CHANNEL;
+    const unsigned ll0 = leftok ? loff + qoff : OFF_BAD_CHANNEL, ll1 = (leftok && lastok) ? loff + qoff : OFF_BAD_CHANNEL;
+    unsigned lo_tile[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) lo_tile[r] = (colok && 16 * (MTB - 1) + 4 * q + r < CQ) ? coff + 4u * qoff : OFF_BAD_CHANNEL;
+    const unsigned lo_base = colok ? coff + 4u * qoff : OFF_BAD_CHANNEL;
+    auto rowoff = [&](int h) { return (h >= 0 && h < H) ? (unsigned)((fh ? H - 1 - h : h) * W) * 4u : OFF_INVALID; };
+
+    float Vc[NF][NK];
+    for (int i = lane; i < 2 * NK * 64 * 6; i += 64) vlds[i] = 0.f;
+    v4u nx[NK];                                           // the next row: this lane's quad ...
+    v2u nl[NK];                                           // ... and the pair left of it (memory order)
+    auto issue = [&](int h) {
+        const unsigned ro = rowoff(h);
+#pragma unroll
+        for (int j = 0; j < NK; ++j) {
+            nx[j] = __builtin_amdgcn_raw_buffer_load_b128(rin, ro + (j == NK - 1 ? lin1 : lin0), 4 * j * HW * 4, 0);
+            nl[j] = __builtin_amdgcn_raw_buffer_load_b64(rin, ro + (j == NK - 1 ? ll1 : ll0), 4 * j * HW * 4, 0);
+        }
+    };
+    auto transform = [&]() {
+#pragma unroll
+        for (int j = 0; j < NK; ++j) {
+            // canonical order = memory order, or mirrored when the group is W-flipped
+            const float d0 = __builtin_bit_cast(float, FW ? nl[j].y : nl[j].x), d1 = __builtin_bit_cast(float, FW ? nl[j].x : nl[j].y);
+            const float d2 = __builtin_bit_cast(float, FW ? nx[j].w : nx[j].x), d3 = __builtin_bit_cast(float, FW ? nx[j].z : nx[j].y);
+            const float d4 = __builtin_bit_cast(float, FW ? nx[j].y : nx[j].z), d5 = __builtin_bit_cast(float, FW ? nx[j].x : nx[j].w);
+            const float t1 = __builtin_fmaf(-4.f, d2, d4), t2 = __builtin_fmaf(-4.f, d1, d3);
+            const float t3 = d4 - d2, t4 = d3 - d1;
+            Vc[0][j] = __builtin_fmaf(4.f, d0, __builtin_fmaf(-5.f, d2, d4));
+            Vc[1][j] = t1 + t2;
+            Vc[2][j] = t1 - t2;
+            Vc[3][j] = __builtin_fmaf(2.f, t4, t3);
+            Vc[4][j] = __builtin_fmaf(-2.f, t4, t3);
+            Vc[5][j] = __builtin_fmaf(4.f, d1, __builtin_fmaf(-5.f, d3, d5));
+        }
+    };
+    auto keep = [&](auto par_c) {                                         // Vc -> the slot of this row's parity
+        constexpr int PAR = decltype(par_c)::value;
+#pragma unroll
+        for (int j = 0; j < NK; ++j) {
+            vA[(PAR * NK + j) * 64 + lane] = (v4f){Vc[0][j], Vc[1][j], Vc[2][j], Vc[3][j]};
+            vB[(PAR * NK + j) * 64 + lane] = (v2f){Vc[4][j], Vc[5][j]};
+        }
+    };
+    // A 16-byte store whose channel offset rides in the instruction's SCALAR offset lost its second dword in the lanes 12..15
+    // of every row when the next instruction overwrote the data registers (seen on gfx950 with a v_pk_add_f32 right behind
+    // the store: the compiler's hazard table only covers the immediate-offset form).  The channel offset therefore goes into
+    // the vector offset (one v_add per store), the form whose wait state the compiler inserts.
+    auto store16 = [&](const v4u &v, unsigned voff, int choff) {
+        __builtin_amdgcn_raw_buffer_store_b128(v, rout, voff + (unsigned)choff, 0, 0);
+    };
+    const int r0 = blockIdx.y * RC, r1 = r0 + RC < H ? r0 + RC : H;       // output rows of this chunk
+    auto step = [&](auto slot_c, int h) {                                 // row h sits in nx / nl; S = h's parity
+        constexpr int S = decltype(slot_c)::value;
+        transform();
+        FINC_SB();
+        issue(h + 1);                                                     // (lands during this step's MFMAs)
+        FINC_SB();
+        if (h < r0) { keep(slot_c); return; }                             // (filling the slots of a chunk: no output row)
+        // (frequency 1 enters all four outputs with weight +1: its accumulators start from the shift)
+        v4f acc[NF][MT];
+#pragma unroll
+        for (int f = 0; f < NF; ++f)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+                acc[f][mt] = f == 1 ? *reinterpret_cast<const v4f *>(blds + (mt * 64 + lane) * 4) : (v4f){0.f, 0.f, 0.f, 0.f};
+        float vb[2][NF];
+        auto fetch = [&](int t, float (&dst)[NF]) {                        // t = (a-1)*NK + j, a = 1, 2
+            const int a = 1 + t / NK, j = t % NK, slot = (S + a) & 1;      // (row h-a has the parity of h+a)
+            const v4f lo = vA[(slot * NK + j) * 64 + lane];
+            const v2f hi = vB[(slot * NK + j) * 64 + lane];
+            dst[0] = lo.x; dst[1] = lo.y; dst[2] = lo.z; dst[3] = lo.w; dst[4] = hi.x; dst[5] = hi.y;
+        };
+        fetch(0, vb[0]);
+#pragma unroll
+        for (int j = 0; j < NK; ++j) {
+#pragma unroll
+            for (int f = 0; f < NF; ++f)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) mma(acc[f][mt], (0 * NF + f) * NK + j, mt, Vc[f][j]);
+        }
+        FINC_SB();
+#pragma unroll
+        for (int t = 0; t < 2 * NK; ++t) {
+            if (t + 1 < 2 * NK) fetch(t + 1, vb[(t + 1) & 1]);
+            const int a = 1 + t / NK, j = t % NK;
+#pragma unroll
+            for (int f = 0; f < NF; ++f)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) mma(acc[f][mt], (a * NF + f) * NK + j, mt, vb[t & 1][f]);
+            FINC_SB();
+        }
+        keep(slot_c);                                                     // (row h-2 has been read for the last time)
+        // output transform and stores: one quad per output register and lane -- 16 lanes write 256 contiguous bytes
+        const unsigned ro = rowoff(h);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+            const v4f s1 = acc[1][mt] + acc[2][mt], e1 = acc[1][mt] - acc[2][mt];
+            const v4f s2 = acc[3][mt] + acc[4][mt], e2 = acc[3][mt] - acc[4][mt];
+            const v4f y0 = acc[0][mt] + s1 + s2;
+            const v4f y1 = e1 + 2.f * e2;
+            const v4f y2 = s1 + 4.f * s2;
+            const v4f y3 = e1 + 8.f * e2 + acc[5][mt];
+            if (mt < MTB) {
+                const float a0[4] = {y0.x, y0.y, y0.z, y0.w}, a1[4] = {y1.x, y1.y, y1.z, y1.w};
+                const float a2[4] = {y2.x, y2.y, y2.z, y2.w}, a3[4] = {y3.x, y3.y, y3.z, y3.w};
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    v4u v;
+                    v.x = __builtin_bit_cast(unsigned, FW ? a3[r] : a0[r]);
+                    v.y = __builtin_bit_cast(unsigned, FW ? a2[r] : a1[r]);
+                    v.z = __builtin_bit_cast(unsigned, FW ? a1[r] : a2[r]);
+                    v.w = __builtin_bit_cast(unsigned, FW ? a0[r] : a3[r]);
+                    const unsigned lo = (NSM == 0 && mt == MTB - 1) ? lo_tile[r] : lo_base;
+                    store16(v, ro + lo, (16 * mt + r) * HW * 4);
+                }
+            } else {
+                const float s0 = finc_block_reduce(y0), sa = finc_block_reduce(y1), sb2 = finc_block_reduce(y2), sc = finc_block_reduce(y3);
+                v4u v;
+                v.x = __builtin_bit_cast(unsigned, FW ? sc : s0);
+                v.y = __builtin_bit_cast(unsigned, FW ? sb2 : sa);
+                v.z = __builtin_bit_cast(unsigned, FW ? sa : sb2);
+                v.w = __builtin_bit_cast(unsigned, FW ? s0 : sc);
+                const int sb = mt - MTB;
+                store16(v, ro + (sb == NSM - 1 ? lin1 : lin0), (16 * MTB + 4 * sb) * HW * 4);
+            }
+        }
+    };
+    const int hs = r0 - 2;
+    issue(hs);
+    for (int h = hs; h < r1; h += 2) {
+        step(IC<0>{}, h);
+        if (h + 1 < r1) step(IC<1>{}, h + 1);
+    }
+}
+
+// grid = (B*G*NS strips of 64 columns, row chunks); one wavefront each; 2 * NK * 64 * 24 + MT * 1024 bytes of LDS
+template <int CQP>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void finc_wino4_kernel(
+    const float *__restrict__ in, const float *__restrict__ packed, float *__restrict__ out, int G, int CQ, int H, int W, int NS, int RC,
+    unsigned orient, int, int)
+{
+    extern __shared__ __attribute__((aligned(16))) float vlds[];
+    const int strip = blockIdx.x % NS, bg = blockIdx.x / NS;
+    const int g = bg % G;
+    const unsigned o = finc_group_orient(orient, g);
+    const bool fh = (o & FINC_FLIP_H) != 0, fw = (o & FINC_FLIP_W) != 0;
+    const int HW = H * W;
+    const unsigned slab_bytes = (unsigned)CQ * (unsigned)HW * 4u;
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)(in + (size_t)bg * CQ * HW), 0, (int)slab_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void *)(out + (size_t)bg * CQ * HW), 0, (int)slab_bytes, 0x00020000);
+    if (fw) wino4_walk<CQP, true>(rin, rout, packed, vlds, g, CQ, H, W, strip, RC, fh);
+    else wino4_walk<CQP, false>(rin, rout, packed, vlds, g, CQ, H, W, strip, RC, fh);
+}
+
+// -----------------------------------------------------------------------------------------------
 // Bank: U_{a,f} = filter transform of row a of the (canonical) 3x3 kernel, in the fragment layout of the strip kernels
 // (lane (q,i) of fragment (a, f, j, mt) = U[row(mt,i)][4j+q]); `transpose` swaps in/out channels (grad-input); `scale` /
 // `shift` fold an output-side affine map (finc_conv.hip conv_pack_kernel).  fp64 arithmetic.
 // -----------------------------------------------------------------------------------------------
 __global__ void wino_pack_kernel(const float *__restrict__ wc, const float *__restrict__ scale, const float *__restrict__ shift,
-                                 float *__restrict__ packed, int Cq, int MT, int MTB, int NK, int transpose)
+                                 float *__restrict__ packed, int Cq, int MT, int MTB, int NK, int NF, int transpose)
 {
     const int g = blockIdx.y;
     const float *wg = wc + (size_t)g * Cq * Cq * 9;
-    const int nfrag = 3 * 4 * NK * MT, npack = nfrag + 4 * MT;
+    const int nfrag = 3 * NF * NK * MT, npack = nfrag + 4 * MT;
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < 4 * MT * 64; e += gridDim.x * blockDim.x) {
         const int lane = e & 63, f = e >> 6;
         const int q = lane >> 4, mt = f >> 2, r = f & 3;
@@ -308,14 +548,17 @@ __global__ void wino_pack_kernel(const float *__restrict__ wc, const float *__re
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < nfrag * 64; e += gridDim.x * blockDim.x) {
         const int lane = e & 63, fr = e >> 6;
         const int q = lane >> 4, i = lane & 15;
-        const int mt = fr % MT, j = (fr / MT) % NK, f = (fr / (MT * NK)) % 4, a = fr / (MT * NK * 4);
+        const int mt = fr % MT, j = (fr / MT) % NK, f = (fr / (MT * NK)) % NF, a = fr / (MT * NK * NF);
         const int row = finc_tile_row(MTB, mt, i), col = 4 * j + q;
         double v = 0.0;
         if (row < Cq && col < Cq) {
             const int oc = transpose ? col : row, ic = transpose ? row : col;
             const float *w3 = wg + ((size_t)oc * Cq + ic) * 9 + (2 - a) * 3;      // g_k = w[o, i, KH-1-a, k]
             const double g0 = w3[0], g1 = w3[1], g2 = w3[2];
-            v = f == 0 ? g0 : f == 1 ? 0.5 * (g0 + g1 + g2) : f == 2 ? 0.5 * (g0 - g1 + g2) : g2;
+            if (NF == 4) v = f == 0 ? g0 : f == 1 ? 0.5 * (g0 + g1 + g2) : f == 2 ? 0.5 * (g0 - g1 + g2) : g2;
+            else
+                v = f == 0 ? g0 / 4.0 : f == 1 ? -(g0 + g1 + g2) / 6.0 : f == 2 ? -(g0 - g1 + g2) / 6.0
+                  : f == 3 ? g0 / 24.0 + g1 / 12.0 + g2 / 6.0 : f == 4 ? g0 / 24.0 - g1 / 12.0 + g2 / 6.0 : g2;
             if (scale) v *= (double)scale[g * Cq + row];
         }
         packed[((size_t)g * npack + fr) * 64 + lane] = (float)v;
@@ -324,13 +567,17 @@ __global__ void wino_pack_kernel(const float *__restrict__ wc, const float *__re
 
 typedef void (*wino_fn)(const float *, const float *, float *, int, int, int, int, int, int, unsigned, int, int);
 struct WInst {
-    int cqp, mt, mtb, nk, npack;
-    wino_fn fn;
+    int cqp, mt, mtb, nk, npack, npack4;          // npack: the F(2,3) bank, npack4: the F(4,3) bank behind it
+    wino_fn fn, fn4;
 };
 template <int CQP>
-constexpr WInst make_winst() { return WInst{CQP, WCfg<CQP>::MT, WCfg<CQP>::MTB, WCfg<CQP>::NK, WCfg<CQP>::NPACK, finc_wino_kernel<CQP>}; }
+constexpr WInst make_winst()
+{
+    return WInst{CQP, WCfg<CQP>::MT, WCfg<CQP>::MTB, WCfg<CQP>::NK, WCfg<CQP>::NPACK, WCfg<CQP, 4>::NPACK, finc_wino_kernel<CQP>, finc_wino4_kernel<CQP>};
+}
 
-// banks whose 12 * NK * MT fragments fit the accumulation registers of one wave
+// banks whose fragments (12 * NK * MT for F(2,3), two waves per SIMD; 18 * NK * MT for F(4,3), one wave per SIMD) fit the
+// accumulation registers
 const WInst g_winsts[] = {make_winst<4>(), make_winst<8>(), make_winst<12>(), make_winst<16>(), make_winst<20>(), make_winst<24>()};
 
 const WInst *find_winst(int Cq)
@@ -341,11 +588,17 @@ const WInst *find_winst(int Cq)
     return nullptr;
 }
 
-// FINC_NO_WINO=1 keeps the forward on the direct strip kernel (A/B timing, tests of that path)
+// FINC_NO_WINO=1 keeps the forward on the direct strip kernel (A/B timing, tests of that path); FINC_WINO_FORM=2|4 pins the
+// Winograd form (A/B timing, tests of each form)
 bool finc_no_wino()
 {
     static const bool off = [] { const char *e = getenv("FINC_NO_WINO"); return e && e[0] == '1'; }();
     return off;
+}
+int finc_wino_forced_form()
+{
+    static const int f = [] { const char *e = getenv("FINC_WINO_FORM"); return e ? atoi(e) : 0; }();
+    return f == 2 || f == 4 ? f : 0;
 }
 
 } // namespace
@@ -354,7 +607,7 @@ size_t finc_wino_packed_bytes(int G, int Cq, int KH, int KW)
 {
     if (KH != 3 || KW != 3) return 0;
     const WInst *i = find_winst(Cq);
-    return i ? (size_t)G * i->npack * 64 * sizeof(float) : 0;
+    return i ? (size_t)G * (i->npack + i->npack4) * 64 * sizeof(float) : 0;
 }
 
 bool finc_wino_takes(const float *in, const float *out, const FincShape &s)
@@ -364,16 +617,31 @@ bool finc_wino_takes(const float *in, const float *out, const FincShape &s)
     return ((((uintptr_t)in) | ((uintptr_t)out)) & 15u) == 0;             // a row arrives as 16-byte windows
 }
 
+// Which form a call runs: F(4,3) has 1.33x fewer MFMAs but runs one wave per SIMD over strips of 64 columns, so it wants
+// (a) its lanes filled -- the last strip of a row at least three quarters wide -- and (b) about a wave per SIMD from whole-height
+// strips; below that F(2,3)'s strips of 32 columns cut the work finer.
+int finc_wino_form(const FincShape &s)
+{
+    if (const int f = finc_wino_forced_form()) return f;
+    const int NS4 = (s.W + 63) / 64;
+    const int tail = s.W - (NS4 - 1) * 64;                                 // columns of the last strip
+    const long long waves4 = (long long)s.B * s.G * NS4;
+    return (tail > 48 && waves4 >= 768) ? 4 : 2;
+}
+
 int finc_wino_pack(const float *wc, void *packed, int G, int Cq, bool transpose, hipStream_t st, const float *scale, const float *shift)
 {
     const WInst *i = find_winst(Cq);
     if (!i) return FINC_ERR_UNSUPPORTED;
-    const int total = 12 * i->nk * i->mt * 64;
-    int blocks = (total + 255) / 256;
-    if (blocks > 64) blocks = 64;
-    hipLaunchKernelGGL(wino_pack_kernel, dim3(blocks, G), dim3(256), 0, st, wc, scale, shift, (float *)packed, Cq, i->mt, i->mtb, i->nk,
-                       transpose ? 1 : 0);
-    FINC_CHECK_LAUNCH();
+    for (int NF = 4; NF <= 6; NF += 2) {
+        const int total = 3 * NF * i->nk * i->mt * 64;
+        int blocks = (total + 255) / 256;
+        if (blocks > 64) blocks = 64;
+        float *dst = (float *)packed + (NF == 4 ? 0 : (size_t)G * i->npack * 64);
+        hipLaunchKernelGGL(wino_pack_kernel, dim3(blocks, G), dim3(256), 0, st, wc, scale, shift, dst, Cq, i->mt, i->mtb, i->nk, NF,
+                           transpose ? 1 : 0);
+        FINC_CHECK_LAUNCH();
+    }
     return FINC_OK;
 }
 
@@ -381,16 +649,21 @@ int finc_wino_launch(const float *in, const void *packed, float *out, const Finc
 {
     const WInst *i = find_winst(s.Cq);
     if (!i) return FINC_ERR_UNSUPPORTED;
-    const int NS = (s.W + 31) / 32;
+    const bool f4 = finc_wino_form(s) == 4;
+    const int NS = f4 ? (s.W + 63) / 64 : (s.W + 31) / 32;
     const long long waves = (long long)s.B * s.G * NS;
-    int nrc = waves >= 2048 ? 1 : waves >= 1024 ? 2 : (int)((1024 + waves - 1) / waves);
+    // F(2,3): two waves per SIMD; F(4,3): one
+    const long long fill = f4 ? 1024 : 2048;
+    int nrc = waves >= fill ? 1 : waves >= fill / 2 ? 2 : (int)((fill / 2 + waves - 1) / waves);
     if (nrc > s.H / 4) nrc = s.H / 4 > 0 ? s.H / 4 : 1;
     const int RC = (s.H + nrc - 1) / nrc;
     nrc = (s.H + RC - 1) / RC;
     static const int skew_mask = getenv("FINC_WINO_SKEW") ? atoi(getenv("FINC_WINO_SKEW")) : 0;          // (experiment switches)
     static const int skew_sleep = getenv("FINC_WINO_SLEEP") ? atoi(getenv("FINC_WINO_SLEEP")) : 2;
-    hipLaunchKernelGGL(i->fn, dim3(s.B * s.G * NS, nrc), dim3(64), (size_t)2 * 4 * i->nk * 256 + (size_t)i->mt * 1024, st, in, (const float *)packed, out, s.G,
-                       s.Cq, s.H, s.W, NS, RC, s.orient, skew_mask, skew_sleep);
+    const float *bank = (const float *)packed + (f4 ? (size_t)s.G * i->npack * 64 : 0);
+    const size_t lds = f4 ? (size_t)2 * i->nk * 64 * 24 + (size_t)i->mt * 1024 : (size_t)2 * 4 * i->nk * 256 + (size_t)i->mt * 1024;
+    hipLaunchKernelGGL(f4 ? i->fn4 : i->fn, dim3(s.B * s.G * NS, nrc), dim3(64), lds, st, in, bank, out, s.G, s.Cq, s.H, s.W, NS, RC,
+                       s.orient, skew_mask, skew_sleep);
     FINC_CHECK_LAUNCH();
     return FINC_OK;
 }
