@@ -22,7 +22,7 @@ SYMBOLS = [
     "finc_canonicalize_weights_f64", "finc_inverse_f64", "finc_forward_f64",
     "finc_inverse_kernel_variant", "finc_debug_attr_table_insert", "finc_debug_inverse_table_row",
     "finc_mix_supported_f32", "finc_mix_f32", "finc_pack_forward_weights_affine_f32", "finc_debug_hlp_timeouts",
-    "finc_build_flags", "finc_inverse_packed_premultiplied_f32", "finc_inverse_premultiplied_supported", "finc_clear_fault", "finc_debug_backward_variant",
+    "finc_build_flags", "finc_inverse_packed_premultiplied_f32", "finc_inverse_premultiplied_supported", "finc_clear_fault", "finc_debug_backward_variant", "finc_debug_set_forward_form",
 ]
 
 _lib = None
@@ -80,6 +80,7 @@ def lib():
     L.finc_debug_inverse_table_row.argtypes = [i, ctypes.POINTER(ctypes.c_int)]
     L.finc_debug_hlp_timeouts.argtypes = [ctypes.POINTER(ctypes.c_uint)]
     L.finc_debug_backward_variant.argtypes = [i, i, i, i, i, i, i, ctypes.POINTER(ctypes.c_int)]
+    L.finc_debug_set_forward_form.argtypes = [i]
     L.finc_mix_supported_f32.argtypes = [i]
     L.finc_mix_f32.argtypes = [vp, vp, vp, vp, i, i, i, vp]
     for name in SYMBOLS:
@@ -109,6 +110,12 @@ def backward_variant(B, G, Cq, H, W, KH, KW):
     form = "scalar" if info[1] == 0 else ("strip", "strip16", "winograd", "msplit", "winograd4")[info[2]]
     return {"gradw": ("direct", "dword", "staged", "tiled")[info[0]], "gradx_waves": info[1], "gradx_staged": bool(info[2]),
             "conv_form": form}
+
+
+def set_forward_form(form):
+    """Pin the 3x3 forward / grad-input kernel family for this process: 0 library's choice, 1 strip kernel, 2 Winograd F(2,3),
+    4 Winograd F(4,3) (tests, A/B timing)."""
+    check(lib().finc_debug_set_forward_form(int(form)), "finc_debug_set_forward_form")
 
 
 def build_flags():

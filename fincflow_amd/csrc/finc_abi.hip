@@ -458,6 +458,8 @@ int finc_debug_backward_variant(int B, int G, int Cq, int H, int W, int KH, int 
     return FINC_OK;
 }
 
+int finc_debug_set_forward_form(int form) { return finc_wino_set_form(form); }
+
 int finc_debug_hlp_timeouts(unsigned *h_count)
 {
     if (!h_count) return FINC_ERR_NULL_POINTER;

@@ -120,6 +120,7 @@ bool finc_wino_takes(const float *in, const float *out, const FincShape &s);
 int finc_wino_pack(const float *wc, void *packed, int G, int Cq, bool transpose, hipStream_t st, const float *scale, const float *shift);
 int finc_wino_launch(const float *in, const void *packed, float *out, const FincShape &s, hipStream_t st);
 int finc_wino_form(const FincShape &s);                                // 2: F(2,3), 4: F(4,3) -- which of the two a call runs
+int finc_wino_set_form(int form);                                      // 0 library's choice, 1 strip kernel, 2 F(2,3), 4 F(4,3)
 unsigned finc_build_flags_wino();
 size_t finc_gradw_workspace_bytes(const FincShape &s); // 0: no MFMA grad-weight kernel for this shape
 int finc_gradw_launch(const float *gz, const float *x, float *gw, void *workspace, const FincShape &s, hipStream_t st);

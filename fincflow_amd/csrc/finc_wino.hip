@@ -26,6 +26,8 @@
 
 #include <stdlib.h>
 
+#include <atomic>
+
 #include <type_traits>
 #include <utility>
 
@@ -41,7 +43,9 @@ constexpr unsigned OFF_BAD_CHANNEL = 0x40000000u;
 template <int I>
 using IC = std::integral_constant<int, I>;
 #define FINC_SB() __builtin_amdgcn_sched_barrier(0)
+#define FINC_SB4() do { if constexpr (!(FINC_WINO_ABLATE & 256)) __builtin_amdgcn_sched_barrier(0); } while (0)   // (256: F(4,3) without its scheduling barriers)
 #ifndef FINC_WINO_ABLATE   // timing-only bits (results wrong): 1 no loads, 2 no stores, 4 no MFMAs of the row taps 1 and 2, 8 no LDS slots
+                           // (F(4,3): 8 no LDS reads, 16 no output transform, 32 no input transform, 64 no LDS writes)
 #define FINC_WINO_ABLATE 0
 #endif
 
@@ -382,23 +386,38 @@ __device__ __forceinline__ void wino4_walk(const __amdgpu_buffer_rsrc_t rin, con
 
     float Vc[NF][NK];
     for (int i = lane; i < 2 * NK * 64 * 6; i += 64) vlds[i] = 0.f;
-    v4u nx[NK];                                           // the next row: this lane's quad ...
-    v2u nl[NK];                                           // ... and the pair left of it (memory order)
-    auto issue = [&](int h) {
+    // two rows in flight (buffer = row parity): a row's loads are issued two steps before its transform -- with one row in
+    // flight a step (3.5 us at c3) did not always cover the load latency of a chip whose 1,024 waves all fetch at once
+    v4u nx[2][NK];                                        // rows h+1, h+2: this lane's quad ...
+    v2u nl[2][NK];                                        // ... and the pair left of it (memory order)
+    auto issue = [&](auto buf_c, int h) {
+        constexpr int BUF = decltype(buf_c)::value;
         const unsigned ro = rowoff(h);
+        if constexpr (FINC_WINO_ABLATE & 1) {
+#pragma unroll
+            for (int j = 0; j < NK; ++j) { nx[BUF][j] = (v4u){ro, ro + 1u, ro + 2u, (unsigned)j}; nl[BUF][j] = (v2u){ro + 3u, ro + 5u}; }
+            return;
+        }
 #pragma unroll
         for (int j = 0; j < NK; ++j) {
-            nx[j] = __builtin_amdgcn_raw_buffer_load_b128(rin, ro + (j == NK - 1 ? lin1 : lin0), 4 * j * HW * 4, 0);
-            nl[j] = __builtin_amdgcn_raw_buffer_load_b64(rin, ro + (j == NK - 1 ? ll1 : ll0), 4 * j * HW * 4, 0);
+            nx[BUF][j] = __builtin_amdgcn_raw_buffer_load_b128(rin, ro + (j == NK - 1 ? lin1 : lin0), 4 * j * HW * 4, 0);
+            nl[BUF][j] = __builtin_amdgcn_raw_buffer_load_b64(rin, ro + (j == NK - 1 ? ll1 : ll0), 4 * j * HW * 4, 0);
         }
     };
-    auto transform = [&]() {
+    auto transform = [&](auto buf_c) {
+        constexpr int BUF = decltype(buf_c)::value;
 #pragma unroll
         for (int j = 0; j < NK; ++j) {
             // canonical order = memory order, or mirrored when the group is W-flipped
-            const float d0 = __builtin_bit_cast(float, FW ? nl[j].y : nl[j].x), d1 = __builtin_bit_cast(float, FW ? nl[j].x : nl[j].y);
-            const float d2 = __builtin_bit_cast(float, FW ? nx[j].w : nx[j].x), d3 = __builtin_bit_cast(float, FW ? nx[j].z : nx[j].y);
-            const float d4 = __builtin_bit_cast(float, FW ? nx[j].y : nx[j].z), d5 = __builtin_bit_cast(float, FW ? nx[j].x : nx[j].w);
+            const v4u m = nx[BUF][j];
+            const v2u l = nl[BUF][j];
+            const float d0 = __builtin_bit_cast(float, FW ? l.y : l.x), d1 = __builtin_bit_cast(float, FW ? l.x : l.y);
+            const float d2 = __builtin_bit_cast(float, FW ? m.w : m.x), d3 = __builtin_bit_cast(float, FW ? m.z : m.y);
+            const float d4 = __builtin_bit_cast(float, FW ? m.y : m.z), d5 = __builtin_bit_cast(float, FW ? m.x : m.w);
+            if constexpr (FINC_WINO_ABLATE & 32) {
+                Vc[0][j] = d0; Vc[1][j] = d1; Vc[2][j] = d2; Vc[3][j] = d3; Vc[4][j] = d4; Vc[5][j] = d5;
+                continue;
+            }
             const float t1 = __builtin_fmaf(-4.f, d2, d4), t2 = __builtin_fmaf(-4.f, d1, d3);
             const float t3 = d4 - d2, t4 = d3 - d1;
             Vc[0][j] = __builtin_fmaf(4.f, d0, __builtin_fmaf(-5.f, d2, d4));
@@ -411,6 +430,7 @@ __device__ __forceinline__ void wino4_walk(const __amdgpu_buffer_rsrc_t rin, con
     };
     auto keep = [&](auto par_c) {                                         // Vc -> the slot of this row's parity
         constexpr int PAR = decltype(par_c)::value;
+        if constexpr (FINC_WINO_ABLATE & 64) return;
 #pragma unroll
         for (int j = 0; j < NK; ++j) {
             vA[(PAR * NK + j) * 64 + lane] = (v4f){Vc[0][j], Vc[1][j], Vc[2][j], Vc[3][j]};
@@ -427,11 +447,10 @@ __device__ __forceinline__ void wino4_walk(const __amdgpu_buffer_rsrc_t rin, con
     const int r0 = blockIdx.y * RC, r1 = r0 + RC < H ? r0 + RC : H;       // output rows of this chunk
     auto step = [&](auto slot_c, int h) {                                 // row h sits in nx / nl; S = h's parity
         constexpr int S = decltype(slot_c)::value;
-        transform();
-        FINC_SB();
-        issue(h + 1);                                                     // (lands during this step's MFMAs)
-        FINC_SB();
-        if (h < r0) { keep(slot_c); return; }                             // (filling the slots of a chunk: no output row)
+        transform(slot_c);
+        FINC_SB4();
+        issue(slot_c, h + 2);                                             // (into the buffer this row just left)
+        FINC_SB4();
         // (frequency 1 enters all four outputs with weight +1: its accumulators start from the shift)
         v4f acc[NF][MT];
 #pragma unroll
@@ -442,6 +461,11 @@ __device__ __forceinline__ void wino4_walk(const __amdgpu_buffer_rsrc_t rin, con
         float vb[2][NF];
         auto fetch = [&](int t, float (&dst)[NF]) {                        // t = (a-1)*NK + j, a = 1, 2
             const int a = 1 + t / NK, j = t % NK, slot = (S + a) & 1;      // (row h-a has the parity of h+a)
+            if constexpr (FINC_WINO_ABLATE & 8) {
+#pragma unroll
+                for (int f = 0; f < NF; ++f) dst[f] = Vc[f][j];
+                return;
+            }
             const v4f lo = vA[(slot * NK + j) * 64 + lane];
             const v2f hi = vB[(slot * NK + j) * 64 + lane];
             dst[0] = lo.x; dst[1] = lo.y; dst[2] = lo.z; dst[3] = lo.w; dst[4] = hi.x; dst[5] = hi.y;
@@ -454,28 +478,28 @@ __device__ __forceinline__ void wino4_walk(const __amdgpu_buffer_rsrc_t rin, con
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) mma(acc[f][mt], (0 * NF + f) * NK + j, mt, Vc[f][j]);
         }
-        FINC_SB();
+        FINC_SB4();
 #pragma unroll
-        for (int t = 0; t < 2 * NK; ++t) {
+        for (int t = 0; t < ((FINC_WINO_ABLATE & 4) ? 0 : 2 * NK); ++t) {
             if (t + 1 < 2 * NK) fetch(t + 1, vb[(t + 1) & 1]);
             const int a = 1 + t / NK, j = t % NK;
 #pragma unroll
             for (int f = 0; f < NF; ++f)
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) mma(acc[f][mt], (a * NF + f) * NK + j, mt, vb[t & 1][f]);
-            FINC_SB();
+            FINC_SB4();
         }
         keep(slot_c);                                                     // (row h-2 has been read for the last time)
         // output transform and stores: one quad per output register and lane -- 16 lanes write 256 contiguous bytes
-        const unsigned ro = rowoff(h);
+        const unsigned ro = (FINC_WINO_ABLATE & 2) ? (h == 12345 ? 0u : OFF_INVALID) : rowoff(h);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) {
             const v4f s1 = acc[1][mt] + acc[2][mt], e1 = acc[1][mt] - acc[2][mt];
             const v4f s2 = acc[3][mt] + acc[4][mt], e2 = acc[3][mt] - acc[4][mt];
-            const v4f y0 = acc[0][mt] + s1 + s2;
-            const v4f y1 = e1 + 2.f * e2;
-            const v4f y2 = s1 + 4.f * s2;
-            const v4f y3 = e1 + 8.f * e2 + acc[5][mt];
+            const v4f y0 = (FINC_WINO_ABLATE & 16) ? acc[0][mt] + acc[4][mt] : acc[0][mt] + s1 + s2;
+            const v4f y1 = (FINC_WINO_ABLATE & 16) ? acc[1][mt] : e1 + 2.f * e2;
+            const v4f y2 = (FINC_WINO_ABLATE & 16) ? acc[2][mt] : s1 + 4.f * s2;
+            const v4f y3 = (FINC_WINO_ABLATE & 16) ? acc[3][mt] + acc[5][mt] : e1 + 8.f * e2 + acc[5][mt];
             if (mt < MTB) {
                 const float a0[4] = {y0.x, y0.y, y0.z, y0.w}, a1[4] = {y1.x, y1.y, y1.z, y1.w};
                 const float a2[4] = {y2.x, y2.y, y2.z, y2.w}, a3[4] = {y3.x, y3.y, y3.z, y3.w};
@@ -501,12 +525,31 @@ __device__ __forceinline__ void wino4_walk(const __amdgpu_buffer_rsrc_t rin, con
             }
         }
     };
+    // Rows r0-2, r0-1 fill the slots (no output row).  The walk below is shaped for the compiler's wait-count pass: a step
+    // waits for ITS row's loads with the stores of the row before still in flight (vmcnt = the number of those stores) only
+    // if every path into the step has issued the same loads and stores in the same order -- with the fill steps inside the
+    // loop it fell back to vmcnt(0) and every step waited for the previous row's stores to reach memory (47 of 245 us at c3).
+    // So: fill steps apart, the first output row peeled, then pairs (slot parities 1, 0), then the odd row left over.
+    auto fill = [&](auto slot_c, int h) {
+        transform(slot_c);
+        FINC_SB4();
+        issue(slot_c, h + 2);
+        FINC_SB4();
+        keep(slot_c);
+    };
     const int hs = r0 - 2;
-    issue(hs);
-    for (int h = hs; h < r1; h += 2) {
-        step(IC<0>{}, h);
-        if (h + 1 < r1) step(IC<1>{}, h + 1);
+    issue(IC<0>{}, hs);
+    issue(IC<1>{}, hs + 1);
+    fill(IC<0>{}, hs);
+    fill(IC<1>{}, hs + 1);
+    int h = r0;
+    step(IC<0>{}, h);
+    ++h;
+    for (; h + 1 < r1; h += 2) {
+        step(IC<1>{}, h);
+        step(IC<0>{}, h + 1);
     }
+    if (h < r1) step(IC<1>{}, h);
 }
 
 // grid = (B*G*NS strips of 64 columns, row chunks); one wavefront each; 2 * NK * 64 * 24 + MT * 1024 bytes of LDS
@@ -589,15 +632,19 @@ const WInst *find_winst(int Cq)
 }
 
 // FINC_NO_WINO=1 keeps the forward on the direct strip kernel (A/B timing, tests of that path); FINC_WINO_FORM=2|4 pins the
-// Winograd form (A/B timing, tests of each form)
+// Winograd form; finc_debug_set_forward_form() does either at run time (tests of each form on one shape, in one process)
+std::atomic<int> g_form_override{0};               // 0: none, 1: direct strip kernel, 2: F(2,3), 4: F(4,3)
 bool finc_no_wino()
 {
     static const bool off = [] { const char *e = getenv("FINC_NO_WINO"); return e && e[0] == '1'; }();
-    return off;
+    const int o = g_form_override.load(std::memory_order_relaxed);
+    return o ? o == 1 : off;
 }
 int finc_wino_forced_form()
 {
     static const int f = [] { const char *e = getenv("FINC_WINO_FORM"); return e ? atoi(e) : 0; }();
+    const int o = g_form_override.load(std::memory_order_relaxed);
+    if (o == 2 || o == 4) return o;
     return f == 2 || f == 4 ? f : 0;
 }
 
@@ -618,15 +665,15 @@ bool finc_wino_takes(const float *in, const float *out, const FincShape &s)
 }
 
 // Which form a call runs: F(4,3) has 1.33x fewer MFMAs but runs one wave per SIMD over strips of 64 columns, so it wants
-// (a) its lanes filled -- the last strip of a row at least three quarters wide -- and (b) about a wave per SIMD from whole-height
-// strips; below that F(2,3)'s strips of 32 columns cut the work finer.
+// (a) its lanes filled -- at least three quarters of the columns its strips cover are image -- and (b) enough whole-height
+// strips: measured (profiles/r03/notes/winograd.md) it wins from 384 strips up (Cq = 24, 64x64: B = 96: 120 vs 140 us; B = 64,
+// 256 strips: 109 vs 85 us the other way); below that F(2,3)'s strips of 32 columns cut the work finer.
 int finc_wino_form(const FincShape &s)
 {
     if (const int f = finc_wino_forced_form()) return f;
     const int NS4 = (s.W + 63) / 64;
-    const int tail = s.W - (NS4 - 1) * 64;                                 // columns of the last strip
     const long long waves4 = (long long)s.B * s.G * NS4;
-    return (tail > 48 && waves4 >= 768) ? 4 : 2;
+    return (4 * s.W >= 3 * NS4 * 64 && waves4 >= 384) ? 4 : 2;
 }
 
 int finc_wino_pack(const float *wc, void *packed, int G, int Cq, bool transpose, hipStream_t st, const float *scale, const float *shift)
@@ -665,6 +712,13 @@ int finc_wino_launch(const float *in, const void *packed, float *out, const Finc
     hipLaunchKernelGGL(f4 ? i->fn4 : i->fn, dim3(s.B * s.G * NS, nrc), dim3(64), lds, st, in, bank, out, s.G, s.Cq, s.H, s.W, NS, RC,
                        s.orient, skew_mask, skew_sleep);
     FINC_CHECK_LAUNCH();
+    return FINC_OK;
+}
+
+int finc_wino_set_form(int form)
+{
+    if (form != 0 && form != 1 && form != 2 && form != 4) return FINC_ERR_BAD_DIMS;
+    g_form_override.store(form, std::memory_order_relaxed);
     return FINC_OK;
 }
 

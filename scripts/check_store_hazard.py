@@ -74,8 +74,8 @@ def scan(text):
     return findings
 
 
-def main():
-    lib = sys.argv[1] if len(sys.argv) > 1 else os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "fincflow_amd", "libfinc_hip.so")
+def main(lib=None):
+    lib = lib or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "fincflow_amd", "libfinc_hip.so")
     bad = []
     with tempfile.TemporaryDirectory() as d:
         shutil.copy(lib, os.path.join(d, "l.so"))
@@ -85,7 +85,7 @@ def main():
         n = 0
         for f in objs:
             text = subprocess.run([f"{LLVM}/llvm-objdump", "-d", "--no-show-raw-insn", f], cwd=d, capture_output=True, text=True).stdout
-            n += len(WIDE.findall(text)) if False else sum(1 for l in text.splitlines() if WIDE.match(l.split("//")[0]))
+            n += sum(1 for l in text.splitlines() if WIDE.match(l.split("//")[0]))
             bad += scan(text)
     print(f"{n} wide stores checked, {len(bad)} followed too closely by a write of their data registers")
     for k, st, nx, ws in bad:
@@ -95,4 +95,4 @@ def main():
 
 
 if __name__ == "__main__":
-    sys.exit(main())
+    sys.exit(main(sys.argv[1] if len(sys.argv) > 1 else None))

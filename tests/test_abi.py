@@ -173,3 +173,24 @@ def test_kernel_attribute_table_is_keyed_by_device_and_kernel():
     [x.start() for x in th]
     [x.join() for x in th]
     assert sorted(got) == [0] * 7 + [1]                         # exactly one thread sets it
+
+
+def test_no_wide_store_is_overwritten_behind_its_back():
+    """gfx950 hazard found in round 3: a buffer_store_dwordx3/x4 whose channel offset rides in an SGPR reads its data registers
+    a few cycles after issue, and the compiler inserts no wait state for that form -- an instruction that overwrites those
+    registers right behind the store makes it write stale lanes (the F(4,3) forward at Cq = 12 lost the second dword of lanes
+    12..15).  scripts/check_store_hazard.py disassembles every kernel of the in-tree library and must find no such pair; it
+    also checks its own detector on a synthetic listing."""
+    import importlib.util
+    import shutil
+    spec = importlib.util.spec_from_file_location("check_store_hazard", os.path.join(REPO, "scripts", "check_store_hazard.py"))
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+    bad = chk.scan("0000 <k>:\n\tbuffer_store_dwordx4 v[112:115], v136, s[24:27], s34 offen // 0\n\tv_pk_add_f32 v[112:113], v[44:45], v[48:49]\n")
+    assert len(bad) == 1 and bad[0][0] == "k"
+    ok = chk.scan("0000 <k>:\n\tbuffer_store_dwordx4 v[112:115], v136, s[24:27], 0 offen\n\ts_nop 1\n\tv_pk_add_f32 v[112:113], v[44:45], v[48:49]\n")
+    assert ok == []
+    assert chk.scan("0000 <k>:\n\tbuffer_store_dwordx2 v[2:3], v1, s[0:3], s9 offen\n\tv_mov_b32_e32 v2, 0\n") == []   # (64-bit stores: no hazard)
+    if not shutil.which(os.path.join(chk.LLVM, "llvm-objdump")):
+        pytest.skip("no llvm-objdump in this image")
+    assert chk.main() == 0

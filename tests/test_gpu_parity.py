@@ -922,3 +922,65 @@ def test_unaligned_activations_fall_back(dev):
         assert st == (0 if split else 7)   # FINC_ERR_ALIGNMENT
         if split:
             assert rel_err(xbuf[1:n + 1].cpu().numpy().reshape(z.shape), oracle.inverse_via_f64(z, wco)) <= 1e-5
+
+
+# (B, C, H, W): every bank of the Winograd kernels (Cq = 4 .. 24, padded channel counts among them), widths that fill one,
+# two and three strips of 64 columns and leave a partial last strip, maps shorter than the two-row prologue, row chunks
+FORWARD_FORM_CASES = [(2, 96, 20, 64), (3, 80, 9, 60), (2, 64, 12, 128), (2, 48, 64, 64), (5, 32, 7, 68), (2, 16, 16, 136),
+                      (1, 88, 5, 64), (2, 40, 1, 4), (4, 12, 2, 8), (1, 92, 33, 196)]
+
+
+@pytest.mark.parametrize("shape", FORWARD_FORM_CASES, ids=lambda c: "B%d_C%d_%dx%d" % c)
+def test_forward_forms_agree_with_fp64_conv(shape, dev):
+    """The 3x3 forward / grad-input has three kernel families: the direct strip kernel, Winograd F(2,3) and F(4,3) along W
+    (layers/conv.py:102-107 is free to run any exact reformulation: cuDNN does).  Each one, pinned through
+    finc_debug_set_forward_form, is held to BASELINE.json's 1e-5 against fp64 F.pad + F.conv2d autograd on the CPU (forward and
+    grad-input, all four corner orientations of a FastFlowUnit), with the output-side affine fold (scale + shift) on top;
+    F(4,3)'s constants cost accuracy (2-3e-6 against 5e-7): the margin is asserted, not assumed."""
+    import torch.nn.functional as F
+    from fincflow_amd import FastFlowUnit, _lib
+    B, C, H, W = shape
+    torch.manual_seed(sum(shape))
+    unit = FastFlowUnit(C, C, 3).to(dev)
+    x = torch.randn(B, C, H, W, device=dev)
+    gz = torch.randn(B, C, H, W, device=dev)
+    xd = x.detach().cpu().double().requires_grad_(True)
+    ref = torch.cat([F.conv2d(F.pad(c, m.pad), m.conv.weight.detach().cpu().double()) for m, c in
+                     zip((unit.conv_tl, unit.conv_tr, unit.conv_bl, unit.conv_br), torch.chunk(xd, 4, 1))], 1)
+    ref.backward(gz.cpu().double())
+    log_scale, translation = 0.3 * torch.randn(C, device=dev), torch.randn(C, device=dev)
+    # (ActNorm.forward behind the unit, layers/actnorm.py:39-46: (z - translation) * exp(-log_scale))
+    ref_aff = (ref.detach() - translation.cpu().double().view(1, -1, 1, 1)) * torch.exp(-log_scale).cpu().double().view(1, -1, 1, 1)
+    want = {1: ("strip", "strip16"), 2: ("winograd",), 4: ("winograd4",)}
+    worst = {}
+    try:
+        for form in (1, 2, 4):
+            _lib.set_forward_form(form)
+            assert _lib.backward_variant(B, 4, C // 4, H, W, 3, 3)["conv_form"] in want[form]
+            xg = x.clone().requires_grad_(True)
+            z, logdet = unit(xg)
+            z.backward(gz)
+            assert logdet == 0.0
+            e_f = rel_err(z.detach().cpu().numpy(), ref.detach().numpy())
+            e_g = rel_err(xg.grad.cpu().numpy(), xd.grad.numpy())
+            with torch.no_grad():
+                fused = unit.forward_affine(x, log_scale, translation)
+            assert fused is not None
+            e_a = rel_err(fused.cpu().numpy(), ref_aff.numpy())
+            worst[form] = max(e_f, e_g, e_a)
+            assert worst[form] <= TOL, (form, e_f, e_g, e_a)
+    finally:
+        _lib.set_forward_form(0)
+    report("forward_forms", shape=list(shape), strip=worst[1], f23=worst[2], f43=worst[4])
+    assert worst[4] <= 6e-6                                   # (F(4,3): observed <= 3.5e-6)
+
+
+def test_forward_form_the_library_picks(dev):
+    """F(4,3) where strips of 64 columns are at least three quarters image and there are 384 of them or more (c3 and its
+    strong-split shares down to 96 images); F(2,3) otherwise; the strip kernel when the call cannot take Winograd at all."""
+    from fincflow_amd import _lib
+    form = lambda B, C, H, W, K=3: _lib.backward_variant(B, 4, C // 4, H, W, K, K)["conv_form"]
+    assert form(256, 96, 64, 64) == "winograd4" and form(96, 96, 64, 64) == "winograd4" and form(256, 48, 64, 64) == "winograd4"
+    assert form(64, 96, 128, 128) == "winograd4" and form(256, 96, 64, 96) == "winograd4"
+    assert form(64, 96, 64, 64) == "winograd" and form(512, 48, 32, 32) == "winograd" and form(16, 96, 128, 128) == "winograd"
+    assert form(256, 96, 64, 62) in ("strip", "strip16") and form(64, 192, 128, 128, 5) in ("strip", "strip16")
