@@ -665,15 +665,15 @@ bool finc_wino_takes(const float *in, const float *out, const FincShape &s)
 }
 
 // Which form a call runs: F(4,3) has 1.33x fewer MFMAs but runs one wave per SIMD over strips of 64 columns, so it wants
-// (a) its lanes filled -- at least three quarters of the columns its strips cover are image -- and (b) enough whole-height
-// strips: measured (profiles/r03/notes/winograd.md) it wins from 384 strips up (Cq = 24, 64x64: B = 96: 120 vs 140 us; B = 64,
-// 256 strips: 109 vs 85 us the other way); below that F(2,3)'s strips of 32 columns cut the work finer.
+// (a) its lanes filled -- at least three quarters of the columns its strips cover are image -- and (b) a wave for every SIMD
+// out of row chunks of 8 rows or more (a chunk recomputes two rows of operands).  Measured (profiles/r03/notes/winograd.md):
+// Cq = 24, 64x64: B = 32 (128 strips x 8 chunks): 40 vs 46 us, B = 16: 35 vs 27 us the other way; 128x128, B = 8: 41 vs 45 us.
 int finc_wino_form(const FincShape &s)
 {
     if (const int f = finc_wino_forced_form()) return f;
     const int NS4 = (s.W + 63) / 64;
-    const long long waves4 = (long long)s.B * s.G * NS4;
-    return (4 * s.W >= 3 * NS4 * 64 && waves4 >= 384) ? 4 : 2;
+    const long long waves4 = (long long)s.B * s.G * NS4 * (s.H >= 16 ? s.H / 8 : 1);
+    return (4 * s.W >= 3 * NS4 * 64 && waves4 >= 1024) ? 4 : 2;
 }
 
 int finc_wino_pack(const float *wc, void *packed, int G, int Cq, bool transpose, hipStream_t st, const float *scale, const float *shift)
@@ -699,9 +699,17 @@ int finc_wino_launch(const float *in, const void *packed, float *out, const Finc
     const bool f4 = finc_wino_form(s) == 4;
     const int NS = f4 ? (s.W + 63) / 64 : (s.W + 31) / 32;
     const long long waves = (long long)s.B * s.G * NS;
-    // F(2,3): two waves per SIMD; F(4,3): one
-    const long long fill = f4 ? 1024 : 2048;
-    int nrc = waves >= fill ? 1 : waves >= fill / 2 ? 2 : (int)((fill / 2 + waves - 1) / waves);
+    // F(2,3): two waves per SIMD, row chunks up to about one; F(4,3): one wave per SIMD, row chunks (of 8 rows or more: a
+    // chunk recomputes two rows of operands) up to that
+    static const int force_chunks = getenv("FINC_WINO_CHUNKS") ? atoi(getenv("FINC_WINO_CHUNKS")) : 0;   // experiment switch
+    int nrc;
+    if (f4) {
+        nrc = waves >= 1024 ? 1 : (int)((1024 + waves - 1) / waves);
+        if (nrc > s.H / 8) nrc = s.H / 8 > 0 ? s.H / 8 : 1;
+    } else {
+        nrc = waves >= 2048 ? 1 : waves >= 1024 ? 2 : (int)((1024 + waves - 1) / waves);
+    }
+    if (force_chunks > 0) nrc = force_chunks;
     if (nrc > s.H / 4) nrc = s.H / 4 > 0 ? s.H / 4 : 1;
     const int RC = (s.H + nrc - 1) / nrc;
     nrc = (s.H + RC - 1) / RC;

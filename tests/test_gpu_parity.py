@@ -976,11 +976,12 @@ def test_forward_forms_agree_with_fp64_conv(shape, dev):
 
 
 def test_forward_form_the_library_picks(dev):
-    """F(4,3) where strips of 64 columns are at least three quarters image and there are 384 of them or more (c3 and its
-    strong-split shares down to 96 images); F(2,3) otherwise; the strip kernel when the call cannot take Winograd at all."""
+    """F(4,3) where strips of 64 columns are at least three quarters image and row chunks of 8 rows or more give every SIMD a
+    wave (c3 and its strong-split shares down to 32 images); F(2,3) otherwise; the strip kernel when the call cannot take
+    Winograd at all."""
     from fincflow_amd import _lib
     form = lambda B, C, H, W, K=3: _lib.backward_variant(B, 4, C // 4, H, W, K, K)["conv_form"]
-    assert form(256, 96, 64, 64) == "winograd4" and form(96, 96, 64, 64) == "winograd4" and form(256, 48, 64, 64) == "winograd4"
-    assert form(64, 96, 128, 128) == "winograd4" and form(256, 96, 64, 96) == "winograd4"
-    assert form(64, 96, 64, 64) == "winograd" and form(512, 48, 32, 32) == "winograd" and form(16, 96, 128, 128) == "winograd"
+    assert form(256, 96, 64, 64) == "winograd4" and form(32, 96, 64, 64) == "winograd4" and form(256, 48, 64, 64) == "winograd4"
+    assert form(8, 96, 128, 128) == "winograd4" and form(256, 96, 64, 96) == "winograd4"
+    assert form(16, 96, 64, 64) == "winograd" and form(512, 48, 32, 32) == "winograd" and form(64, 48, 32, 32) == "winograd"
     assert form(256, 96, 64, 62) in ("strip", "strip16") and form(64, 192, 128, 128, 5) in ("strip", "strip16")
