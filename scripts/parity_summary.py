@@ -1,4 +1,4 @@
-"""Summarise gpurun_out/parity_report.jsonl (written by the -m gpu tests) into profiles/r02/parity_errors.json: per kind
+"""Summarise gpurun_out/parity_report.jsonl (written by the -m gpu tests) into profiles/<round>/parity_errors.json (`parity_summary.py r03`; default r02): per kind
 of test the number of cases, the worst max-normalised and element-wise errors, and every case that needed more than the 1e-5
 of BASELINE.json's north_star (with the reference's own fp32-vs-fp64 gap on that bank beside it)."""
 import collections, json, os, sys
@@ -25,6 +25,6 @@ for k, rs in by.items():
     else:
         d["records"] = rs
     out["by_kind"][k] = d
-path = os.path.join(REPO, "profiles", "r02", "parity_errors.json")
+path = os.path.join(REPO, "profiles", sys.argv[1] if len(sys.argv) > 1 else "r02", "parity_errors.json")
 json.dump(out, open(path, "w"), indent=1)
 print(json.dumps({k: {x: v[x] for x in v if x in ("cases", "worst_max_normalised", "worst_elementwise", "io_forms_launched")} for k, v in out["by_kind"].items()}, indent=1))
