@@ -294,14 +294,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2))) void fi
 
 // -----------------------------------------------------------------------------------------------
 // F(4,3) along W: FOUR neighbouring outputs of a row share six inputs -- 6 multiplies per (o, i, row tap) instead of 12 (2x
-// fewer MFMAs than the direct sum, 1.33x fewer than F(2,3)).  Interpolation points 0, +-1, +-2, infinity (Lavin & Gray):
+// fewer MFMAs than the direct sum, 1.33x fewer than F(2,3)).  Interpolation points 0, +-1, +-3/2, infinity -- the textbook
+// set (Lavin & Gray) has +-2; +-3/2 costs the same operations, every constant is still exact in fp32, and the error is
+// 1.27x smaller (numpy model of this arithmetic: profiles/r03/notes/winograd.md):
 //
 //     d[m] = x[i, h-a, wt-2+m], m = 0..5        the six columns the outputs wt .. wt+3 of row tap a read
-//     V = B^T d   = (4d0-5d2+d4, (d4-4d2)+(d3-4d1), (d4-4d2)-(d3-4d1), (d4-d2)+2(d3-d1), (d4-d2)-2(d3-d1), 4d1-5d3+d5)
-//     U = G g     = (g0/4, -(g0+g1+g2)/6, -(g0-g1+g2)/6, g0/24+g1/12+g2/6, g0/24-g1/12+g2/6, g2)       (pack kernel, fp64)
-//     y = A^T M   : y0 = M0+(M1+M2)+(M3+M4), y1 = (M1-M2)+2(M3-M4), y2 = (M1+M2)+4(M3+M4), y3 = (M1-M2)+8(M3-M4)+M5
+//     V = B^T d   = (2.25d0-3.25d2+d4, (d4-2.25d2)+-(d3-2.25d1), (d4-d2)+-1.5(d3-d1), 2.25d1-3.25d3+d5)
+//     U = G g     = (g0/2.25, -(g0+-g1+g2)/2.5, (g0+-1.5g1+2.25g2)/5.625, g2)                           (pack kernel, fp64)
+//     y = A^T M   : y0 = M0+(M1+M2)+(M3+M4), y1 = (M1-M2)+1.5(M3-M4), y2 = (M1+M2)+2.25(M3+M4), y3 = (M1-M2)+3.375(M3-M4)+M5
 //
-// The constants cost accuracy: 1.5e-6 of the largest output against 3e-7 for F(2,3) and 5e-7 for the direct fp32 sum at the c3
+// The constants cost accuracy: 1.1e-6 of the largest output against 3e-7 for F(2,3) and 5e-7 for the direct fp32 sum at the c3
 // bank (numpy model of this exact arithmetic; the GPU tests hold the kernel to 1e-5).  Mapping: one wavefront owns 16 column
 // QUADS = 64 columns of one (image, group) slab -- the whole width at 64x64 --, lane (q,p) = quad p, k-slot q; one wave per SIMD
 // (162 bank registers + 72 accumulators at Cq = 24).  A row arrives as one dwordx4 (the lane's own quad) + one dwordx2 (the pair
@@ -418,14 +420,14 @@ __device__ __forceinline__ void wino4_walk(const __amdgpu_buffer_rsrc_t rin, con
                 Vc[0][j] = d0; Vc[1][j] = d1; Vc[2][j] = d2; Vc[3][j] = d3; Vc[4][j] = d4; Vc[5][j] = d5;
                 continue;
             }
-            const float t1 = __builtin_fmaf(-4.f, d2, d4), t2 = __builtin_fmaf(-4.f, d1, d3);
+            const float t1 = __builtin_fmaf(-2.25f, d2, d4), t2 = __builtin_fmaf(-2.25f, d1, d3);
             const float t3 = d4 - d2, t4 = d3 - d1;
-            Vc[0][j] = __builtin_fmaf(4.f, d0, __builtin_fmaf(-5.f, d2, d4));
+            Vc[0][j] = __builtin_fmaf(2.25f, d0, __builtin_fmaf(-3.25f, d2, d4));
             Vc[1][j] = t1 + t2;
             Vc[2][j] = t1 - t2;
-            Vc[3][j] = __builtin_fmaf(2.f, t4, t3);
-            Vc[4][j] = __builtin_fmaf(-2.f, t4, t3);
-            Vc[5][j] = __builtin_fmaf(4.f, d1, __builtin_fmaf(-5.f, d3, d5));
+            Vc[3][j] = __builtin_fmaf(1.5f, t4, t3);
+            Vc[4][j] = __builtin_fmaf(-1.5f, t4, t3);
+            Vc[5][j] = __builtin_fmaf(2.25f, d1, __builtin_fmaf(-3.25f, d3, d5));
         }
     };
     auto keep = [&](auto par_c) {                                         // Vc -> the slot of this row's parity
@@ -497,9 +499,9 @@ __device__ __forceinline__ void wino4_walk(const __amdgpu_buffer_rsrc_t rin, con
             const v4f s1 = acc[1][mt] + acc[2][mt], e1 = acc[1][mt] - acc[2][mt];
             const v4f s2 = acc[3][mt] + acc[4][mt], e2 = acc[3][mt] - acc[4][mt];
             const v4f y0 = (FINC_WINO_ABLATE & 16) ? acc[0][mt] + acc[4][mt] : acc[0][mt] + s1 + s2;
-            const v4f y1 = (FINC_WINO_ABLATE & 16) ? acc[1][mt] : e1 + 2.f * e2;
-            const v4f y2 = (FINC_WINO_ABLATE & 16) ? acc[2][mt] : s1 + 4.f * s2;
-            const v4f y3 = (FINC_WINO_ABLATE & 16) ? acc[3][mt] + acc[5][mt] : e1 + 8.f * e2 + acc[5][mt];
+            const v4f y1 = (FINC_WINO_ABLATE & 16) ? acc[1][mt] : e1 + 1.5f * e2;
+            const v4f y2 = (FINC_WINO_ABLATE & 16) ? acc[2][mt] : s1 + 2.25f * s2;
+            const v4f y3 = (FINC_WINO_ABLATE & 16) ? acc[3][mt] + acc[5][mt] : e1 + 3.375f * e2 + acc[5][mt];
             if (mt < MTB) {
                 const float a0[4] = {y0.x, y0.y, y0.z, y0.w}, a1[4] = {y1.x, y1.y, y1.z, y1.w};
                 const float a2[4] = {y2.x, y2.y, y2.z, y2.w}, a3[4] = {y3.x, y3.y, y3.z, y3.w};
@@ -600,8 +602,8 @@ __global__ void wino_pack_kernel(const float *__restrict__ wc, const float *__re
             const double g0 = w3[0], g1 = w3[1], g2 = w3[2];
             if (NF == 4) v = f == 0 ? g0 : f == 1 ? 0.5 * (g0 + g1 + g2) : f == 2 ? 0.5 * (g0 - g1 + g2) : g2;
             else
-                v = f == 0 ? g0 / 4.0 : f == 1 ? -(g0 + g1 + g2) / 6.0 : f == 2 ? -(g0 - g1 + g2) / 6.0
-                  : f == 3 ? g0 / 24.0 + g1 / 12.0 + g2 / 6.0 : f == 4 ? g0 / 24.0 - g1 / 12.0 + g2 / 6.0 : g2;
+                v = f == 0 ? g0 / 2.25 : f == 1 ? -(g0 + g1 + g2) / 2.5 : f == 2 ? -(g0 - g1 + g2) / 2.5
+                  : f == 3 ? (g0 + 1.5 * g1 + 2.25 * g2) / 5.625 : f == 4 ? (g0 - 1.5 * g1 + 2.25 * g2) / 5.625 : g2;
             if (scale) v *= (double)scale[g * Cq + row];
         }
         packed[((size_t)g * npack + fr) * 64 + lane] = (float)v;

@@ -936,7 +936,7 @@ def test_forward_forms_agree_with_fp64_conv(shape, dev):
     (layers/conv.py:102-107 is free to run any exact reformulation: cuDNN does).  Each one, pinned through
     finc_debug_set_forward_form, is held to BASELINE.json's 1e-5 against fp64 F.pad + F.conv2d autograd on the CPU (forward and
     grad-input, all four corner orientations of a FastFlowUnit), with the output-side affine fold (scale + shift) on top;
-    F(4,3)'s constants cost accuracy (2-3e-6 against 5e-7): the margin is asserted, not assumed."""
+    F(4,3)'s constants cost accuracy (2e-6 against 5e-7): the margin is asserted, not assumed."""
     import torch.nn.functional as F
     from fincflow_amd import FastFlowUnit, _lib
     B, C, H, W = shape
@@ -972,7 +972,7 @@ def test_forward_forms_agree_with_fp64_conv(shape, dev):
     finally:
         _lib.set_forward_form(0)
     report("forward_forms", shape=list(shape), strip=worst[1], f23=worst[2], f43=worst[4])
-    assert worst[4] <= 6e-6                                   # (F(4,3): observed <= 3.5e-6)
+    assert worst[4] <= 5e-6                                   # (F(4,3), points 0, +-1, +-3/2: observed <= 2.6e-6)
 
 
 def test_forward_form_the_library_picks(dev):
