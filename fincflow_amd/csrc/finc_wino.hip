@@ -317,6 +317,7 @@ __device__ __forceinline__ void wino4_walk(const __amdgpu_buffer_rsrc_t rin, con
 {
     using C = WCfg<CQP, 4>;
     constexpr int MT = C::MT, MTB = C::MTB, NSM = C::NSM, NK = C::NK, NF = C::NF, NFRAG = C::NFRAG;
+    constexpr int NB = CQP >= 20 ? 1 : 2;                 // rows of loads in flight (see below)
     typedef float v2f __attribute__((ext_vector_type(2)));
     const int lane = threadIdx.x & 63;
     const int q = lane >> 4, p = lane & 15;
@@ -388,12 +389,14 @@ __device__ __forceinline__ void wino4_walk(const __amdgpu_buffer_rsrc_t rin, con
 
     float Vc[NF][NK];
     for (int i = lane; i < 2 * NK * 64 * 6; i += 64) vlds[i] = 0.f;
-    // two rows in flight (buffer = row parity): a row's loads are issued two steps before its transform -- with one row in
-    // flight a step (3.5 us at c3) did not always cover the load latency of a chip whose 1,024 waves all fetch at once
-    v4u nx[2][NK];                                        // rows h+1, h+2: this lane's quad ...
-    v2u nl[2][NK];                                        // ... and the pair left of it (memory order)
+    // The small banks keep TWO rows of loads in flight (buffer = row parity; a row's loads are issued two steps before its
+    // transform: their steps are shorter than the load latency of a chip whose 1,024 waves all fetch at once -- Cq = 12: -5 %,
+    // Cq = 16: -8 %).  The banks of 20 and 24 channels keep one: their step (3.5 us at c3) covers the latency, and the second
+    // buffer's 36 registers pushed the allocation to its limit (42 register-to-register copies per step).
+    v4u nx[NB][NK];                                       // rows h+1 (, h+2): this lane's quad ...
+    v2u nl[NB][NK];                                        // ... and the pair left of it (memory order)
     auto issue = [&](auto buf_c, int h) {
-        constexpr int BUF = decltype(buf_c)::value;
+        constexpr int BUF = decltype(buf_c)::value % NB;
         const unsigned ro = rowoff(h);
         if constexpr (FINC_WINO_ABLATE & 1) {
 #pragma unroll
@@ -407,7 +410,7 @@ __device__ __forceinline__ void wino4_walk(const __amdgpu_buffer_rsrc_t rin, con
         }
     };
     auto transform = [&](auto buf_c) {
-        constexpr int BUF = decltype(buf_c)::value;
+        constexpr int BUF = decltype(buf_c)::value % NB;
 #pragma unroll
         for (int j = 0; j < NK; ++j) {
             // canonical order = memory order, or mirrored when the group is W-flipped
@@ -451,7 +454,7 @@ __device__ __forceinline__ void wino4_walk(const __amdgpu_buffer_rsrc_t rin, con
         constexpr int S = decltype(slot_c)::value;
         transform(slot_c);
         FINC_SB4();
-        issue(slot_c, h + 2);                                             // (into the buffer this row just left)
+        issue(slot_c, h + NB);                                            // (into the buffer this row just left)
         FINC_SB4();
         // (frequency 1 enters all four outputs with weight +1: its accumulators start from the shift)
         v4f acc[NF][MT];
@@ -535,13 +538,13 @@ __device__ __forceinline__ void wino4_walk(const __amdgpu_buffer_rsrc_t rin, con
     auto fill = [&](auto slot_c, int h) {
         transform(slot_c);
         FINC_SB4();
-        issue(slot_c, h + 2);
+        issue(slot_c, h + NB);
         FINC_SB4();
         keep(slot_c);
     };
     const int hs = r0 - 2;
     issue(IC<0>{}, hs);
-    issue(IC<1>{}, hs + 1);
+    if constexpr (NB == 2) issue(IC<1>{}, hs + 1);
     fill(IC<0>{}, hs);
     fill(IC<1>{}, hs + 1);
     int h = r0;
