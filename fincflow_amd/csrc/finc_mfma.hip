@@ -1539,7 +1539,10 @@ const Inst g_insts[] = {
     // the same 2 problems keep all 4 SIMDs busy (1.25 -> 0.89 ms at B = 256, 64x64)
     make_inst<32, 3, 3, 2, 2>(), FINC_BOTH(32, 3, 3),
     make_inst<40, 3, 3, 2, 2>(), make_inst<40, 3, 3, 2>(), make_inst<48, 3, 3, 4>(), make_inst<64, 3, 3, 4>(),
-    FINC_BOTH(4, 2, 2),  FINC_BOTH(8, 2, 2),  FINC_BOTH(12, 2, 2), FINC_BOTH(16, 2, 2), FINC_BOTH(24, 2, 2), FINC_BOTH(32, 2, 2),
+    FINC_BOTH(4, 2, 2),  FINC_BOTH(8, 2, 2),  FINC_BOTH(12, 2, 2), FINC_BOTH(16, 2, 2), FINC_BOTH(24, 2, 2),
+    // (Cq = 32 at 2x2: as at 3x3, one wave's rings let 3 problems onto a CU; 2 waves per problem, packed in pairs: 685 -> 608 us
+    // at B = 256, 64x64)
+    make_inst<32, 2, 2, 2, 2>(), FINC_BOTH(32, 2, 2),
     FINC_BOTH(4, 5, 5),  FINC_BOTH(8, 5, 5),  FINC_BOTH(12, 5, 5), FINC_BOTH(16, 5, 5),
     // (Cq = 17 .. 24 at 5x5 -- the 20-channel 5x5 layers of fastflow/test_examples.py:218-222 -- on two waves: the operands
     // of a 5x5 filter do not rotate in place, and their ageing copies beside 450 fragments do not fit one wave)
