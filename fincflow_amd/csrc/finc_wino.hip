@@ -576,6 +576,28 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void
     else wino4_walk<CQP, false>(rin, rout, packed, vlds, g, CQ, H, W, strip, RC, fh);
 }
 
+// the same walk with TWO waves per SIMD for the banks of 4 and 8 channels (93 / 192 registers): their steps are short and
+// memory-bound, and a second tenant fills the gaps -- C = 16 at 64x64, B = 256: 30.7 -> 24.9 us (0.55 -> 0.67 of the HBM peak),
+// C = 32: 65.7 -> 58.2; at 16 channels per group (244 registers, MFMA-bound) it gains nothing (139 -> 143 us), at 12 it spills.
+// grid as above; 2 * NK * 64 * 24 + MT * 1024 bytes of LDS
+template <int CQP>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void finc_wino4t_kernel(
+    const float *__restrict__ in, const float *__restrict__ packed, float *__restrict__ out, int G, int CQ, int H, int W, int NS, int RC,
+    unsigned orient, int, int)
+{
+    extern __shared__ __attribute__((aligned(16))) float vlds[];
+    const int strip = blockIdx.x % NS, bg = blockIdx.x / NS;
+    const int g = bg % G;
+    const unsigned o = finc_group_orient(orient, g);
+    const bool fh = (o & FINC_FLIP_H) != 0, fw = (o & FINC_FLIP_W) != 0;
+    const int HW = H * W;
+    const unsigned slab_bytes = (unsigned)CQ * (unsigned)HW * 4u;
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)(in + (size_t)bg * CQ * HW), 0, (int)slab_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void *)(out + (size_t)bg * CQ * HW), 0, (int)slab_bytes, 0x00020000);
+    if (fw) wino4_walk<CQP, true>(rin, rout, packed, vlds, g, CQ, H, W, strip, RC, fh);
+    else wino4_walk<CQP, false>(rin, rout, packed, vlds, g, CQ, H, W, strip, RC, fh);
+}
+
 // -----------------------------------------------------------------------------------------------
 // Bank: U_{a,f} = filter transform of row a of the (canonical) 3x3 kernel, in the fragment layout of the strip kernels
 // (lane (q,i) of fragment (a, f, j, mt) = U[row(mt,i)][4j+q]); `transpose` swaps in/out channels (grad-input); `scale` /
@@ -614,14 +636,20 @@ __global__ void wino_pack_kernel(const float *__restrict__ wc, const float *__re
 }
 
 typedef void (*wino_fn)(const float *, const float *, float *, int, int, int, int, int, int, unsigned, int, int);
+template <int CQP>
+constexpr wino_fn finc_wino4_pick()
+{
+    if constexpr (CQP <= 8) return finc_wino4t_kernel<CQP>;
+    else return finc_wino4_kernel<CQP>;
+}
 struct WInst {
-    int cqp, mt, mtb, nk, npack, npack4;          // npack: the F(2,3) bank, npack4: the F(4,3) bank behind it
+    int cqp, mt, mtb, nk, npack, npack4;          // npack: the F(2,3) bank, npack4: the F(4,3) bank behind it (two waves per SIMD for cqp <= 8)
     wino_fn fn, fn4;
 };
 template <int CQP>
 constexpr WInst make_winst()
 {
-    return WInst{CQP, WCfg<CQP>::MT, WCfg<CQP>::MTB, WCfg<CQP>::NK, WCfg<CQP>::NPACK, WCfg<CQP, 4>::NPACK, finc_wino_kernel<CQP>, finc_wino4_kernel<CQP>};
+    return WInst{CQP, WCfg<CQP>::MT, WCfg<CQP>::MTB, WCfg<CQP>::NK, WCfg<CQP>::NPACK, WCfg<CQP, 4>::NPACK, finc_wino_kernel<CQP>, finc_wino4_pick<CQP>()};
 }
 
 // banks whose fragments (12 * NK * MT for F(2,3), two waves per SIMD; 18 * NK * MT for F(4,3), one wave per SIMD) fit the
@@ -709,7 +737,8 @@ int finc_wino_launch(const float *in, const void *packed, float *out, const Finc
     static const int force_chunks = getenv("FINC_WINO_CHUNKS") ? atoi(getenv("FINC_WINO_CHUNKS")) : 0;   // experiment switch
     int nrc;
     if (f4) {
-        nrc = waves >= 1024 ? 1 : (int)((1024 + waves - 1) / waves);
+        const long long fill4 = i->cqp <= 8 ? 2048 : 1024;                 // (the small banks: two waves per SIMD)
+        nrc = waves >= fill4 ? 1 : (int)((fill4 + waves - 1) / waves);
         if (nrc > s.H / 8) nrc = s.H / 8 > 0 ? s.H / 8 : 1;
     } else {
         nrc = waves >= 2048 ? 1 : waves >= 1024 ? 2 : (int)((1024 + waves - 1) / waves);
