@@ -1,4 +1,5 @@
-// 3x3 forward (and, with transposed fragments, grad-input) with FEWER MULTIPLIES: Winograd F(2,3) along W (gfx950 only).
+// 3x3 forward (and, with transposed fragments, grad-input) with FEWER MULTIPLIES: Winograd along W (gfx950 only) -- F(2,3),
+// described first, and F(4,3) (finc_wino4_kernel, further down), which a call runs whenever its strips of 64 columns fill the chip.
 //
 // The strip kernel of finc_conv.hip runs at ~78 % of the fp32 MFMA peak and the shape is compute-bound: the only
 // way to a faster forward is fewer multiplies.  The forward has no recurrence, so any exact reformulation of the masked
