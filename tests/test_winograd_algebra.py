@@ -1,0 +1,90 @@
+"""Host-only check of the algebra behind finc_wino.hip: the transform matrices the two Winograd kernels implement (the comments
+at the top of wino_walk / wino4_walk and the constants in their `transform` lambdas, output transforms and wino_pack_kernel) are
+restated here with exact rational arithmetic and must reproduce the direct correlation y[m] = sum_k g[k] d[m + k] -- the row
+convolution of layers/conv.py:102-107 -- for every basis pair.  A typo in a constant of the kernel's comment block shows up
+here without a GPU; the GPU tests (test_forward_forms_agree_with_fp64_conv) hold the kernels themselves to fp64 conv2d."""
+from fractions import Fraction as Fr
+
+import numpy as np
+
+F23 = dict(
+    BT=[[1, 0, -1, 0], [0, 1, 1, 0], [0, -1, 1, 0], [0, 1, 0, -1]],                       # V = (d0-d2, d1+d2, d2-d1, d1-d3)
+    G=[[1, 0, 0], [Fr(1, 2), Fr(1, 2), Fr(1, 2)], [Fr(1, 2), Fr(-1, 2), Fr(1, 2)], [0, 0, 1]],
+    AT=[[1, 1, 1, 0], [0, 1, -1, -1]],                                                    # y0 = M0+M1+M2, y1 = M1-M2-M3
+)
+b = Fr(3, 2)                                                                              # points 0, +-1, +-3/2, infinity
+F43 = dict(
+    BT=[[b * b, 0, -(1 + b * b), 0, 1, 0],                                                # 2.25 d0 - 3.25 d2 + d4
+        [0, -b * b, -b * b, 1, 1, 0],                                                     # (d4 - 2.25 d2) + (d3 - 2.25 d1)
+        [0, b * b, -b * b, -1, 1, 0],                                                     # (d4 - 2.25 d2) - (d3 - 2.25 d1)
+        [0, -b, -1, b, 1, 0],                                                             # (d4 - d2) + 1.5 (d3 - d1)
+        [0, b, -1, -b, 1, 0],                                                             # (d4 - d2) - 1.5 (d3 - d1)
+        [0, b * b, 0, -(1 + b * b), 0, 1]],                                               # 2.25 d1 - 3.25 d3 + d5
+    G=[[1 / (b * b), 0, 0],                                                               # g0 / 2.25
+       [Fr(-2, 5), Fr(-2, 5), Fr(-2, 5)], [Fr(-2, 5), Fr(2, 5), Fr(-2, 5)],               # -(g0 +- g1 + g2) / 2.5
+       [Fr(8, 45), Fr(8, 45) * b, Fr(8, 45) * b * b], [Fr(8, 45), -Fr(8, 45) * b, Fr(8, 45) * b * b],   # (g0 +- 1.5 g1 + 2.25 g2) / 5.625
+       [0, 0, 1]],
+    AT=[[1, 1, 1, 1, 1, 0], [0, 1, -1, b, -b, 0], [0, 1, 1, b * b, b * b, 0], [0, 1, -1, b ** 3, -b ** 3, 1]],
+)
+
+
+def _check(form, m, r):
+    BT, G, AT = ([[Fr(x) for x in row] for row in form[k]] for k in ("BT", "G", "AT"))
+    n = m + r - 1
+    assert len(BT) == n and len(G) == n and len(AT) == m
+    for k in range(r):                                    # filter = e_k
+        U = [G[f][k] for f in range(n)]
+        for j in range(n):                                # data = e_j
+            V = [BT[f][j] for f in range(n)]
+            for i in range(m):
+                y = sum(AT[i][f] * U[f] * V[f] for f in range(n))
+                assert y == (1 if j == i + k else 0), (k, j, i, y)
+
+
+def test_f23_matrices_are_exact():
+    _check(F23, 2, 3)
+
+
+def test_f43_matrices_are_exact():
+    _check(F43, 4, 3)
+    # every constant of the kernel's transforms is a dyadic rational: exact in fp32
+    for row in F43["BT"] + F43["AT"]:
+        for x in row:
+            x = Fr(x)
+            assert x.denominator & (x.denominator - 1) == 0 and np.float32(float(x)) == float(x)
+    # frequency 1 (the point +1) enters all four outputs with weight 1: the folded shift rides in as its start value
+    assert [Fr(F43["AT"][i][1]) for i in range(4)] == [1, 1, 1, 1]
+
+
+def test_f43_fp32_error_model_stays_within_the_margin_the_gpu_test_asserts():
+    """The kernel's arithmetic in numpy fp32 (K = 72 accumulations per frequency, as at the c3 bank): the error of the shipped
+    points must stay far inside BASELINE.json's 1e-5 and below the textbook points' (0, +-1, +-2)."""
+    rng = np.random.default_rng(0)
+    Cq, N = 24, 2048
+    w = (rng.standard_normal((Cq, Cq, 3, 3)) * 0.05).astype(np.float32)
+    x = rng.standard_normal((Cq, 3, N + 2)).astype(np.float32)
+    ref = np.zeros((Cq, N))
+    for a in range(3):
+        for k in range(3):
+            ref += w[:, :, a, k].astype(np.float64) @ x[:, a, k:k + N].astype(np.float64)
+
+    def run(form):
+        BT, G, AT = (np.array([[float(Fr(v)) for v in row] for row in form[k]]) for k in ("BT", "G", "AT"))
+        U = np.einsum("fk,oiak->oiaf", G, w.astype(np.float64)).astype(np.float32)
+        idx = (np.arange(N // 4) * 4)[:, None] + np.arange(6)[None, :]
+        V = np.einsum("fr,iatr->iatf", BT.astype(np.float32), x[:, :, idx]).astype(np.float32)
+        M = np.zeros((Cq, N // 4, 6), np.float32)
+        for a in range(3):
+            for i in range(Cq):
+                M += U[:, i, a, None, :] * V[None, i, a, :, :]
+        Y = np.einsum("mf,otf->otm", AT.astype(np.float32), M).astype(np.float32).reshape(Cq, N)
+        return np.abs(Y - ref).max() / np.abs(ref).max()
+
+    two = Fr(2)
+    textbook = dict(
+        BT=[[4, 0, -5, 0, 1, 0], [0, -4, -4, 1, 1, 0], [0, 4, -4, -1, 1, 0], [0, -2, -1, 2, 1, 0], [0, 2, -1, -2, 1, 0], [0, 4, 0, -5, 0, 1]],
+        G=[[Fr(1, 4), 0, 0], [Fr(-1, 6)] * 3, [Fr(-1, 6), Fr(1, 6), Fr(-1, 6)], [Fr(1, 24), Fr(1, 12), Fr(1, 6)], [Fr(1, 24), Fr(-1, 12), Fr(1, 6)], [0, 0, 1]],
+        AT=[[1, 1, 1, 1, 1, 0], [0, 1, -1, two, -two, 0], [0, 1, 1, 4, 4, 0], [0, 1, -1, 8, -8, 1]])
+    _check(textbook, 4, 3)
+    e_ship, e_text = run(F43), run(textbook)
+    assert e_ship < 2.5e-6 and e_ship < e_text, (e_ship, e_text)
