@@ -7,7 +7,11 @@ import ctypes
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.environ.get("FINCFLOW_LIB") or os.path.join(HERE, "libfinc_hip.so")  # env override: debug builds only
+#: FINCFLOW_LIB selects another build of the library (scripts/: A/B timing of experiment builds).  It is never silent: the
+#: override is announced on stderr with the library's build flags, `library_info()` reports it, and bench.py refuses to print a
+#: judged line from an overridden library unless its build flags are 0 and the line says which file ran.
+LIB_OVERRIDE = os.environ.get("FINCFLOW_LIB") or None
+LIB_PATH = LIB_OVERRIDE or os.path.join(HERE, "libfinc_hip.so")
 
 OK = 0
 ALGO = {"auto": 0, "strict": 1, "mfma": 2}
@@ -23,6 +27,8 @@ SYMBOLS = [
     "finc_inverse_kernel_variant", "finc_debug_attr_table_insert", "finc_debug_inverse_table_row",
     "finc_mix_supported_f32", "finc_mix_f32", "finc_pack_forward_weights_affine_f32", "finc_debug_hlp_timeouts",
     "finc_build_flags", "finc_inverse_packed_premultiplied_f32", "finc_inverse_premultiplied_supported", "finc_clear_fault", "finc_debug_backward_variant", "finc_debug_set_forward_form",
+    "finc_inverse_affine_supported", "finc_fault_pending", "finc_runtime_switches",
+    "finc_debug_clock_probe_begin", "finc_debug_clock_probe_end",
 ]
 
 _lib = None
@@ -65,6 +71,11 @@ def lib():
     L.finc_inverse_packed_f32.argtypes = runp
     L.finc_inverse_packed_premultiplied_f32.argtypes = runp
     L.finc_inverse_premultiplied_supported.argtypes = [i, i, i, i, i, i, i]
+    L.finc_inverse_affine_supported.argtypes = [i, i, i, i, i, i, i]
+    L.finc_fault_pending.restype = i
+    L.finc_runtime_switches.argtypes = [ctypes.c_char_p, sz]
+    L.finc_debug_clock_probe_begin.argtypes = [i, i]
+    L.finc_debug_clock_probe_end.argtypes = [ctypes.POINTER(ctypes.c_double)]
     L.finc_forward_packed_f32.argtypes = runp
     L.finc_backward_workspace_bytes.restype = sz
     L.finc_inverse_workspace_bytes.restype = sz
@@ -86,7 +97,16 @@ def lib():
     for name in SYMBOLS:
         getattr(L, name)  # AttributeError here = header and library out of sync
     _lib = L
+    if LIB_OVERRIDE:
+        import sys
+        print(f"fincflow_amd: FINCFLOW_LIB override -> {LIB_PATH} (finc_build_flags = {int(L.finc_build_flags()):#x})", file=sys.stderr)
     return L
+
+
+def library_info():
+    """Which library file is loaded, whether the environment chose it, and the measurement knobs it was built with."""
+    return {"path": os.path.relpath(LIB_PATH, os.path.dirname(HERE)) if not LIB_OVERRIDE else LIB_PATH,
+            "env_override": bool(LIB_OVERRIDE), "build_flags": int(lib().finc_build_flags()), "version": int(lib().finc_version())}
 
 
 def inverse_variant(B, G, Cq, H, W, KH, KW):
@@ -121,6 +141,36 @@ def set_forward_form(form):
 def build_flags():
     """Measurement knobs the library was built with (0 = product build)."""
     return int(lib().finc_build_flags())
+
+
+def runtime_switches():
+    """FINC_* environment switches the library found set, plus a pinned forward form: [] = the library's own dispatch."""
+    buf = ctypes.create_string_buffer(1024)
+    n = lib().finc_runtime_switches(buf, len(buf))
+    return [t for t in buf.value.decode().split(",") if t] if n else []
+
+
+def clock_probe_begin(period_us=250, max_ms=3000):
+    """Start the one-wave shader-clock probe on the current device (include/finc.h).  No device-wide synchronisation until
+    clock_probe_end()."""
+    check(lib().finc_debug_clock_probe_begin(int(period_us), int(max_ms)), "finc_debug_clock_probe_begin")
+
+
+def clock_probe_end():
+    st = (ctypes.c_double * 6)()
+    check(lib().finc_debug_clock_probe_end(st), "finc_debug_clock_probe_end")
+    return {"mean_mhz": st[0], "min_mhz": st[1], "max_mhz": st[2], "samples": int(st[3]), "seconds": st[4], "median_mhz": st[5]}
+
+
+def fault_pending():
+    """Has a helper-wave wait of an earlier launch on the current device given up (its output is garbage)?  Host-side read."""
+    return bool(lib().finc_fault_pending())
+
+
+def raise_if_faulted(where):
+    if fault_pending():
+        raise FincError(f"{where}: a helper-wave wait of an earlier launch on this device gave up -- its output is not valid "
+                        "(fincflow_amd._lib.clear_fault() resets)")
 
 
 def clear_fault():

@@ -2,8 +2,10 @@
 // and the reference interfaces each entry point replaces.
 #include "finc_common.h"
 
+#include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <mutex>
 #include <utility>
 #include <vector>
@@ -19,6 +21,9 @@ constexpr int MAX_DEVICES = 64;
 int *g_invariant_flag[MAX_DEVICES];                       // one 4-byte device word per device, allocated on first use
 volatile unsigned *g_fault_host[MAX_DEVICES];             // one pinned, mapped host word per device: set by a kernel that gave up a wait
 std::vector<std::pair<int, size_t>> g_debug_tokens;       // finc_debug_attr_table_insert's own table (never the live one)
+
+std::atomic<bool> g_fault_armed_any{false};
+std::vector<const char *> g_env_seen;                      // run-time switches found set (finc_env)
 
 // caller holds g_table_mutex
 bool attr_table_has(int device, const void *fn)
@@ -94,23 +99,46 @@ int finc_ensure_dynamic_lds(const void *fn, size_t bytes)
     return FINC_OK;
 }
 
-int finc_fault_gate(bool arm)
+const char *finc_env(const char *name)
 {
+    const char *v = getenv(name);
+    if (v) {
+        std::lock_guard<std::mutex> lk(g_table_mutex);
+        bool seen = false;
+        for (const char *n : g_env_seen) seen = seen || strcmp(n, name) == 0;
+        if (!seen) g_env_seen.push_back(name);              // (string literals of the callers: they outlive the table)
+    }
+    return v;
+}
+
+// `arm`: publish the device's fault word if that has not happened yet.  Arming is a hipHostMalloc + a synchronous copy to a
+// device symbol: both are illegal while `st` is being captured into a graph, so a capture skips it (the packing calls, which
+// run before any capture of the launches, arm too); a failed step frees the word and is retried by the next arming call.
+int finc_fault_gate(bool arm, hipStream_t st)
+{
+    if (!arm && !g_fault_armed_any.load(std::memory_order_acquire)) return FINC_OK;   // nothing armed yet: no HIP call at all
     int dev = 0;
     FINC_HIP_TRY(hipGetDevice(&dev));
     if (dev < 0 || dev >= MAX_DEVICES) return FINC_ERR_BAD_DIMS;
     volatile unsigned *w = g_fault_host[dev];
     if (!w && arm) {
-        std::lock_guard<std::mutex> lk(g_table_mutex);
-        if (!g_fault_host[dev]) {
-            unsigned *h = nullptr, *d = nullptr;
-            FINC_HIP_TRY(hipHostMalloc((void **)&h, sizeof(unsigned), hipHostMallocMapped));
-            *h = 0;
-            FINC_HIP_TRY(hipHostGetDevicePointer((void **)&d, h, 0));
-            if (int e = finc_mfma_arm_fault_word(d)) return e;
-            g_fault_host[dev] = h;
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
+        if (cs == hipStreamCaptureStatusNone) {
+            std::lock_guard<std::mutex> lk(g_table_mutex);
+            if (!g_fault_host[dev]) {
+                unsigned *h = nullptr, *d = nullptr;
+                FINC_HIP_TRY(hipHostMalloc((void **)&h, sizeof(unsigned), hipHostMallocMapped));
+                *h = 0;
+                int e = FINC_OK;
+                if (hipError_t he = hipHostGetDevicePointer((void **)&d, h, 0); he != hipSuccess) { finc_set_hip_error(he); e = FINC_ERR_LAUNCH; }
+                if (!e) e = finc_mfma_arm_fault_word(d);
+                if (e) { (void)hipHostFree(h); return e; }
+                g_fault_host[dev] = h;
+                g_fault_armed_any.store(true, std::memory_order_release);
+            }
+            w = g_fault_host[dev];
         }
-        w = g_fault_host[dev];
     }
     if (w && *w != 0) {
         strncpy(g_hip_error, "a helper-wave wait of an earlier launch on this device gave up: its output is not valid (finc_clear_fault() resets)",
@@ -142,7 +170,35 @@ int finc_version(void) { return 102; }
 unsigned finc_build_flags(void)
 {
     return FINC_BUILD_FLAGS | finc_build_flags_mfma() | finc_build_flags_split() | finc_build_flags_conv() | finc_build_flags_gradw() |
-           finc_build_flags_mix() | finc_build_flags_generic() | finc_build_flags_wino() | finc_build_flags_big();
+           finc_build_flags_mix() | finc_build_flags_generic() | finc_build_flags_wino() | finc_build_flags_big() | finc_build_flags_probe();
+}
+
+int finc_fault_pending(void)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return 0;
+    volatile unsigned *w = g_fault_host[dev];
+    return (w && *w != 0) ? 1 : 0;
+}
+
+int finc_runtime_switches(char *h_buf, size_t n)
+{
+    std::lock_guard<std::mutex> lk(g_table_mutex);
+    size_t used = 0;
+    int count = 0;
+    auto put = [&](const char *t) {
+        const size_t l = strlen(t);
+        if (h_buf && used + l + 2 < n) {
+            if (used) h_buf[used++] = ',';
+            memcpy(h_buf + used, t, l);
+            used += l;
+        }
+        ++count;
+    };
+    for (const char *name : g_env_seen) put(name);
+    if (finc_wino_form_override() != 0) put("forward_form_override");
+    if (h_buf && n) h_buf[used < n ? used : n - 1] = 0;
+    return count;
 }
 
 int finc_clear_fault(void)
@@ -265,6 +321,7 @@ static int run(const float *in, const float *w_canon, float *out, int B, int G, 
     if (int e = check_shape(B, G, Cq, H, W, KH, KW)) return e;
     if (misaligned(in) || misaligned(w_canon) || misaligned(out)) return FINC_ERR_ALIGNMENT;
     if (in == out) return FINC_ERR_BAD_DIMS;
+    if (int e = finc_fault_gate(false)) return e;          // an earlier launch on this device gave up a protocol wait
     FincShape s{B, G, Cq, H, W, KH, KW, orient};
     hipStream_t st = (hipStream_t)stream;
     if (algo == FINC_ALGO_AUTO && !forward) {
@@ -365,6 +422,7 @@ static int run_packed(const float *in, const void *packed, float *out, int B, in
     if (int e = check_shape(B, G, Cq, H, W, KH, KW)) return e;
     if (misaligned(in) || misaligned(out)) return FINC_ERR_ALIGNMENT;
     if (in == out) return FINC_ERR_BAD_DIMS;
+    if (int e = finc_fault_gate(false)) return e;
     FincShape s{B, G, Cq, H, W, KH, KW, orient};
     if (forward) {
         if (!finc_conv_supported(Cq, H, W, KH, KW)) return FINC_ERR_UNSUPPORTED;
@@ -384,6 +442,12 @@ int finc_forward_packed_f32(const float *x, const void *packed, float *z, int B,
                             int KW, unsigned orient, finc_stream_t stream)
 {
     return run_packed(x, packed, z, B, G, Cq, H, W, KH, KW, orient, stream, true);
+}
+
+int finc_inverse_affine_supported(int B, int G, int Cq, int H, int W, int KH, int KW)
+{
+    if (check_shape(B, G, Cq, H, W, KH, KW)) return 0;
+    return finc_mfma_affine_takes(FincShape{B, G, Cq, H, W, KH, KW, 0}) ? 1 : 0;
 }
 
 int finc_inverse_premultiplied_supported(int B, int G, int Cq, int H, int W, int KH, int KW)
@@ -442,6 +506,7 @@ int finc_mix_f32(const float *in, const float *mat, const float *bias, float *ou
     if (B <= 0 || C <= 0 || HW <= 0 || C > FINC_MAX_CQ * FINC_MAX_GROUPS) return FINC_ERR_BAD_DIMS;
     if (misaligned(in) || misaligned(mat) || misaligned(out) || (bias && misaligned(bias))) return FINC_ERR_ALIGNMENT;
     if ((size_t)B * C * HW >= ((size_t)1 << 40)) return FINC_ERR_BAD_DIMS;
+    if (int e = finc_fault_gate(false)) return e;
     return finc_mix_launch(in, mat, bias, out, B, C, HW, (hipStream_t)stream);
 }
 
@@ -489,6 +554,7 @@ int finc_backward_f32(const float *grad_z, const float *x, const float *w_canon,
     if (grad_w_canon && !x) return FINC_ERR_NULL_POINTER;
     if (int e = check_shape(B, G, Cq, H, W, KH, KW)) return e;
     if (grad_x == grad_z) return FINC_ERR_BAD_DIMS;
+    if (int e = finc_fault_gate(false)) return e;
     FincShape s{B, G, Cq, H, W, KH, KW, orient};
     hipStream_t st = (hipStream_t)stream;
     const size_t pk = align256(finc_conv_packed_bytes(G, Cq, KH, KW));

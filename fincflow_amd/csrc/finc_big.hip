@@ -685,7 +685,7 @@ bool finc_big_wide_bank(int Cq, int KH, int KW)
 // on, so that both forms can be compared on one shape)
 static bool big_wide(int W, int KH, int KW)
 {
-    static const bool force = getenv("FINC_BIG_WIDE") != nullptr;
+    static const bool force = finc_env("FINC_BIG_WIDE") != nullptr;
     const bool fits = (size_t)big_fifo_depth(W, KH, KW) * 4 * (KH - 1) * 4 <= (size_t)FIFO_J - 4;   // (+ the zero word)
     return !fits || (force && W >= 48);
 }
@@ -754,7 +754,7 @@ size_t finc_bigfwd_packed_bytes(int G, int Cq, int KH, int KW)
 
 bool finc_bigfwd_takes(const float *in, const float *out, const FincShape &s)
 {
-    static const bool off = getenv("FINC_NO_BIGFWD") != nullptr;           // A/B switch: the 8-wave K-split row of the strip kernel
+    static const bool off = finc_env("FINC_NO_BIGFWD") != nullptr;           // A/B switch: the 8-wave K-split row of the strip kernel
     const BFInst *i = find_bfinst(s.Cq, s.KH, s.KW);
     if (!i || off || s.W % 4 != 0 || s.W < 4 || s.H < 1) return false;       // (16-byte pieces)
     if (((uintptr_t)in | (uintptr_t)out) & 15u) return false;

@@ -40,8 +40,13 @@ int finc_ensure_dynamic_lds(const void *fn, size_t bytes);
 // Protocol faults (helper-wave waits that gave up): finc_fault_gate returns FINC_ERR_LAUNCH if the device's fault word is
 // set (sticky; no synchronisation -- the word lives in mapped host memory); `arm` allocates and publishes the word on the
 // first call per device.  finc_abi.hip owns the per-device table, finc_mfma.hip the device symbol.
-int finc_fault_gate(bool arm);
+int finc_fault_gate(bool arm, hipStream_t st = nullptr);
 int finc_mfma_arm_fault_word(unsigned *device_ptr_to_host_word);
+
+// Run-time A/B switches (FINC_NO_HLP, FINC_WINO_FORM, FINC_SPLIT_MAX ...: scripts/ only) are read through finc_env, which
+// remembers every switch that was found SET: finc_runtime_switches() reports them, bench.py refuses a judged run with any.
+const char *finc_env(const char *name);
+int finc_wino_form_override();   // 0 = the library's choice (finc_debug_set_forward_form)
 
 // the measurement knobs each kernel translation unit was built with (finc_experiment.h); finc_build_flags() ORs them
 unsigned finc_build_flags_mfma();
@@ -50,6 +55,7 @@ unsigned finc_build_flags_conv();
 unsigned finc_build_flags_gradw();
 unsigned finc_build_flags_mix();
 unsigned finc_build_flags_generic();
+unsigned finc_build_flags_probe();
 
 struct FincShape {
     int B, G, Cq, H, W, KH, KW;
@@ -76,6 +82,9 @@ int finc_mfma_pack(const float *wc, const float *scale, const float *shift, void
 // zpre: `in` is Linv * z already (the caller's channel mix applied blockdiag(Linv)): the helper-wave form without its z-term
 int finc_mfma_launch(const float *in, const void *packed, float *out, const FincShape &s, hipStream_t st, bool zpre = false);
 bool finc_mfma_zpre_takes(const FincShape &s);
+// can an affine map with a SHIFT be folded into the bank this problem set runs on? (not on finc_big.hip's kernels: the big
+// banks and the wide-map takeover of the 33..64-channel banks carry a scale only)
+bool finc_mfma_affine_takes(const FincShape &s);
 // info[0..7] = {Cq padded, waves per problem, problems per workgroup, 32-byte I/O (1) or 16-byte (0), LDS bytes of a
 // workgroup, workgroups, index into the instantiation table, rows of the table}; FINC_ERR_UNSUPPORTED if none applies
 int finc_mfma_variant(int B, int G, int Cq, int H, int W, int KH, int KW, int *info);

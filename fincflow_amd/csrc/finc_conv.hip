@@ -663,12 +663,12 @@ int finc_conv_launch(const float *in, const void *packed, float *out, const Finc
     // still pay up to 2 waves per SIMD), in chunks of at least 4 rows (every chunk recomputes KH-1 rows of operands)
     const long long waves = (long long)s.B * s.G * NS * i->nw;
     int nrc = waves >= 2048 ? 1 : waves >= 1024 ? 2 : (int)((1024 + waves - 1) / waves);
-    static const int force_chunks = getenv("FINC_CONV_CHUNKS") ? atoi(getenv("FINC_CONV_CHUNKS")) : 0;   // experiment switch
+    static const int force_chunks = finc_env("FINC_CONV_CHUNKS") ? atoi(finc_env("FINC_CONV_CHUNKS")) : 0;   // experiment switch
     if (force_chunks > 0) nrc = force_chunks;
     if (nrc > s.H / 4) nrc = s.H / 4 > 0 ? s.H / 4 : 1;
     const int RC = (s.H + nrc - 1) / nrc;
     nrc = (s.H + RC - 1) / RC;
-    static const bool no_wide = getenv("FINC_CONV_NO_WIDE") != nullptr;   // experiment switch: the dword form everywhere
+    static const bool no_wide = finc_env("FINC_CONV_NO_WIDE") != nullptr;   // experiment switch: the dword form everywhere
     // the staged form moves 16-byte pieces: activations that are only float-aligned (a view into a larger tensor) take the
     // dword form, as the inverse sends them to its strict kernel
     const bool aligned16 = (((uintptr_t)in | (uintptr_t)out) & 15) == 0;
@@ -683,7 +683,7 @@ int finc_conv_variant(int B, int G, int Cq, int H, int W, int KH, int KW, int *i
 {
     const ConvInst *i = find_conv(Cq, KH, KW);
     if (!i || !finc_conv_supported(Cq, H, W, KH, KW)) return FINC_ERR_UNSUPPORTED;
-    static const bool no_wide = getenv("FINC_CONV_NO_WIDE") != nullptr;
+    static const bool no_wide = finc_env("FINC_CONV_NO_WIDE") != nullptr;
     info[0] = i->nw;
     info[1] = (i->fn_wide && W % 16 == 0 && !no_wide) ? 1 : 0;
     info[2] = (W + 15) / 16;

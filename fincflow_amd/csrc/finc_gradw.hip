@@ -630,7 +630,7 @@ int finc_gradw_launch(const float *gz, const float *x, float *gw, void *workspac
     } else {
         if (!i->gw) return FINC_ERR_UNSUPPORTED;
         WPG = gradw_wpg(s);
-        static const bool no_staged = getenv("FINC_GRADW_NO_STAGED") != nullptr;   // experiment switch
+        static const bool no_staged = finc_env("FINC_GRADW_NO_STAGED") != nullptr;   // experiment switch
         const gradw_fn fn = (i->gw_staged && s.W % 4 == 0 && aligned16 && !no_staged) ? i->gw_staged : i->gw;
         hipLaunchKernelGGL(fn, dim3(s.G * WPG), dim3(64), 0, st, gz, x, (float *)workspace, s.G, s.Cq, s.H, s.W, NS, s.B,
                            WPG, s.orient);
@@ -652,7 +652,7 @@ int finc_gradw_variant(const FincShape &s)
     if (!i || finc_gradw_workspace_bytes(s) == 0) return 0;
     if (gradw_use_tiled(i, s)) return 3;
     if (!i->gw) return 0;
-    static const bool no_staged = getenv("FINC_GRADW_NO_STAGED") != nullptr;
+    static const bool no_staged = finc_env("FINC_GRADW_NO_STAGED") != nullptr;
     return (i->gw_staged && s.W % 4 == 0 && !no_staged) ? 2 : 1;
 }
 

@@ -41,8 +41,10 @@
 
 #include <stdlib.h>
 
+#include <mutex>
 #include <type_traits>
 #include <utility>
+#include <vector>
 
 namespace {
 
@@ -172,14 +174,6 @@ struct BTaps {
 #ifndef FINC_ABLATE_IO   // timing-only bit mask: 1 no loads, 2 no stores, 4 no landing, 8 no x-ring read
 #define FINC_ABLATE_IO 0
 #endif
-// Experiment builds only (scripts/build_variant.sh): cache-policy bits of the activation loads / stores
-// (gfx940+: bit 0 = sc0, bit 1 = nt, bit 4 = sc1).  The product is built with 0.
-#ifndef FINC_LD_AUX
-#define FINC_LD_AUX 0
-#endif
-#ifndef FINC_ST_AUX
-#define FINC_ST_AUX 0
-#endif
 template <int I>
 using IC = std::integral_constant<int, I>;
 
@@ -295,10 +289,7 @@ __global__ __launch_bounds__(HLP ? 512 : 64 * NW * NPW) void finc_wave_kernel(co
     const bool fh = (o & FINC_FLIP_H) != 0, fw = (o & FINC_FLIP_W) != 0;
     const int HW = H * W;
     const unsigned slab_bytes = (unsigned)CQ * (unsigned)HW * 4u;
-#ifndef FINC_SAMEBUF     // timing-only experiment: bit 0 = every problem reads one of 32 slabs, bit 1 = writes one of 32
-#define FINC_SAMEBUF 0   // (the working set then lives in L2 / Infinity Cache: separates DRAM from CU-side limits)
-#endif
-    const int bg_in = (FINC_SAMEBUF & 1) ? bg % 32 : bg, bg_out = (FINC_SAMEBUF & 2) ? bg % 32 : bg;
+    const int bg_in = bg, bg_out = bg;
     const __amdgpu_buffer_rsrc_t rin =
         __builtin_amdgcn_make_buffer_rsrc((void *)(in + (size_t)bg_in * CQ * HW), 0, (int)slab_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rout =
@@ -638,7 +629,7 @@ __global__ __launch_bounds__(HLP ? 512 : 64 * NW * NPW) void finc_wave_kernel(co
         const unsigned vb = ok ? (unsigned)loffS[WP] : OFF_INVALID;
 #pragma unroll
         for (int j = 0; j < NKZ; ++j)
-            Z[WP][j] = __builtin_amdgcn_raw_buffer_load_b128(rin, (NW > 1 || j == NKZ - 1) ? vb + zmark(j) : vb, j * 16 * HW, FINC_LD_AUX);
+            Z[WP][j] = __builtin_amdgcn_raw_buffer_load_b128(rin, (NW > 1 || j == NKZ - 1) ? vb + zmark(j) : vb, j * 16 * HW, 0);
         lcolS[WP] += 8;
         loffS[WP] += 32 * dirw;
         if (lcolS[WP] == W) { lcolS[WP] = 0; lrowS[WP] += P; loffS[WP] += rowstep - dirw * W * 4; }
@@ -711,10 +702,10 @@ __global__ __launch_bounds__(HLP ? 512 : 64 * NW * NPW) void finc_wave_kernel(co
                     w.y = __builtin_bit_cast(unsigned, e1);
                     w.z = __builtin_bit_cast(unsigned, e2);
                     w.w = __builtin_bit_cast(unsigned, e3);
-                    __builtin_amdgcn_raw_buffer_store_b128(w, rout, vo2 + (unsigned)uni, 0, FINC_ST_AUX);   // (offset in the vector operand: scripts/check_store_hazard.py)
+                    __builtin_amdgcn_raw_buffer_store_b128(w, rout, vo2 + (unsigned)uni, 0, 0);   // (offset in the vector operand: scripts/check_store_hazard.py)
                 }
             }
-            __builtin_amdgcn_raw_buffer_store_b128(v, rout, vo + (unsigned)uni, 0, FINC_ST_AUX);     // (offset in the vector operand: scripts/check_store_hazard.py)
+            __builtin_amdgcn_raw_buffer_store_b128(v, rout, vo + (unsigned)uni, 0, 0);     // (offset in the vector operand: scripts/check_store_hazard.py)
         }
         if constexpr (S64S) {
             if (spark) {                       // (divergent) park this window's lower piece where the upper one will find it
@@ -748,7 +739,7 @@ __global__ __launch_bounds__(HLP ? 512 : 64 * NW * NPW) void finc_wave_kernel(co
 #pragma unroll
         for (int j = 0; j < NKZ; ++j) {
             if (j < j0 || j >= j1) continue;
-            zb[j] = __builtin_amdgcn_raw_buffer_load_b128(rin, (NW > 1 || j == NKZ - 1) ? vb + zmark(j) : vb, j * 16 * HW, FINC_LD_AUX);
+            zb[j] = __builtin_amdgcn_raw_buffer_load_b128(rin, (NW > 1 || j == NKZ - 1) ? vb + zmark(j) : vb, j * 16 * HW, 0);
         }
         if (advance) {
             lcol += 4;
@@ -799,7 +790,7 @@ __global__ __launch_bounds__(HLP ? 512 : 64 * NW * NPW) void finc_wave_kernel(co
             v.y = __builtin_bit_cast(unsigned, sv[j][1]);
             v.z = __builtin_bit_cast(unsigned, sv[j][2]);
             v.w = __builtin_bit_cast(unsigned, sv[j][3]);
-            __builtin_amdgcn_raw_buffer_store_b128(v, rout, vo + (unsigned)uni, 0, FINC_ST_AUX);     // (offset in the vector operand: scripts/check_store_hazard.py)
+            __builtin_amdgcn_raw_buffer_store_b128(v, rout, vo + (unsigned)uni, 0, 0);     // (offset in the vector operand: scripts/check_store_hazard.py)
         }
     };
     // the window's HBM work, spread over its 4 steps: step 0 reads the x ring; steps 1-3 store a third of the registers
@@ -883,18 +874,14 @@ __global__ __launch_bounds__(HLP ? 512 : 64 * NW * NPW) void finc_wave_kernel(co
     float *pop_p[KH];                         // = fifo + pop_base + ((fslot+1) % D) * pop_stride
 #pragma unroll
     for (int a = 1; a < KH; ++a) pop_p[a] = fifo + pop_base[a] + (D > 1 ? pop_stride[a] : 0);
-#ifndef FINC_FIFO_EXEC   // experiment: 1 = only the lanes that really push / pop touch LDS (exec-masked), no trash words
-#define FINC_FIFO_EXEC 0
-#endif
+    // (exec-masked pushes / pops instead of the trash words: 1.2 % slower, profiles/r02/notes/ab30)
     auto fifo_push = [&](const float (&v)[NK]) {
-        if (FINC_FIFO_EXEC && !do_push) return;
 #pragma unroll
         for (int j = 0; j < NK; ++j) push_p[j * JS] = v[j];
     };
     auto fifo_pop_all = [&]() {
 #pragma unroll
         for (int a = 1; a < KH; ++a) {
-            if (FINC_FIFO_EXEC && !(p < a)) continue;
 #pragma unroll
             for (int j = 0; j < NK; ++j) fv[a][j] = pop_p[a][j * JS];
         }
@@ -955,14 +942,10 @@ __global__ __launch_bounds__(HLP ? 512 : 64 * NW * NPW) void finc_wave_kernel(co
     if constexpr (HLP) {
         if (helper) {
             // ===== the HBM side of one problem, in the order the single-wave kernel issues it =====
-#ifndef FINC_HLP_PRIO
-#define FINC_HLP_PRIO 0
-#endif
             // (Priority: at equal priority the helper gets only the bubbles of its partner's MFMA stream -- ~60 cycles per VALU
             // instruction, scripts/micro/mfma_helper.hip -- and its landing is late for two checks out of three; raised, it is
             // late for one in seven, but every instruction it then issues first delays the MFMA wave and the kernel is 2 %
             // SLOWER (profiles/r02/notes/ab18): the partner's slack is the pole wave's cover.  It stays at 0.)
-            if constexpr (FINC_HLP_PRIO != 0) __builtin_amdgcn_s_setprio(FINC_HLP_PRIO);
             s64_init();
             const int wlast = Tend >> 2;       // the window after the last computed one (even: Tend % 8 == 0)
             s64_event(IC<0>{}, IC<0>{});       // window -4: the first pieces of the class-0 rows leave
@@ -1182,15 +1165,6 @@ __global__ __launch_bounds__(HLP ? 512 : 64 * NW * NPW) void finc_wave_kernel(co
                     if (NW == 1 && finc_zterm_is_zero(C::MTB, j, mt)) continue;   // Linv is lower triangular
                     mma(accn[mt], FZ + j * MT + mt, zv[j]);
                 }
-#ifdef FINC_ZREP   // timing-only: the MFMA cost of a z-term FINC_ZREP times as wide (a folded C x C 1x1 conv
-                   // makes it G times as wide and dense); results are wrong, never shipped
-#pragma unroll
-            for (int rep = 1; rep < FINC_ZREP; ++rep)
-#pragma unroll
-                for (int j = 0; j < NKZ; ++j)
-#pragma unroll
-                    for (int mt = 0; mt < MT; ++mt) mma(accn[mt], FZ + NKZ * MT + j * MT + mt, zv[j]);
-#endif
             FINC_STAMP_AT(1);                           // segment 1: z-term
             if constexpr (NW > 1) {
                 // K-split exchange: acc holds this wave's share of ALL output registers.  Ship the registers other waves
@@ -1496,11 +1470,7 @@ constexpr Inst make_inst()
     // AGPR budget next to the pinned fragments: loads paired park 16 registers per k-step of z
     constexpr bool one = NW == 1 && NPW == 1;
     constexpr int pinned = (C::NFRAG / C::MT) * C::MTB - zskip + ((C::NFRAG / C::MT) * C::NSM + 3) / 4;
-#ifndef FINC_S64_MODE
-#define FINC_S64_MODE 3
-#endif
-    constexpr int mode = !one ? 0 : (FINC_S64_MODE == 3 && pinned + 8 * C::NKZ + 8 * C::NKD <= 256) ? 3
-                                  : (FINC_S64_MODE >= 1 && pinned + 8 * C::NKD <= 256) ? 1 : 0;
+    constexpr int mode = !one ? 0 : (pinned + 8 * C::NKZ + 8 * C::NKD <= 256) ? 3 : (pinned + 8 * C::NKD <= 256) ? 1 : 0;
     wave_fn f64 = nullptr, fhl = nullptr, fzp = nullptr;
     if constexpr (mode != 0) f64 = finc_wave_kernel<CQP, KH, KW, true, NW, NPW, mode>;
 #ifndef FINC_HLP_MODE
@@ -1556,14 +1526,14 @@ size_t lds_bytes(const Inst &i, int W, int P);
 // FINC_NO_HLP=1 keeps the helper-wave variant off (A/B timing, tests of the single-wave sector-pairing path)
 bool finc_no_hlp()
 {
-    static const bool off = [] { const char *e = getenv("FINC_NO_HLP"); return e && e[0] == '1'; }();
+    static const bool off = [] { const char *e = finc_env("FINC_NO_HLP"); return e && e[0] == '1'; }();
     return off;
 }
 
 // FINC_NO_S64=1 in the environment keeps W % 16 == 0 shapes on the 32-byte-piece kernel (A/B timing, tests of that path)
 bool finc_no_s64()
 {
-    static const bool off = [] { const char *e = getenv("FINC_NO_S64"); return e && e[0] == '1'; }();
+    static const bool off = [] { const char *e = finc_env("FINC_NO_S64"); return e && e[0] == '1'; }();
     return off;
 }
 
@@ -1677,6 +1647,40 @@ static bool wide_takeover(const FincShape &s)
            finc_big_supported(s.Cq, s.H, s.W, s.KH, s.KW);
 }
 
+// Banks packed WITH a folded shift have no wide-map form (finc_big.hip carries a scale only).  Such a packed buffer is
+// remembered here (device, address) and its big-bank region is filled with NaNs, so a wide-map launch on it is refused
+// (FINC_ERR_UNSUPPORTED) -- and could not pass for a result even if the table were bypassed.  Re-packing the address
+// without a shift takes it out again.
+static std::mutex g_dead_mutex;
+static std::vector<std::pair<int, const void *>> g_dead_wide;
+static void dead_wide_set(const void *packed, bool dead)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return;
+    std::lock_guard<std::mutex> lk(g_dead_mutex);
+    for (size_t i = 0; i < g_dead_wide.size(); ++i)
+        if (g_dead_wide[i].first == dev && g_dead_wide[i].second == packed) {
+            if (!dead) { g_dead_wide[i] = g_dead_wide.back(); g_dead_wide.pop_back(); }
+            return;
+        }
+    if (dead) g_dead_wide.emplace_back(dev, packed);
+}
+static bool dead_wide_has(const void *packed)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return false;
+    std::lock_guard<std::mutex> lk(g_dead_mutex);
+    for (const auto &e : g_dead_wide)
+        if (e.first == dev && e.second == packed) return true;
+    return false;
+}
+
+bool finc_mfma_affine_takes(const FincShape &s)
+{
+    if (!finc_mfma_supported(s.Cq, s.H, s.W, s.KH, s.KW)) return false;
+    return !finc_big_bank(s.Cq, s.KH, s.KW) && !wide_takeover(s);
+}
+
 size_t finc_mfma_packed_bytes(int G, int Cq, int KH, int KW)
 {
     if (finc_big_bank(Cq, KH, KW)) return finc_big_packed_bytes(G, Cq, KH, KW);
@@ -1687,16 +1691,19 @@ size_t finc_mfma_packed_bytes(int G, int Cq, int KH, int KW)
 int finc_mfma_pack(const float *wc, const float *scale, const float *shift, void *packed, int G, int Cq, int KH, int KW,
                    hipStream_t st)
 {
+    (void)finc_fault_gate(true, st);           // arm the device's fault word here, outside any capture of the launches
     if (finc_big_bank(Cq, KH, KW)) return finc_big_pack(wc, scale, shift, packed, G, Cq, KH, KW, st);
     const Inst *i = find_inst(Cq, KH, KW);
     if (!i) return FINC_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(pack_kernel, dim3(G), dim3(256), sizeof(double) * Cq * Cq, st, wc, scale, shift, (float *)packed, Cq,
                        KH, KW, i->mt, i->nkz, i->nkd, i->mtb, i->nfrag);
     FINC_CHECK_LAUNCH();
-    // (a folded shift is the one thing finc_big.hip does not carry: such a bank simply has no wide-map form -- zeros there)
+    // (a folded shift is the one thing finc_big.hip does not carry: such a bank has no wide-map form -- the launch refuses
+    // it, finc_inverse_affine_supported() says so beforehand, and the region holds NaNs, never a plausible bank)
     if (finc_big_wide_bank(Cq, KH, KW)) {
         char *behind = (char *)packed + wave_bank_bytes(G, Cq, KH, KW);
-        if (shift) FINC_HIP_TRY(hipMemsetAsync(behind, 0, finc_big_packed_bytes(G, Cq, KH, KW), st));
+        dead_wide_set(packed, shift != nullptr);
+        if (shift) FINC_HIP_TRY(hipMemsetAsync(behind, 0xFF, finc_big_packed_bytes(G, Cq, KH, KW), st));
         else return finc_big_pack(wc, scale, nullptr, behind, G, Cq, KH, KW, st);
     }
     return FINC_OK;
@@ -1762,6 +1769,7 @@ int finc_mfma_launch(const float *in, const void *packed, float *out, const Finc
     if (zpre && !finc_mfma_zpre_takes(s)) return FINC_ERR_UNSUPPORTED;
     if (int e = finc_fault_gate(false)) return e;          // an earlier launch on this device gave up a protocol wait
     if (finc_big_bank(s.Cq, s.KH, s.KW)) return finc_big_launch(in, packed, out, s, st);   // beyond this table (finc_big.hip)
+    if (wide_takeover(s) && dead_wide_has(packed)) return FINC_ERR_UNSUPPORTED;            // packed with a folded shift: no wide-map form
     if (wide_takeover(s))                                                                  // too wide for this table's forms
         return finc_big_launch(in, (const char *)packed + wave_bank_bytes(s.G, s.Cq, s.KH, s.KW), out, s, st);
     if (finc_split_takes(s)) return finc_split_launch(in, packed, out, s, st);   // the under-filled chip (finc_split.hip)
@@ -1779,7 +1787,7 @@ int finc_mfma_launch(const float *in, const void *packed, float *out, const Finc
     const wave_fn fn = zpre ? i->fn_zpre : hlp ? i->fn_hlp : s64 ? i->fn_s64 : (s.W % 8 == 0) ? i->fn_sec : i->fn;
     if (int e = finc_ensure_dynamic_lds((const void *)fn, hlp ? lds_hlp : lds)) return e;
     if (hlp) {
-        if (int e = finc_fault_gate(true)) return e;       // (arms the device's fault word on the first helper-wave launch)
+        if (int e = finc_fault_gate(true, st)) return e;   // (arms the device's fault word if no packing call has: never inside a capture)
     }
     if (hlp)
         hipLaunchKernelGGL(fn, dim3(s.B * s.G / 4), dim3(512), lds_hlp, st, in, (const float *)packed, out, s.G, s.Cq, s.H, s.W, P,

@@ -578,7 +578,7 @@ bool fifo_fits(const SInst &i, int W, int P) { return (size_t)fifo_depth(W, P, i
 // problems (B*G) up to which the role-split kernel is the faster one; FINC_SPLIT_MAX overrides (0 turns it off: A/B timing)
 long long split_max_problems()
 {
-    static const long long v = [] { const char *e = getenv("FINC_SPLIT_MAX"); return e ? atoll(e) : 256LL; }();
+    static const long long v = [] { const char *e = finc_env("FINC_SPLIT_MAX"); return e ? atoll(e) : 256LL; }();
     return v;
 }
 

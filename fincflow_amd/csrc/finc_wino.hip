@@ -670,13 +670,13 @@ const WInst *find_winst(int Cq)
 std::atomic<int> g_form_override{0};               // 0: none, 1: direct strip kernel, 2: F(2,3), 4: F(4,3)
 bool finc_no_wino()
 {
-    static const bool off = [] { const char *e = getenv("FINC_NO_WINO"); return e && e[0] == '1'; }();
+    static const bool off = [] { const char *e = finc_env("FINC_NO_WINO"); return e && e[0] == '1'; }();
     const int o = g_form_override.load(std::memory_order_relaxed);
     return o ? o == 1 : off;
 }
 int finc_wino_forced_form()
 {
-    static const int f = [] { const char *e = getenv("FINC_WINO_FORM"); return e ? atoi(e) : 0; }();
+    static const int f = [] { const char *e = finc_env("FINC_WINO_FORM"); return e ? atoi(e) : 0; }();
     const int o = g_form_override.load(std::memory_order_relaxed);
     if (o == 2 || o == 4) return o;
     return f == 2 || f == 4 ? f : 0;
@@ -735,7 +735,7 @@ int finc_wino_launch(const float *in, const void *packed, float *out, const Finc
     const long long waves = (long long)s.B * s.G * NS;
     // F(2,3): two waves per SIMD, row chunks up to about one; F(4,3): one wave per SIMD, row chunks (of 8 rows or more: a
     // chunk recomputes two rows of operands) up to that
-    static const int force_chunks = getenv("FINC_WINO_CHUNKS") ? atoi(getenv("FINC_WINO_CHUNKS")) : 0;   // experiment switch
+    static const int force_chunks = finc_env("FINC_WINO_CHUNKS") ? atoi(finc_env("FINC_WINO_CHUNKS")) : 0;   // experiment switch
     int nrc;
     if (f4) {
         const long long fill4 = i->cqp <= 8 ? 2048 : 1024;                 // (the small banks: two waves per SIMD)
@@ -748,8 +748,8 @@ int finc_wino_launch(const float *in, const void *packed, float *out, const Finc
     if (nrc > s.H / 4) nrc = s.H / 4 > 0 ? s.H / 4 : 1;
     const int RC = (s.H + nrc - 1) / nrc;
     nrc = (s.H + RC - 1) / RC;
-    static const int skew_mask = getenv("FINC_WINO_SKEW") ? atoi(getenv("FINC_WINO_SKEW")) : 0;          // (experiment switches)
-    static const int skew_sleep = getenv("FINC_WINO_SLEEP") ? atoi(getenv("FINC_WINO_SLEEP")) : 2;
+    static const int skew_mask = finc_env("FINC_WINO_SKEW") ? atoi(finc_env("FINC_WINO_SKEW")) : 0;          // (experiment switches)
+    static const int skew_sleep = finc_env("FINC_WINO_SLEEP") ? atoi(finc_env("FINC_WINO_SLEEP")) : 2;
     const float *bank = (const float *)packed + (f4 ? (size_t)s.G * i->npack * 64 : 0);
     const size_t lds = f4 ? (size_t)2 * i->nk * 64 * 24 + (size_t)i->mt * 1024 : (size_t)2 * 4 * i->nk * 256 + (size_t)i->mt * 1024;
     hipLaunchKernelGGL(f4 ? i->fn4 : i->fn, dim3(s.B * s.G * NS, nrc), dim3(64), lds, st, in, bank, out, s.G, s.Cq, s.H, s.W, NS, RC,
@@ -757,6 +757,8 @@ int finc_wino_launch(const float *in, const void *packed, float *out, const Finc
     FINC_CHECK_LAUNCH();
     return FINC_OK;
 }
+
+int finc_wino_form_override() { return g_form_override.load(std::memory_order_relaxed); }
 
 int finc_wino_set_form(int form)
 {

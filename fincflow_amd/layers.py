@@ -16,7 +16,7 @@ from abc import ABCMeta, abstractmethod
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import _lib, ops
 
 
 class FlowLayer(nn.Module, metaclass=ABCMeta):
@@ -264,6 +264,8 @@ def load_reference_checkpoint(model, checkpoint, strict=True, validate=True, tru
     missing = [k for k in result.missing_keys if k not in own_bias]
     if strict and (missing or result.unexpected_keys):
         raise RuntimeError(f"checkpoint does not match the model: missing {missing}, unexpected {list(result.unexpected_keys)}")
+    if any(p.is_cuda for p in model.parameters()):
+        _lib.raise_if_faulted("load_reference_checkpoint")   # (the invariant check below synchronises: a natural reporting point)
     for m in model.modules():
         cache = getattr(m, "_cache", None)
         if isinstance(cache, ops.PackedWeights):
@@ -391,6 +393,12 @@ class FlowSequential(nn.Module):
             x_true = self._reverse_chain(z, context, fuse=False)
         else:
             x_true = x
+        # A helper-wave launch whose protocol wait gave up has returned FINC_OK (launches are asynchronous); every later
+        # launching call on the device refuses, but a chain that ENDS on such a launch would hand its garbage out.  The fault
+        # word lives in host memory: reading it here costs nothing and catches every launch that has finished by now (the
+        # caller's own synchronisation + the next call catch the rest).
+        if x.is_cuda:
+            _lib.raise_if_faulted("FlowSequential.sample")
         return x, x_true
 
     def reconstruct(self, input, context=None, compute_expensive=False):

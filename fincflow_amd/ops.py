@@ -207,10 +207,13 @@ def inverse(input, kernel, output):
 
 class _DeviceBank:
     """What PackedWeights holds for ONE device."""
-    __slots__ = ("key", "w_canon", "packed_inv", "packed_fwd", "packed_aff", "aff_key", "packed_faff", "faff_key", "linv")
+    __slots__ = ("key", "keep", "validated", "w_canon", "packed_inv", "packed_fwd", "packed_aff", "aff_key", "packed_faff",
+                 "faff_key", "linv")
 
     def __init__(self):
         self.key = None
+        self.keep = None          # the source tensors' storages, kept alive while the entry is (see PackedWeights._get)
+        self.validated = False    # check_invariant has run on THIS weight version
         self.w_canon = None
         self.packed_inv = None
         self.packed_fwd = None
@@ -260,18 +263,27 @@ class PackedWeights:
         """`validate=False`: the training path -- the gradient mask keeps the corner tap unit triangular (layers/conv.py:98-99,
         applied inside the HIP backward), and the check is a device->host synchronisation per layer and step."""
         bank = self._bank(weights[0].device)
+        # The entry is keyed on (address, version counter) of every source tensor AND holds their storages alive: a weight
+        # rebound through `.data` to a fresh tensor keeps its version counter, and the address of a freed tensor is the first
+        # one the allocator hands out again -- with the old storage still referenced here the new one cannot land on it.
         key = tuple((w.data_ptr(), w._version) for w in weights) + (orient,)
         if key != bank.key:
             ws = torch.cat([w.detach() for w in weights], dim=0).contiguous() if len(weights) > 1 else weights[0].detach().contiguous()
             bank.w_canon = canonicalize(ws, G, orient)
-            if validate:
-                check_invariant(bank.w_canon, G)
+            bank.validated = False
             bank.packed_inv = None
             bank.packed_fwd = None
             bank.packed_aff = None
             bank.packed_faff = None
             bank.linv = None
             bank.key = key
+            bank.keep = tuple(w.untyped_storage() for w in weights)
+        # An entry the training path created (validate=False) is NOT validated: the first inference call on the same weight
+        # version runs the check, so an optimiser effect outside the in-kernel gradient mask (weight decay on the diagonal,
+        # a manual edit followed by a forward under grad) cannot reach the inverse unnoticed.
+        if validate and not bank.validated:
+            check_invariant(bank.w_canon, G)
+            bank.validated = True
         return bank
 
     def forward(self, x, weights, G, orient, out=None, validate=True):
@@ -413,6 +425,10 @@ class PackedWeights:
             out = torch.empty_like(y)
         if not self._packed_path_ok(L, y, out, Cq, H, W, KH, KW):
             return None
+        # the shift rides on the wavefront / role-split kernels only: the big banks and the wide maps that finc_big.hip takes
+        # over from the 33..64-channel banks (Cq = 50 at 256 columns) carry a scale and nothing else -> two launches there
+        if not L.finc_inverse_affine_supported(B, G, Cq, H, W, KH, KW):
+            return None
         key = (log_scale.data_ptr(), log_scale._version, translation.data_ptr(), translation._version)
         with torch.cuda.device(y.device):
             if bank.packed_aff is None or bank.aff_key != key:
@@ -428,8 +444,11 @@ class PackedWeights:
                 _lib.check(st, "finc_pack_inverse_weights_affine_f32")
                 bank.packed_aff = packed
                 bank.aff_key = key
-            _lib.check(L.finc_inverse_packed_f32(y.data_ptr(), bank.packed_aff.data_ptr(), out.data_ptr(), B, G, Cq, H, W,
-                                                 KH, KW, orient, _stream_ptr(y)), "finc_inverse_packed_f32")
+            st = L.finc_inverse_packed_f32(y.data_ptr(), bank.packed_aff.data_ptr(), out.data_ptr(), B, G, Cq, H, W, KH, KW, orient,
+                                           _stream_ptr(y))
+            if st == 3:            # (the launch itself refuses a shift-carrying bank on a map it cannot serve)
+                return None
+            _lib.check(st, "finc_inverse_packed_f32")
         return out
 
 

@@ -139,7 +139,14 @@ int finc_pack_forward_weights_f32(const float *w_canon, void *packed, int G, int
  * per-step cost of the plain inverse: Linv*diag(scale) replaces Linv as the z-term and Linv*shift is the
  * accumulators' initial value.  scale / shift: [G*Cq] device floats, either may be NULL (identity).
  * FINC_ERR_UNSUPPORTED when the shape has no MFMA instantiation (there is no strict twin of this call).
+ * A SHIFT cannot ride on every kernel: the big banks (64 < Cq <= 96) refuse it here (FINC_ERR_UNSUPPORTED), and the
+ * 33..64-channel banks carry it on every map except those too wide for the wavefront kernel's forms (Cq = 50 at 256
+ * columns ...), which run on the big-bank kernel.  Packing does not know the map, so ask first:
+ * finc_inverse_affine_supported(B, G, Cq, H, W, KH, KW) == 1 iff finc_inverse_packed_f32 on THIS problem set accepts a
+ * bank packed with a shift.  A launch that does not (a wide map on a shift-carrying bank) returns FINC_ERR_UNSUPPORTED --
+ * it never computes with a partial bank -- and the caller runs the affine layer as its own launch.
  */
+int finc_inverse_affine_supported(int B, int G, int Cq, int H, int W, int KH, int KW);
 int finc_pack_inverse_weights_affine_f32(const float *w_canon, const float *scale, const float *shift, void *packed,
                                          int G, int Cq, int KH, int KW, finc_stream_t stream);
 /*
@@ -247,11 +254,29 @@ int finc_debug_attr_table_insert(int device, size_t kernel_token);
  * that gave up since the library was loaded on the current device: anything but 0 is a bug. */
 int finc_debug_hlp_timeouts(unsigned *h_count);
 /* A wait that gives up leaves garbage in that launch's output.  It does not pass silently: the kernel also sets a word in
- * mapped host memory, and every later finc_inverse_* / finc_check_invariant_f32 call on that device returns FINC_ERR_LAUNCH
- * (finc_last_hip_error() names the cause) until finc_clear_fault() -- no synchronisation is added to the launch path.
- * The launch that faulted has itself returned FINC_OK (it is asynchronous): callers that cannot afford one bad result check
- * finc_debug_hlp_timeouts() at their own synchronisation points (bench.py does). */
+ * mapped host memory, and every later launching call on that device -- finc_inverse_*, finc_forward_*, finc_mix_f32,
+ * finc_backward_f32, finc_check_invariant_f32 -- returns FINC_ERR_LAUNCH (finc_last_hip_error() names the cause) until
+ * finc_clear_fault(); no synchronisation is added to the launch path.  The word is armed by the packing calls (and by the
+ * first helper-wave launch outside a stream capture).  The launch that faulted has itself returned FINC_OK (it is
+ * asynchronous): callers check finc_fault_pending() at their own synchronisation points -- the Python layer does at the
+ * end of FlowSequential.sample and in load_reference_checkpoint, bench.py after every timed leg. */
 int finc_clear_fault(void);
+/* 1 if the current device's fault word is set (host-side read of mapped memory, no synchronisation), else 0. */
+int finc_fault_pending(void);
+/* Run-time A/B switches in effect in this process: every FINC_* environment switch the library found SET when it looked
+ * (FINC_NO_HLP, FINC_NO_S64, FINC_NO_WINO, FINC_WINO_FORM, FINC_SPLIT_MAX ...: scripts/ only) and a forward form pinned by
+ * finc_debug_set_forward_form.  Returns their number and writes a comma-separated list into h_buf (n bytes, may be NULL).
+ * 0 = the library's own dispatch; bench.py records the list and refuses to report a judged line otherwise. */
+int finc_runtime_switches(char *h_buf, size_t n);
+/* Clock probe (bench.py's per-leg `sclk_mhz`).  The chip lowers its shader clock under load by an amount that depends on
+ * the data, so one kernel can take different wall times on different inputs with no code difference.  _begin starts ONE
+ * wavefront on a stream of its own that samples s_memtime (shader clock) against s_memrealtime (100 MHz) every
+ * `period_us` until _end, its sample budget or `max_ms` of wall time, whichever comes first -- nothing is stamped in the
+ * measured kernels.  _end (SYNCHRONOUS on the probe's stream only) stops it and returns h_stats[6] = {mean MHz of the
+ * window, min and max over the sampling intervals, samples, seconds covered, median MHz}.  One probe per device at a
+ * time; the caller must not device-synchronise between _begin and _end (stream synchronisation is fine). */
+int finc_debug_clock_probe_begin(int period_us, int max_ms);
+int finc_debug_clock_probe_end(double *h_stats);
 
 #ifdef __cplusplus
 }

@@ -194,3 +194,34 @@ def test_no_wide_store_is_overwritten_behind_its_back():
     if not shutil.which(os.path.join(chk.LLVM, "llvm-objdump")):
         pytest.skip("no llvm-objdump in this image")
     assert chk.main() == 0
+
+
+def test_runtime_switches_are_reported():
+    """the environment's A/B switches and a pinned forward form change kernel choice and timing; the library
+    lists the ones in effect so that a benchmark line can show it ran the library's own dispatch (bench.py refuses otherwise)."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from fincflow_amd import _lib\n"
+            "a = _lib.runtime_switches()\n"
+            "_lib.inverse_variant(256, 4, 24, 64, 64, 3, 3)\n"          # (consults FINC_NO_S64 / FINC_NO_HLP, host only)
+            "b = _lib.runtime_switches()\n"
+            "_lib.set_forward_form(4)\n"
+            "c = _lib.runtime_switches()\n"
+            "print(a, '|', b, '|', c)\n") % REPO
+    clean = {k: v for k, v in os.environ.items() if not k.startswith("FINC")}
+    out = subprocess.run([sys.executable, "-c", code], env=clean, capture_output=True, text=True, check=True).stdout.strip()
+    assert out == "[] | [] | ['forward_form_override']", out
+    out = subprocess.run([sys.executable, "-c", code], env=dict(clean, FINC_NO_HLP="1"), capture_output=True, text=True, check=True).stdout.strip()
+    assert out == "[] | ['FINC_NO_HLP'] | ['FINC_NO_HLP', 'forward_form_override']", out
+
+
+def test_library_override_is_announced():
+    import subprocess
+    import sys
+    code = "import sys; sys.path.insert(0, %r)\nfrom fincflow_amd import _lib\nprint(_lib.library_info())\n" % REPO
+    clean = {k: v for k, v in os.environ.items() if not k.startswith("FINC")}
+    r = subprocess.run([sys.executable, "-c", code], env=clean, capture_output=True, text=True, check=True)
+    assert "'env_override': False" in r.stdout and "'build_flags': 0" in r.stdout and "FINCFLOW_LIB" not in r.stderr
+    r = subprocess.run([sys.executable, "-c", code], env=dict(clean, FINCFLOW_LIB=_lib.LIB_PATH), capture_output=True, text=True, check=True)
+    assert "'env_override': True" in r.stdout and "FINCFLOW_LIB override" in r.stderr

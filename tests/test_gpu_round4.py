@@ -1,0 +1,202 @@
+"""Round-4 parity cases (GPU; through the C ABI; nothing here reads /root/reference).
+
+* every kernel family of the 3x3 forward / grad-input -- the direct strip kernel, Winograd F(2,3), Winograd F(4,3) --
+  against REFERENCE-GENERATED data: the golden forward outputs (tests/golden/make_golden.py) and the golden input gradients
+  (tests/golden/make_golden_r4.py: torch autograd through the reference's own layers), including the trained-like fixtures
+  (F(4,3), the headline forward kernel, had only met the oracle and fp64 conv2d at init-scale weights);
+* the affine fold on the maps finc_big.hip takes over from the 33..64-channel banks (a bank packed with a
+  shift had an all-zero wide-map half and the launch computed with it);
+* the packed-weight cache: an entry created by the training path is validated by the first inference call.
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle
+from helpers import ORDER_BITS, ORIENT_FASTFLOW, elem_rel_err, golden, golden_names, rel_err, report, unit_stored_weights
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    from fincflow_amd import _lib
+    _lib.lib()
+    return torch.device("cuda:0")
+
+
+def t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+GRAD_CASES = [n[len("grad_"):] for n in golden_names("grad_")]
+FORMS = {1: ("strip", "strip16"), 2: ("winograd",), 4: ("winograd4",)}
+
+
+@pytest.mark.parametrize("name", GRAD_CASES)
+def test_every_forward_form_against_reference_outputs_and_gradients(name, dev):
+    """layers/conv.py:102-107 (forward) and its autograd (grad-input), each kernel family pinned in turn.  Max-normalised
+    error <= 1e-5 (BASELINE.json) asserted; the element-wise error (every element against its own magnitude, down to 1e-3 of
+    the largest) goes on record in gpurun_out/parity_report.jsonl."""
+    from fincflow_amd import _lib, ops
+    g, gg = golden(name), golden("grad_" + name)
+    if name.startswith("unit_"):
+        ws, G, orient = unit_stored_weights(g), 4, ORIENT_FASTFLOW
+    else:
+        ws, G, orient = g["w"], 1, ORDER_BITS[str(g["order"])]
+    assert ws.shape[2:] == (3, 3) and g["x"].shape[3] % 4 == 0
+    B, C, H, W = g["x"].shape
+    wc = ops.canonicalize(t(ws, dev), G, orient)
+    x, gz = t(g["x"], dev), t(gg["gz_times16"].astype(np.float32) / 16.0, dev)
+    try:
+        for form, names in FORMS.items():
+            _lib.set_forward_form(form)
+            assert _lib.backward_variant(B, G, C // G, H, W, 3, 3)["conv_form"] in names, (form, name)
+            z = ops.finc_forward(x, wc, G, orient).cpu().numpy()
+            gx, _ = ops.finc_backward(gz, x, wc, G, orient, need_gx=True, need_gw=False)
+            gx = gx.cpu().numpy()
+            e_f, e_g = rel_err(z, g["z"]), rel_err(gx, gg["grad_x"])
+            report("forward_form_vs_reference", fixture=name, form=form, forward=e_f, grad_input=e_g,
+                   forward_elementwise=elem_rel_err(z, g["z"]), grad_input_elementwise=elem_rel_err(gx, gg["grad_x"]))
+            assert e_f <= TOL and e_g <= TOL, (name, form, e_f, e_g)
+    finally:
+        _lib.set_forward_form(0)
+
+
+def test_f43_on_trained_like_weights_at_a_shape_the_library_sends_there(dev):
+    """B = 64, C = 96, 64x64 (a 4-way strong split's share of configs[2]) with the free taps x 1.5: AUTO picks F(4,3); three
+    images against the pinned oracle (fp64 accumulation) and against fp64 conv2d autograd for grad-input."""
+    import torch.nn.functional as F
+    from fincflow_amd import FastFlowUnit, _lib
+    B, C, H, W = 64, 96, 64, 64
+    assert _lib.backward_variant(B, 4, C // 4, H, W, 3, 3)["conv_form"] == "winograd4"
+    torch.manual_seed(404)
+    unit = FastFlowUnit(C, C, 3)
+    with torch.no_grad():
+        for m in (unit.conv_tl, unit.conv_tr, unit.conv_bl, unit.conv_br):
+            m.conv.weight.mul_(1 + 0.5 * m.get_mask())                      # make_golden.unit_case's `heavy`, 1.5
+    unit = unit.to(dev)
+    x = torch.randn(B, C, H, W, device=dev)
+    gz = torch.randn(B, C, H, W, device=dev)
+    xg = x.clone().requires_grad_(True)
+    z, logdet = unit(xg)
+    z.backward(gz)
+    assert logdet == 0.0
+    pick = [0, 31, 63]
+    ws = torch.cat(unit._weights()).detach().cpu().numpy()
+    wco = oracle.canonicalize(ws, 4, ORIENT_FASTFLOW)
+    z_ref = oracle.forward_f32(x[pick].cpu().numpy(), wco, 4, ORIENT_FASTFLOW, accumulate_f64=True)
+    xd = x[pick].cpu().double().requires_grad_(True)
+    ref = torch.cat([F.conv2d(F.pad(c, m.pad), m.conv.weight.detach().cpu().double()) for m, c in
+                     zip((unit.conv_tl, unit.conv_tr, unit.conv_bl, unit.conv_br), torch.chunk(xd, 4, 1))], 1)
+    ref.backward(gz[pick].cpu().double())
+    e_f = rel_err(z[pick].detach().cpu().numpy(), z_ref)
+    e_g = rel_err(xg.grad[pick].cpu().numpy(), xd.grad.numpy())
+    report("f43_trained_like", shape=[B, C, H, W], forward=e_f, grad_input=e_g,
+           forward_elementwise=elem_rel_err(z[pick].detach().cpu().numpy(), z_ref),
+           grad_input_elementwise=elem_rel_err(xg.grad[pick].cpu().numpy(), xd.grad.numpy()))
+    assert e_f <= TOL and e_g <= TOL, (e_f, e_g)
+    # and the inverse of what it produced, on the same weights (ill-conditioned on purpose: tests/test_oracle.py's tolerance)
+    with torch.no_grad():
+        xr = unit.reverse(z.detach())
+    x_ref = oracle.inverse_via_f64(z[pick].detach().cpu().numpy(), wco, 4, ORIENT_FASTFLOW)
+    assert rel_err(xr[pick].cpu().numpy(), x_ref) <= 1e-3
+
+
+# (B, C, H, W): FastFlowUnit shapes whose inverse runs on finc_big.hip's wide-map form of a 33..64-channel bank
+WIDE_AFFINE_CASES = [(1, 192, 18, 256), (1, 200, 40, 256)]
+
+
+@pytest.mark.parametrize("shape", WIDE_AFFINE_CASES, ids=lambda c: "B%d_C%d_%dx%d" % c)
+def test_affine_fold_declines_where_the_kernel_cannot_carry_a_shift(shape, dev):
+    from fincflow_amd import FastFlowUnit, FlowSequential, _lib, glow
+    from fincflow_amd.layers import StandardNormal
+    B, C, H, W = shape
+    Cq = C // 4
+    L = _lib.lib()
+    v = _lib.inverse_variant(B, 4, Cq, H, W, 3, 3)
+    assert v is not None and v["sec"] == 5, v                        # the wide takeover: form 5
+    assert L.finc_inverse_affine_supported(B, 4, Cq, H, W, 3, 3) == 0
+    assert L.finc_inverse_affine_supported(B, 4, Cq, 16, 32, 3, 3) == 1   # the same bank on a narrow map carries the shift
+    torch.manual_seed(sum(shape))
+    unit = FastFlowUnit(C, C, 3)
+    with torch.no_grad():
+        for m in (unit.conv_tl, unit.conv_tr, unit.conv_bl, unit.conv_br):
+            m.conv.weight.mul_(1 - 0.6 * m.get_mask())               # (a wide map amplifies: keep the system well conditioned)
+    unit = unit.to(dev)
+    an = glow.ActNorm(C).to(dev)
+    with torch.no_grad():
+        an.log_scale.copy_(0.3 * torch.randn(C, device=dev))
+        an.translation.copy_(torch.randn(C, device=dev))
+        an.initialized.fill_(1)
+    y = torch.randn(B, C, H, W, device=dev)
+    with torch.no_grad():
+        assert unit.reverse_affine(y, an.log_scale, an.translation) is None
+        two = unit.reverse(an.reverse(y))
+        seq = FlowSequential(StandardNormal((C, H, W)), unit, an)
+        assert seq.fuse_affine
+        chain = seq._reverse_chain(y, None)
+    ws = torch.cat(unit._weights()).detach().cpu().numpy()
+    wco = oracle.canonicalize(ws, 4, ORIENT_FASTFLOW)
+    zin = (y * torch.exp(an.log_scale).view(1, -1, 1, 1) + an.translation.view(1, -1, 1, 1)).cpu().numpy()
+    want = oracle.inverse_via_f64(zin, wco, 4, ORIENT_FASTFLOW, nthreads=8)
+    tol = max(TOL, 2.0 * rel_err(oracle.inverse_f32(zin, wco, 4, ORIENT_FASTFLOW, nthreads=8), want))   # (as test_wide_maps_...)
+    assert rel_err(two.cpu().numpy(), want) <= tol
+    assert torch.equal(chain, two)                                   # the container took the two-launch path
+    # at the C ABI: a bank packed WITH a shift serves the narrow map and is refused -- not computed with -- on the wide one
+    from fincflow_amd import ops
+    wc = ops.canonicalize(torch.cat(unit._weights()).detach().contiguous(), 4, ORIENT_FASTFLOW)
+    packed = torch.empty(L.finc_workspace_bytes(4, Cq, 3, 3), dtype=torch.uint8, device=dev)
+    scale, shift = torch.exp(an.log_scale).contiguous(), an.translation.detach().contiguous()
+    st = torch.cuda.current_stream().cuda_stream
+    assert L.finc_pack_inverse_weights_affine_f32(wc.data_ptr(), scale.data_ptr(), shift.data_ptr(), packed.data_ptr(), 4, Cq, 3, 3, st) == 0
+    out = torch.empty_like(y)
+    assert L.finc_inverse_packed_f32(y.data_ptr(), packed.data_ptr(), out.data_ptr(), B, 4, Cq, H, W, 3, 3, ORIENT_FASTFLOW, st) == 3
+    ys = y[:, :, :16, :32].contiguous()
+    outs = torch.empty_like(ys)
+    assert L.finc_inverse_packed_f32(ys.data_ptr(), packed.data_ptr(), outs.data_ptr(), B, 4, Cq, 16, 32, 3, 3, ORIENT_FASTFLOW, st) == 0
+    want_s = oracle.inverse_via_f64(np.ascontiguousarray(zin[:, :, :16, :32]), wco, 4, ORIENT_FASTFLOW)
+    assert rel_err(outs.cpu().numpy(), want_s) <= TOL
+    # a scale alone rides on the wide map too; and re-packing the same buffer without a shift revives it
+    assert L.finc_pack_inverse_weights_affine_f32(wc.data_ptr(), scale.data_ptr(), None, packed.data_ptr(), 4, Cq, 3, 3, st) == 0
+    assert L.finc_inverse_packed_f32(y.data_ptr(), packed.data_ptr(), out.data_ptr(), B, 4, Cq, H, W, 3, 3, ORIENT_FASTFLOW, st) == 0
+    want_scale = oracle.inverse_via_f64((y * torch.exp(an.log_scale).view(1, -1, 1, 1)).cpu().numpy(), wco, 4, ORIENT_FASTFLOW, nthreads=8)
+    assert rel_err(out.cpu().numpy(), want_scale) <= tol
+
+
+def test_an_entry_the_training_path_created_is_validated_by_the_first_inference_call(dev):
+    from fincflow_amd import FastFlowUnit
+    unit = FastFlowUnit(16, 16, 3).to(dev)
+    x = torch.randn(2, 16, 8, 8, device=dev, requires_grad=True)
+    with torch.no_grad():
+        unit.conv_tl.conv.weight[1, 1, -1, -1] = 0.9                # (what weight decay does to the unit diagonal)
+    z, _ = unit(x)                                                   # training path: cached, not validated
+    with pytest.raises(RuntimeError):
+        unit.reverse(z.detach())                                     # same weight version: the check must still run
+    with torch.no_grad():
+        unit.conv_tl.conv.weight[1, 1, -1, -1] = 1.0
+    z, _ = unit(x)
+    xr = unit.reverse(z.detach())
+    assert rel_err(xr.cpu().numpy(), x.detach().cpu().numpy()) <= 1e-4
+
+
+def test_fault_gate_is_consulted_by_every_launching_entry_point(dev):
+    """after a protocol fault, forward / mix / backward must refuse too -- not only the next inverse.  No fault
+    is injected here (tests/test_gpu_variants.py does that with an experiment build): this checks the word is armed by a
+    packing call and that a clean device passes every gate."""
+    from fincflow_amd import FastFlowUnit, _lib, ops
+    unit = FastFlowUnit(48, 48, 3).to(dev)
+    x = torch.randn(72, 48, 16, 16, device=dev)
+    with torch.no_grad():
+        z, _ = unit(x)
+        unit.reverse(z)
+    torch.cuda.synchronize()
+    assert not _lib.fault_pending() and _lib.hlp_timeouts() == 0
+    _lib.raise_if_faulted("test")
+    m = torch.eye(48, device=dev)
+    assert torch.equal(ops.finc_mix(x, m), x)

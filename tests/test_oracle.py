@@ -17,7 +17,7 @@ LITERAL_CASES = golden_names("literal_")
 
 
 def test_fixture_inventory():
-    assert len(UNIT_CASES) == 10 and len(PADDED_CASES) == 6 and len(LITERAL_CASES) == 6
+    assert len(UNIT_CASES) == 11 and len(PADDED_CASES) == 6 and len(LITERAL_CASES) == 6 and len(golden_names("grad_")) == 8
 
 
 @pytest.mark.parametrize("name", UNIT_CASES)
