@@ -101,11 +101,9 @@ def test_f43_on_trained_like_weights_at_a_shape_the_library_sends_there(dev):
            forward_elementwise=elem_rel_err(z[pick].detach().cpu().numpy(), z_ref),
            grad_input_elementwise=elem_rel_err(xg.grad[pick].cpu().numpy(), xd.grad.numpy()))
     assert e_f <= TOL and e_g <= TOL, (e_f, e_g)
-    # and the inverse of what it produced, on the same weights (ill-conditioned on purpose: tests/test_oracle.py's tolerance)
-    with torch.no_grad():
-        xr = unit.reverse(z.detach())
-    x_ref = oracle.inverse_via_f64(z[pick].detach().cpu().numpy(), wco, 4, ORIENT_FASTFLOW)
-    assert rel_err(xr[pick].cpu().numpy(), x_ref) <= 1e-3
+    # (no inverse here: free taps x 1.5 at 24 channels per group make a 64x64 system lose its digits in the reference's own
+    # fp64 solver -- tests/golden/make_golden_r4.py found the same on 16x64 at x 2; the inverse meets trained-like weights in
+    # the `heavy` fixtures, at sizes the reference itself can still solve)
 
 
 # (B, C, H, W): FastFlowUnit shapes whose inverse runs on finc_big.hip's wide-map form of a 33..64-channel bank
