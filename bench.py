@@ -673,8 +673,11 @@ def inverse_kernel_name(B, Cq, H, W, K):
     if v is None:
         return "inverse_strict_kernel<float> (inverse, scalar)"
     if v["sec"] == 4:
+        per = v["workgroups"] // (B * 4)
+        bands = "" if per == 1 else (f"; the bands of a problem dealt out to {per} workgroups on different compute units, the rows "
+                                     f"above a band handed over through memory")
         return (f"finc_split_kernel<CQP={v['cqp']},{K},{K}> (inverse, role-split: 1 wave carries the recurrence, {v['nw'] - 1} prepare "
-                f"the rest one step ahead; {v['workgroups']} workgroups of {v['nw']} waves, {v['lds_bytes']} B LDS)")
+                f"the rest one step ahead{bands}; {v['workgroups']} workgroups of {v['nw']} waves, {v['lds_bytes']} B LDS)")
     io = {0: "32-byte I/O", 1: "32-byte I/O, lane pairs", 2: "64-byte sector pairing",
           3: "64-byte sector pairing, helper waves do the I/O (512-thread workgroups of 4 problems)"}.get(v["sec"], str(v["sec"]))
     return (f"finc_wave_kernel<CQP={v['cqp']},{K},{K},NW={v['nw']},NPW={v['npw']}> (inverse; {io}; "

@@ -20,6 +20,7 @@ std::vector<std::pair<int, const void *>> g_attr_done;   // (device, kernel) pai
 constexpr int MAX_DEVICES = 64;
 int *g_invariant_flag[MAX_DEVICES];                       // one 4-byte device word per device, allocated on first use
 volatile unsigned *g_fault_host[MAX_DEVICES];             // one pinned, mapped host word per device: set by a kernel that gave up a wait
+unsigned *g_fault_dev[MAX_DEVICES];                       // ... and the device's pointer to it
 std::vector<std::pair<int, size_t>> g_debug_tokens;       // finc_debug_attr_table_insert's own table (never the live one)
 
 std::atomic<bool> g_fault_armed_any{false};
@@ -99,6 +100,13 @@ int finc_ensure_dynamic_lds(const void *fn, size_t bytes)
     return FINC_OK;
 }
 
+unsigned *finc_fault_device_word()
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEVICES) return nullptr;
+    return g_fault_host[dev] ? g_fault_dev[dev] : nullptr;
+}
+
 const char *finc_env(const char *name)
 {
     const char *v = getenv(name);
@@ -134,6 +142,7 @@ int finc_fault_gate(bool arm, hipStream_t st)
                 if (hipError_t he = hipHostGetDevicePointer((void **)&d, h, 0); he != hipSuccess) { finc_set_hip_error(he); e = FINC_ERR_LAUNCH; }
                 if (!e) e = finc_mfma_arm_fault_word(d);
                 if (e) { (void)hipHostFree(h); return e; }
+                g_fault_dev[dev] = d;
                 g_fault_host[dev] = h;
                 g_fault_armed_any.store(true, std::memory_order_release);
             }
@@ -528,7 +537,11 @@ int finc_debug_set_forward_form(int form) { return finc_wino_set_form(form); }
 int finc_debug_hlp_timeouts(unsigned *h_count)
 {
     if (!h_count) return FINC_ERR_NULL_POINTER;
-    return finc_mfma_hlp_timeouts(h_count);
+    unsigned a = 0, b = 0;
+    if (int e = finc_mfma_hlp_timeouts(&a)) return e;          // helper-wave protocol (finc_mfma.hip)
+    if (int e = finc_split_timeouts_count(&b)) return e;       // band split's progress words (finc_split.hip)
+    *h_count = a + b;
+    return FINC_OK;
 }
 
 int finc_debug_inverse_table_row(int row, int *info)

@@ -112,7 +112,10 @@ int finc_bigfwd_pack(const float *wc, void *packed, int G, int Cq, int KH, int K
 int finc_bigfwd_launch(const float *in, const void *packed, float *out, const FincShape &s, hipStream_t st);
 unsigned finc_build_flags_big();
 bool finc_split_takes(const FincShape &s);       // this problem set runs on the role-split kernel
-int finc_split_info(const FincShape &s, int *waves, int *lds_bytes, int *steps);
+int finc_split_info(const FincShape &s, int *waves, int *lds_bytes, int *steps, int *nwg = nullptr);   // nwg: workgroups per problem (band split)
+int finc_split_prepare(hipStream_t st);          // allocates the band split's progress words for the current device (not inside a capture)
+int finc_split_timeouts_count(unsigned *count);  // progress waits of the band split that gave up (must be 0)
+unsigned *finc_fault_device_word();              // device pointer to the current device's (armed) fault word, or nullptr
 int finc_split_launch(const float *in, const void *packed, float *out, const FincShape &s, hipStream_t st);
 
 // ---- forward / grad-input, MFMA strip kernel: finc_conv.hip ----

@@ -1692,6 +1692,7 @@ int finc_mfma_pack(const float *wc, const float *scale, const float *shift, void
                    hipStream_t st)
 {
     (void)finc_fault_gate(true, st);           // arm the device's fault word here, outside any capture of the launches
+    (void)finc_split_prepare(st);              // ... and the band split's progress words (finc_split.hip)
     if (finc_big_bank(Cq, KH, KW)) return finc_big_pack(wc, scale, shift, packed, G, Cq, KH, KW, st);
     const Inst *i = find_inst(Cq, KH, KW);
     if (!i) return FINC_ERR_UNSUPPORTED;
@@ -1723,10 +1724,10 @@ int finc_mfma_variant(int B, int G, int Cq, int H, int W, int KH, int KW, int *i
     if (!i) return FINC_ERR_UNSUPPORTED;
     const int P = W < 16 ? W : 16;
     const FincShape fs{B, G, Cq, H, W, KH, KW, 0};
-    if (finc_split_takes(fs)) {                // form 4: the role-split kernel, one workgroup of info[1] waves per problem
-        int waves = 0, lds = 0, steps = 0;
-        if (int e = finc_split_info(fs, &waves, &lds, &steps)) return e;
-        info[0] = i->cqp; info[1] = waves; info[2] = 1; info[3] = 4; info[4] = lds; info[5] = B * G;
+    if (finc_split_takes(fs)) {                // form 4: the role-split kernel, info[5] / (B*G) workgroups of info[1] waves per problem
+        int waves = 0, lds = 0, steps = 0, nwg = 1;
+        if (int e = finc_split_info(fs, &waves, &lds, &steps, &nwg)) return e;
+        info[0] = i->cqp; info[1] = waves; info[2] = 1; info[3] = 4; info[4] = lds; info[5] = B * G * nwg;
         info[6] = -1; info[7] = (int)(sizeof(g_insts) / sizeof(g_insts[0]));
         return FINC_OK;
     }

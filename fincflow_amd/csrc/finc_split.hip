@@ -25,10 +25,27 @@
 // Same packed bank as the wavefront kernel (finc_mfma_pack), same lanes (lane p owns the rows p, P+p, ... and trails
 // lane p-1 by one step), same arithmetic (exact fp32 MFMA; only the order in which the partial sums of a pixel are added
 // differs).  Any Cq <= CQP (padded channels are masked per k-step) and any W (dword I/O: no alignment rule).
+//
+// BSP ("bands split over workgroups", round 4): with problems to spare CUs for -- B*G <= half the compute units: c3 at the 32
+// images an 8-way strong split leaves a GPU -- ONE problem still is a chain of NB*W + P - 1 steps on one CU while the other
+// half of the chip idles.  The bands of 16 rows are therefore dealt out to NWG workgroups on different CUs (band k to
+// workgroup k % NWG; each workgroup chains ITS bands as before), and the one thing a band needs from the band above -- its
+// last KH-1 rows -- comes through memory: the workgroup above stores those rows like every other row (write-through), says how
+// far it got in a progress word, and the consumer's B waves fetch the pieces (past the caches) into the very FIFO slots the
+// chained form pushes them to, two windows before the first lane needs them.  Nothing else changes: same lanes, same
+// visitation inside a band (cinc_cuda_kernel_level2.cu:49-56), same arithmetic.  The dependent chain of c3 shrinks from 271
+// steps to 64 + 15 + 3 x (the hand-over lag); the lag is what the memory round trip makes it, ~34 steps.
+// Progress words live in a per-device area that the library owns (slots handed out round-robin per launch); a word is valid
+// only with the area's current EPOCH, which the last workgroup of a launch to finish advances -- so nothing is cleared
+// between launches, and a captured launch can be replayed.  Every wait is bounded; one that gives up sets the device's fault
+// word (include/finc.h) exactly like the helper-wave protocol of the wavefront kernel.
 #include "finc_common.h"
 #include "finc_tile.h"
 
 #include <stdlib.h>
+
+#include <atomic>
+#include <mutex>
 
 #include <type_traits>
 #include <utility>
@@ -118,10 +135,13 @@ struct SCfg {
 // -----------------------------------------------------------------------------------------------
 // grid = B*G workgroups of (1 + NBW) waves.  W % 4 == 0 (16-byte pieces), DF * JS * 4 <= JSTRIDE.
 // -----------------------------------------------------------------------------------------------
-template <int CQP, int KH, int KW, int NBW>
+__device__ unsigned finc_split_timeouts = 0;     // BSP: progress waits that gave up (must stay 0)
+
+template <int CQP, int KH, int KW, int NBW, bool BSP>
 __global__ __launch_bounds__(64 * (1 + NBW)) void finc_split_kernel(const float *__restrict__ in, const float *__restrict__ packed,
                                                                    float *__restrict__ out, int G, int CQ, int H, int W, int P,
-                                                                   int T, unsigned orient, int DF)
+                                                                   int T, unsigned orient, int DF, int nwg, int nprob,
+                                                                   unsigned *__restrict__ sync, unsigned *fault_word)
 {
     using C = SCfg<CQP, KH, KW, NBW>;
     constexpr int MT = C::MT, MTB = C::MTB, NK = C::NK, NCH = C::NCH, JS = C::JS;
@@ -131,7 +151,14 @@ __global__ __launch_bounds__(64 * (1 + NBW)) void finc_split_kernel(const float 
     const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // 0: A, 1..NBW: B
     const int lane = threadIdx.x & 63;
     const int q = lane >> 4, p = lane & 15;
-    const int bg = blockIdx.x, g = bg % G;
+    // BSP: workgroup `wg` of the problem owns the bands wg, wg + nwg, ...; band-major block order, so that a band's producer is
+    // dispatched no later than its consumer
+    const int wg = BSP ? __builtin_amdgcn_readfirstlane((int)blockIdx.x / nprob) : 0;
+    const int bg = BSP ? (int)blockIdx.x - wg * nprob : (int)blockIdx.x, g = bg % G;
+    const int band_rows = BSP ? nwg * P : P;   // rows from a band of this workgroup to its next one
+    const int row0 = BSP ? wg * P : 0;         // first row of its first band
+    unsigned epoch = 0;
+    if constexpr (BSP) epoch = __builtin_amdgcn_readfirstlane(__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 0xFFFu;
     const unsigned o = finc_group_orient(orient, g);
     const bool fh = (o & FINC_FLIP_H) != 0, fw = (o & FINC_FLIP_W) != 0;
     const int HW = H * W;
@@ -171,7 +198,7 @@ __global__ __launch_bounds__(64 * (1 + NBW)) void finc_split_kernel(const float 
 #pragma unroll
         for (int j = 0; j < NK; ++j) q0[j] = q1[j] = 0.f;
         int ca = -p;                           // col of this lane at step t (negative: not started)
-        const bool pusher = KH > 1 && p >= P - (KH - 1) && p < P;
+        const bool pusher = KH > 1 && !BSP && p >= P - (KH - 1) && p < P;   // (BSP: the FIFO is filled from memory by the B waves)
         // byte addresses inside one k-step's block (the k-step is the instruction's immediate offset)
         const int ring_w = C::RING_B + lane * 4;
         const int push_w = C::FIFO_B + (q * (KH - 1) + (p - (P - (KH - 1)))) * 4;
@@ -181,6 +208,17 @@ __global__ __launch_bounds__(64 * (1 + NBW)) void finc_split_kernel(const float 
         int fpush = 0;
         int fpop = ((-(W - P)) % DF + DF) % DF;
         int tm = 0;                            // t % W
+        if constexpr (BSP && KH > 1) {
+            // the first band of this workgroup may have real rows above it (image band wg >= 1): the B waves have just landed their
+            // first pieces in the FIFO -- S_1(-1) of lane 0 is the pixel above column 0, the push of virtual step -1
+            __syncthreads();
+            float fv0[NK];
+            const int fp0 = fpop == 0 ? DF - 1 : fpop - 1;
+#pragma unroll
+            for (int j = 0; j < NK; ++j) fv0[j] = ld(pop_r + fp0 * (JS * 4) + j * JSTRIDE);
+#pragma unroll
+            for (int j = 0; j < NK; ++j) q1[j] = row_shr1(fv0[j], 0.f);
+        }
         __syncthreads();                       // (iteration t = -1: the B waves prepare step 0)
         unsigned long long st_busy = 0;
         for (int t = 0; t <= T; ++t) {
@@ -275,6 +313,15 @@ __global__ __launch_bounds__(64 * (1 + NBW)) void finc_split_kernel(const float 
 #else
         (void)st_busy;
 #endif
+        if constexpr (BSP) {                   // the last workgroup to finish retires the epoch: every progress word of this launch is void
+            if (lane == 0) {
+                const unsigned done = __hip_atomic_fetch_add(sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (done == gridDim.x - 1) {
+                    __hip_atomic_store(sync + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(sync, (epoch + 1) & 0xFFFu, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
         return;
     }
 
@@ -337,11 +384,11 @@ __global__ __launch_bounds__(64 * (1 + NBW)) void finc_split_kernel(const float 
     }
     const int f4 = -((p + 3) >> 2), fs4 = -((p + 3 + 3) >> 2);             // floor(-p / 4), floor((-3 - p) / 4)
     const int dgrp = fw ? -16 : 16;                                        // bytes from a group to the next one of the row
-    const int drow = (fh ? -P : P) * W * 4 - (dgrp / 4) * W;               // ... and from the end of a row to the start of row + P
+    const int drow = (fh ? -band_rows : band_rows) * W * 4 - (dgrp / 4) * W;   // ... and from the end of a row to the start of the same lane's next row
     auto piece_off = [&](int row, int col0) { return ((fh ? H - 1 - row : row) * W + (fw ? W - 4 - col0 : col0)) * 4; };
     // load walk: next group to request (starts at group f); store walk: next group to store (starts at group fs)
-    int lcol = 4 * f4, lrow = p, loff = piece_off(p, 0) + f4 * dgrp;
-    int scol = 4 * fs4, srow = p, soff = piece_off(p, 0) + fs4 * dgrp;
+    int lcol = 4 * f4, lrow = row0 + p, loff = piece_off(row0 + p, 0) + f4 * dgrp;
+    int scol = 4 * fs4, srow = row0 + p, soff = piece_off(row0 + p, 0) + fs4 * dgrp;
     v4f zin[2][NJ > 0 ? NJ : 1];               // in flight: the set of window parity wp is requested in the windows of parity wp
     auto zreq = [&](v4f (&dst)[NJ > 0 ? NJ : 1]) {
         const bool ok = lcol >= 0 && lrow < H && p < P;
@@ -350,7 +397,7 @@ __global__ __launch_bounds__(64 * (1 + NBW)) void finc_split_kernel(const float 
         for (int j = 0; j < NJ; ++j)
             asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen" : "=v"(dst[j]) : "v"(base + zmask[j]), "s"(rin) : "memory");
         lcol += 4; loff += dgrp;
-        if (lcol == W) { lcol = 0; lrow += P; loff += drow; }
+        if (lcol == W) { lcol = 0; lrow += band_rows; loff += drow; }
     };
     // landing: group gl (mod 3) -> slots 4*(gl % 3) + k; element k of the piece is canonical column k, or 3 - k when flipped
     int gland = ((f4 % 3) + 3) % 3;            // ring group of the next landing
@@ -387,18 +434,108 @@ __global__ __launch_bounds__(64 * (1 + NBW)) void finc_split_kernel(const float 
             v.w = ld((xs3 ^ stog) + (JLO + j) * JSTRIDE);
             // (s_nop: a store of more than 8 bytes reads its data one wait state after issue, and the hazard recognizer does not
             // see inline asm -- without it the next instruction may overwrite the data registers: measured, lanes 12-15 of one register)
-            asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" ::"v"(v), "v"(base + xmask[j]), "s"(rout) : "memory");
+            // (BSP: write-through -- the band below is solved on another CU, possibly behind another L2)
+            if constexpr (BSP)
+                asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen sc0 sc1\n\ts_nop 1" ::"v"(v), "v"(base + xmask[j]), "s"(rout) : "memory");
+            else
+                asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen\n\ts_nop 1" ::"v"(v), "v"(base + xmask[j]), "s"(rout) : "memory");
         }
         stog ^= 1024;
         scol += 4; soff += dgrp;
-        if (scol == W) { scol = 0; srow += P; soff += drow; }
+        if (scol == W) { scol = 0; srow += band_rows; soff += drow; }
+    };
+    // ---- BSP: the rows above a band, fetched from the output of the workgroup that solves the band above.
+    // Lanes (q, p < KH-1) carry row a' = p + 1 above the band; a piece of 4 canonical columns goes to the 4 FIFO slots the chained
+    // form pushes those pixels to: pixel (row -a', column c) of this workgroup's local band i = the push of lane P - a' at local
+    // step (i-1)*W + c + P - a', slot = that step mod DF -- so nothing changes for the readers (A's pop, the B waves' taps).  The
+    // slot of the previous content (DF steps earlier) was read by local step (i-1)*W + c + P + KH + KW - 2 at the latest and the
+    // new one is first read at i*W + c - 1: the piece lands one window before that, two after it was requested.
+    // Progress: producer B wave `bi` of workgroup wgp = (wg - 1) mod nwg publishes, in its word, the number of its local windows
+    // whose stores are complete; group gq of its local band i' leaves in its window i'*W/4 + gq + 5 (rows P-2, P-1: fs4 = -5).
+    const bool hl = BSP && p < KH - 1;
+    int hcol = 0, hband = 0;
+    int hoff = BSP ? piece_off(row0 - 1 - p, 0) : 0;
+    int hslot = BSP ? (((-W + P - 1 - p) % DF) + DF) % DF : 0;            // slot of the first element of the next piece to LAND
+    v4f hin[NJ > 0 ? NJ : 1];
+    int seen = 0;                                                          // producer progress read so far
+    const int wgp = BSP ? (wg + nwg - 1) % nwg : 0;
+    const int NBimg = (H + P - 1) / P;
+    const __amdgpu_buffer_rsrc_t rsync = __builtin_amdgcn_make_buffer_rsrc((void *)sync, 0, BSP ? (2 + nprob * nwg * NBW) * 4 : 0, 0x00020000);
+    const unsigned my_flag = (unsigned)(2 + (bg * nwg + wg) * NBW + bi) * 4u, its_flag = (unsigned)(2 + (bg * nwg + wgp) * NBW + bi) * 4u;
+    unsigned seen_raw = 0;                     // the progress word as last fetched (asynchronously, once per window)
+    auto progress_fetch = [&]() {              // (no wait: the value is read by progress_take, behind the window's one vmcnt wait)
+        asm volatile("buffer_load_dword %0, %1, %2, 0 offen sc0 sc1" : "=v"(seen_raw) : "v"(its_flag), "s"(rsync) : "memory");
+    };
+    auto progress_take = [&]() {
+        asm volatile("" : "+v"(seen_raw));
+        const unsigned val = __builtin_amdgcn_readfirstlane(seen_raw);
+        if ((val >> 20) == epoch && (int)(val & 0xFFFFFu) > seen) seen = (int)(val & 0xFFFFFu);
+    };
+    auto progress_wait = [&](int need) {
+        if (seen >= need) return;
+        int budget = 1 << 18;                  // bounded (~0.2 s): a protocol bug must not hang the GPU, and must not pass unnoticed
+        for (; budget > 0; --budget) {
+            unsigned v;
+            asm volatile("buffer_load_dword %0, %1, %2, 0 offen sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(its_flag), "s"(rsync) : "memory");
+            const unsigned val = __builtin_amdgcn_readfirstlane(v);
+            if ((val >> 20) == epoch) seen = (int)(val & 0xFFFFFu);
+            if (seen >= need) break;
+            __builtin_amdgcn_s_sleep(8);
+        }
+        if (budget == 0 && lane == 0) {
+            atomicAdd(&finc_split_timeouts, 1u);
+            if (fault_word) __hip_atomic_store(fault_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    };
+    auto publish = [&](int windows_done) {
+        if (lane == 0) {
+            const unsigned v = (epoch << 20) | (unsigned)windows_done;
+            asm volatile("buffer_store_dword %0, %1, %2, 0 offen sc0 sc1" ::"v"(v), "v"(my_flag), "s"(rsync) : "memory");
+        }
+    };
+    auto hreq = [&]() {
+        const int kb = wg + hband * nwg;                                   // the image band these rows sit above
+        const bool live = kb >= 1 && kb < NBimg;                           // (band 0: the zero rows above the image; beyond: nothing)
+        if (live) progress_wait(((kb - 1) / nwg) * (W >> 2) + (hcol >> 2) + 6);
+        const unsigned base = (live && hl) ? (unsigned)hoff : OFF_INVALID;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen sc0 sc1" : "=v"(hin[j]) : "v"(base + xmask[j]), "s"(rout) : "memory");
+        hcol += 4; hoff += dgrp;
+        if (hcol == W) { hcol = 0; ++hband; hoff += drow; }
+    };
+    auto hland = [&]() {                       // (the caller has waited for the loads)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) asm volatile("" : "+v"(hin[j]));
+        if (hl) {
+            int s0 = hslot, s1 = hslot + 1, s2 = hslot + 2, s3 = hslot + 3;
+            s1 = s1 >= DF ? s1 - DF : s1; s2 = s2 >= DF ? s2 - DF : s2; s3 = s3 >= DF ? s3 - DF : s3;
+            const int cell = C::FIFO_B + (q * (KH - 1) + (KH - 2 - p)) * 4;
+            const int se[4] = {s0, s1, s2, s3};                            // canonical column k of the piece -> its slot
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const float v0 = hin[j].x, v1 = hin[j].y, v2 = hin[j].z, v3 = hin[j].w;
+                st(cell + se[fw ? 3 : 0] * (JS * 4) + (JLO + j) * JSTRIDE, v0);
+                st(cell + se[fw ? 2 : 1] * (JS * 4) + (JLO + j) * JSTRIDE, v1);
+                st(cell + se[fw ? 1 : 2] * (JS * 4) + (JLO + j) * JSTRIDE, v2);
+                st(cell + se[fw ? 0 : 3] * (JS * 4) + (JLO + j) * JSTRIDE, v3);
+            }
+        }
+        hslot += 4;
+        hslot = hslot >= DF ? hslot - DF : hslot;
     };
     // prologue: groups f, f+1 land now (window 0 reads them), f+2 and f+3 wait in the two sets
     if constexpr (NJ > 0) {
         v4f tmp0[NJ], tmp1[NJ];
         zreq(tmp0); zreq(tmp1); zreq(zin[0]); zreq(zin[1]);
         zland(tmp0, IC<0>{}); zland(tmp1, IC<0>{});
+        if constexpr (BSP) {                   // the rows above: piece 0 lands before the loop (window w requests AND lands piece w + 1)
+            hreq();
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            hland();
+        }
     }
+    if constexpr (BSP) __syncthreads();        // every B wave's first piece of the rows above is in the FIFO (the taps read all k-steps)
     // z read address: slot (n mod 12) of this lane
     int zn = ((-p) % 12 + 12) % 12;
 
@@ -446,7 +583,27 @@ __global__ __launch_bounds__(64 * (1 + NBW)) void finc_split_kernel(const float 
         constexpr int par = KU & 1;
         v4f acc[MT];
         // ---- HBM side of the window
-        if constexpr (NJ > 0 && PH == 0) {
+        if constexpr (NJ > 0 && PH == 0 && BSP) {
+            // everything this wave has in memory is waited for here, once per window: last window's stores (two steps old),
+            // requests and progress word.  Then: land z and the piece of the rows above requested a window ago, say how far the
+            // stores got (windows 0 .. w-1 are complete: w of them), request the next pieces.
+            // Window w (BSP).  Step 0: land z (requested two windows ago: long complete, see step 3), ask for the producer's progress
+            // word (no wait), request piece w + 1 of the rows above -- its first reader is step 3 of THIS window's successor... no:
+            // of this window + 1, i.e. four steps from now -- and the next z.  Step 2: stores.  Step 3: the window's ONE wait,
+            // vmcnt(2 NJ): everything up to the requests of step 0 is back (this step's z requests and stores stay in flight), so
+            // the piece lands, the progress word is read, and the stores of the windows 0 .. w-1 are complete: w windows.
+            zland(zin[WP], IC<63>{});
+            hreq();                            // (first: a progress wait that has to spin does so on vmcnt(0), and only last window's stores are in flight)
+            progress_fetch();
+            zreq(zin[WP]);
+        }
+        if constexpr (NJ > 0 && PH == 3 && BSP) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NJ) : "memory");
+            progress_take();
+            hland();
+            publish((t + 1) >> 2);
+        }
+        if constexpr (NJ > 0 && PH == 0 && !BSP) {
             // younger than the set that lands: the other set's requests (NJ) and the stores of the two windows in between
             zland(zin[WP], IC<NJ + 2 * NJ>{});
             zreq(zin[WP]);
@@ -542,13 +699,18 @@ __global__ __launch_bounds__(64 * (1 + NBW)) void finc_split_kernel(const float 
 // -----------------------------------------------------------------------------------------------
 // Instantiations: every bank of the wavefront kernel's table with a 2x2 or 3x3 filter that one wave holds
 // -----------------------------------------------------------------------------------------------
-typedef void (*split_fn)(const float *, const float *, float *, int, int, int, int, int, int, unsigned, int);
+typedef void (*split_fn)(const float *, const float *, float *, int, int, int, int, int, int, unsigned, int, int, int, unsigned *, unsigned *);
 struct SInst {
     int cqp, kh, kw, nbw, lds_bytes;
-    split_fn fn;
+    split_fn fn;      // one workgroup per problem, its bands chained
+    split_fn fn_bsp;  // bands dealt out to several workgroups per problem (BSP)
 };
 template <int CQP, int KH, int KW, int NBW = 3>
-constexpr SInst make_sinst() { return SInst{CQP, KH, KW, NBW, SCfg<CQP, KH, KW, NBW>::LDS_BYTES, finc_split_kernel<CQP, KH, KW, NBW>}; }
+constexpr SInst make_sinst()
+{
+    return SInst{CQP, KH, KW, NBW, SCfg<CQP, KH, KW, NBW>::LDS_BYTES, finc_split_kernel<CQP, KH, KW, NBW, false>,
+                 finc_split_kernel<CQP, KH, KW, NBW, true>};
+}
 
 #ifdef FINC_ONLY_C3
 const SInst g_sinsts[] = {make_sinst<24, 3, 3>(), make_sinst<12, 3, 3>()};
@@ -582,7 +744,75 @@ long long split_max_problems()
     return v;
 }
 
+// ---- BSP: where the progress words live.  One area per device, SLOTS slots of SLOT_WORDS words: [0] epoch, [1] workgroups
+// finished, [2 ..] one word per (problem, workgroup of the problem, B wave).  A launch takes the next slot (round-robin), so two
+// launches in flight on different streams do not share words.  Allocated (and zeroed, synchronously) outside any stream
+// capture: by the packing calls, or by the first launch that finds no capture going on; until then the chained form runs.
+constexpr int BSP_SLOTS = 32, BSP_SLOT_WORDS = 2048, BSP_MAX_NWG = 2;
+constexpr int BSP_MAX_DEV = 64;
+unsigned *g_bsp_area[BSP_MAX_DEV];
+std::atomic<unsigned> g_bsp_next{0};
+std::mutex g_bsp_mutex;
+
+int device_cus()
+{
+    static const int cus = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) {
+            (void)hipGetLastError();
+            return 256;                         // (no device: host-side queries answer for an MI355X)
+        }
+        return n;
+    }();
+    return cus;
+}
+
+// FINC_SPLIT_BANDS=0 keeps every problem on one workgroup (A/B timing, tests of the chained form)
+bool bsp_off()
+{
+    static const bool off = [] { const char *e = finc_env("FINC_SPLIT_BANDS"); return e && e[0] == '0'; }();
+    return off;
+}
+
+// workgroups per problem the band split would use for this problem set (1: the chained form)
+int bsp_nwg(const SInst &i, const FincShape &s)
+{
+    const int P = s.W < 16 ? s.W : 16;
+    const int NB = (s.H + P - 1) / P;
+    const long long problems = (long long)s.B * s.G;
+    // W >= 64: band k + 2 starts W steps after band k on the same workgroup, and by then band k + 1 -- two hand-over lags behind
+    // band k -- must have delivered its first pieces (narrower maps: the two workgroups would wait for each other)
+    if (bsp_off() || i.kh < 2 || NB < 2 || s.W < 64 || 2 * problems > device_cus()) return 1;
+    if (2 + problems * BSP_MAX_NWG * i.nbw > BSP_SLOT_WORDS) return 1;
+    return 2;       // (more workgroups per problem do not shorten the chain: every band boundary costs the same hand-over lag)
+}
+
 } // namespace
+
+int finc_split_prepare(hipStream_t st)
+{
+    int dev = 0;
+    FINC_HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= BSP_MAX_DEV) return FINC_ERR_BAD_DIMS;
+    if (g_bsp_area[dev]) return FINC_OK;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
+    if (cs != hipStreamCaptureStatusNone) return FINC_OK;     // (not now: the launches of this capture run the chained form)
+    std::lock_guard<std::mutex> lk(g_bsp_mutex);
+    if (g_bsp_area[dev]) return FINC_OK;
+    unsigned *a = nullptr;
+    const size_t bytes = sizeof(unsigned) * BSP_SLOTS * BSP_SLOT_WORDS;
+    FINC_HIP_TRY(hipMalloc((void **)&a, bytes));
+    if (hipError_t e = hipMemset(a, 0, bytes); e != hipSuccess) { finc_set_hip_error(e); (void)hipFree(a); return FINC_ERR_LAUNCH; }
+    g_bsp_area[dev] = a;
+    return FINC_OK;
+}
+
+int finc_split_timeouts_count(unsigned *count)
+{
+    FINC_HIP_TRY(hipMemcpyFromSymbol(count, HIP_SYMBOL(finc_split_timeouts), sizeof(unsigned)));
+    return FINC_OK;
+}
 
 #ifdef FINC_SPLIT_STAMP
 extern "C" int finc_debug_split_stamps(unsigned long long *h) { return (int)hipMemcpyFromSymbol(h, HIP_SYMBOL(finc_split_stamps), sizeof(finc_split_stamps)); }
@@ -600,14 +830,17 @@ bool finc_split_takes(const FincShape &s)
     return fifo_fits(*i, s.W, P);
 }
 
-int finc_split_info(const FincShape &s, int *waves, int *lds, int *steps)
+int finc_split_info(const FincShape &s, int *waves, int *lds, int *steps, int *nwg)
 {
     const SInst *i = find_sinst(s.Cq, s.KH, s.KW);
     if (!i) return FINC_ERR_UNSUPPORTED;
     const int P = s.W < 16 ? s.W : 16;
+    const int NB = (s.H + P - 1) / P;
+    const int n = bsp_nwg(*i, s);
     *waves = 1 + i->nbw;
     *lds = i->lds_bytes;
-    *steps = ((s.H + P - 1) / P) * s.W + P - 1;
+    *steps = ((NB + n - 1) / n) * s.W + P - 1;         // steps of one workgroup (BSP: + the hand-over lag between workgroups)
+    if (nwg) *nwg = n;
     return FINC_OK;
 }
 
@@ -616,12 +849,30 @@ int finc_split_launch(const float *in, const void *packed, float *out, const Fin
     const SInst *i = find_sinst(s.Cq, s.KH, s.KW);
     if (!i) return FINC_ERR_UNSUPPORTED;
     const int P = s.W < 16 ? s.W : 16;
-    const int T = ((s.H + P - 1) / P) * s.W + P - 1;           // steps of one problem
-    const int Tr = (T + 2 + UNROLL - 1) / UNROLL * UNROLL - 2; // the B waves' loop is unrolled by UNROLL
+    const int NB = (s.H + P - 1) / P;
     const size_t lds = (size_t)i->lds_bytes;
-    if (int e = finc_ensure_dynamic_lds((const void *)i->fn, lds)) return e;
-    hipLaunchKernelGGL(i->fn, dim3(s.B * s.G), dim3(64 * (1 + i->nbw)), lds, st, in, (const float *)packed, out, s.G, s.Cq, s.H, s.W, P,
-                       Tr, s.orient, fifo_depth(s.W, P, s.KH, s.KW));
+    int nwg = bsp_nwg(*i, s);
+    unsigned *area = nullptr;
+    if (nwg > 1) {
+        (void)finc_split_prepare(st);                          // (allocates unless a capture is going on)
+        int dev = 0;
+        FINC_HIP_TRY(hipGetDevice(&dev));
+        area = (dev >= 0 && dev < BSP_MAX_DEV) ? g_bsp_area[dev] : nullptr;
+        if (!area) nwg = 1;
+    }
+    const int T = ((NB + nwg - 1) / nwg) * s.W + P - 1;        // steps of one workgroup
+    const int Tr = (T + 2 + UNROLL - 1) / UNROLL * UNROLL - 2; // the B waves' loop is unrolled by UNROLL
+    const int DF = fifo_depth(s.W, P, s.KH, s.KW);
+    if (nwg > 1) {
+        if (int e = finc_ensure_dynamic_lds((const void *)i->fn_bsp, lds)) return e;
+        unsigned *slot = area + (size_t)(g_bsp_next.fetch_add(1) % BSP_SLOTS) * BSP_SLOT_WORDS;
+        hipLaunchKernelGGL(i->fn_bsp, dim3(s.B * s.G * nwg), dim3(64 * (1 + i->nbw)), lds, st, in, (const float *)packed, out, s.G, s.Cq, s.H,
+                           s.W, P, Tr, s.orient, DF, nwg, s.B * s.G, slot, finc_fault_device_word());
+    } else {
+        if (int e = finc_ensure_dynamic_lds((const void *)i->fn, lds)) return e;
+        hipLaunchKernelGGL(i->fn, dim3(s.B * s.G), dim3(64 * (1 + i->nbw)), lds, st, in, (const float *)packed, out, s.G, s.Cq, s.H, s.W, P,
+                           Tr, s.orient, DF, 1, s.B * s.G, (unsigned *)nullptr, (unsigned *)nullptr);
+    }
     FINC_CHECK_LAUNCH();
     return FINC_OK;
 }

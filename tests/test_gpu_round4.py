@@ -198,3 +198,72 @@ def test_fault_gate_is_consulted_by_every_launching_entry_point(dev):
     _lib.raise_if_faulted("test")
     m = torch.eye(48, device=dev)
     assert torch.equal(ops.finc_mix(x, m), x)
+
+
+# (B, C, H, W, K): problem sets the band split takes (2 * B * 4 workgroups <= compute units, >= 2 bands, W >= 64): 2 .. 8 bands,
+# partial last bands, an odd number of bands, a padded bank (Cq = 22), 2x2 taps, widths beyond 64
+BAND_SPLIT_CASES = [(32, 96, 64, 64, 3), (4, 96, 64, 64, 3), (3, 96, 48, 64, 3), (2, 96, 33, 64, 3), (8, 48, 17, 72, 3),
+                    (1, 128, 40, 72, 3), (7, 88, 31, 64, 3), (5, 64, 128, 64, 3), (6, 64, 50, 64, 2)]
+
+
+@pytest.mark.parametrize("shape", BAND_SPLIT_CASES, ids=lambda c: "B%d_C%d_%dx%d_k%d" % c)
+def test_band_split_of_the_role_split_inverse(shape, dev):
+    """finc_split.hip, BSP: the bands of a problem dealt out to two workgroups on different compute units, the rows above a band
+    handed over through memory (progress words, write-through stores, loads past the caches).  Same visitation inside a band
+    (cinc_cuda_kernel_level2.cu:49-56) -- against the oracle's fp64 path, against the chained form (FINC_SPLIT_BANDS=0 is another
+    process: here the strict kernel stands in as the independent answer), repeated launches bit-identical (the epoch of the
+    progress words advances on the device), no wait gave up."""
+    from fincflow_amd import FastFlowUnit, _lib, ops
+    B, C, H, W, K = shape
+    v = _lib.inverse_variant(B, 4, C // 4, H, W, K, K)
+    assert v is not None and v["sec"] == 4 and v["workgroups"] == 2 * B * 4, v
+    torch.manual_seed(sum(shape))
+    unit = FastFlowUnit(C, C, K).to(dev)
+    x = torch.randn(B, C, H, W, device=dev)
+    with torch.no_grad():
+        z, _ = unit(x)
+        got = unit.reverse(z)
+        strict = ops.finc_inverse(z, unit._cache.w_canon, algo="strict")
+        again = [unit.reverse(z) for _ in range(4)]
+    torch.cuda.synchronize()
+    ws = torch.cat(unit._weights()).detach().cpu().numpy()
+    wco = oracle.canonicalize(ws, 4, ORIENT_FASTFLOW)
+    pick = sorted({0, B // 2, B - 1})
+    want = oracle.inverse_via_f64(z[pick].cpu().numpy(), wco, 4, ORIENT_FASTFLOW, nthreads=8)
+    e = rel_err(got[pick].cpu().numpy(), want)
+    report("band_split", shape=list(shape), err_max_norm=e, err_elementwise=elem_rel_err(got[pick].cpu().numpy(), want))
+    assert e <= TOL, e
+    assert rel_err(got.cpu().numpy(), strict.cpu().numpy()) <= TOL
+    assert all(torch.equal(a, got) for a in again)
+    assert _lib.hlp_timeouts() == 0 and not _lib.fault_pending()
+
+
+def test_band_split_in_a_captured_graph_and_with_a_folded_affine_map(dev):
+    """A captured launch keeps its slot of progress words; the epoch lives on the device, so every replay starts clean.  The
+    affine fold rides on the band split like on the chained form (same packed bank)."""
+    from fincflow_amd import FastFlowUnit, _lib, glow
+    B, C, H, W = 8, 96, 64, 64
+    assert _lib.inverse_variant(B, 4, C // 4, H, W, 3, 3)["workgroups"] == 2 * B * 4
+    torch.manual_seed(5)
+    unit = FastFlowUnit(C, C, 3).to(dev)
+    an = glow.ActNorm(C).to(dev)
+    with torch.no_grad():
+        an.log_scale.copy_(0.2 * torch.randn(C, device=dev))
+        an.translation.copy_(torch.randn(C, device=dev))
+        an.initialized.fill_(1)
+    y = torch.randn(B, C, H, W, device=dev)
+    with torch.no_grad():
+        two = unit.reverse(an.reverse(y))
+        fused = unit.reverse_affine(y, an.log_scale, an.translation)
+        assert fused is not None and rel_err(fused.cpu().numpy(), two.cpu().numpy()) <= TOL
+        ref = unit.reverse(y)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = unit.reverse(y)
+        for _ in range(5):
+            out.zero_()
+            g.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(out, ref)
+    assert _lib.hlp_timeouts() == 0 and not _lib.fault_pending()
