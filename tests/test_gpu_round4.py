@@ -141,7 +141,7 @@ def test_affine_fold_declines_where_the_kernel_cannot_carry_a_shift(shape, dev):
         chain = seq._reverse_chain(y, None)
     ws = torch.cat(unit._weights()).detach().cpu().numpy()
     wco = oracle.canonicalize(ws, 4, ORIENT_FASTFLOW)
-    zin = (y * torch.exp(an.log_scale).view(1, -1, 1, 1) + an.translation.view(1, -1, 1, 1)).cpu().numpy()
+    zin = (y * torch.exp(an.log_scale).view(1, -1, 1, 1) + an.translation.view(1, -1, 1, 1)).detach().cpu().numpy()
     want = oracle.inverse_via_f64(zin, wco, 4, ORIENT_FASTFLOW, nthreads=8)
     tol = max(TOL, 2.0 * rel_err(oracle.inverse_f32(zin, wco, 4, ORIENT_FASTFLOW, nthreads=8), want))   # (as test_wide_maps_...)
     assert rel_err(two.cpu().numpy(), want) <= tol
@@ -163,7 +163,7 @@ def test_affine_fold_declines_where_the_kernel_cannot_carry_a_shift(shape, dev):
     # a scale alone rides on the wide map too; and re-packing the same buffer without a shift revives it
     assert L.finc_pack_inverse_weights_affine_f32(wc.data_ptr(), scale.data_ptr(), None, packed.data_ptr(), 4, Cq, 3, 3, st) == 0
     assert L.finc_inverse_packed_f32(y.data_ptr(), packed.data_ptr(), out.data_ptr(), B, 4, Cq, H, W, 3, 3, ORIENT_FASTFLOW, st) == 0
-    want_scale = oracle.inverse_via_f64((y * torch.exp(an.log_scale).view(1, -1, 1, 1)).cpu().numpy(), wco, 4, ORIENT_FASTFLOW, nthreads=8)
+    want_scale = oracle.inverse_via_f64((y * torch.exp(an.log_scale).view(1, -1, 1, 1)).detach().cpu().numpy(), wco, 4, ORIENT_FASTFLOW, nthreads=8)
     assert rel_err(out.cpu().numpy(), want_scale) <= tol
 
 
