@@ -462,7 +462,7 @@ class _FincConvFunction(torch.autograd.Function):
     def forward(ctx, x, cache, G, orient, *weights):
         x = x.contiguous()
         out = cache.forward(x, list(weights), G, orient, validate=False)
-        ctx.save_for_backward(x, cache.get(list(weights), G, orient))
+        ctx.save_for_backward(x, cache._get(list(weights), G, orient, validate=False).w_canon)   # (same entry: no check, no synchronisation)
         ctx.G, ctx.orient, ctx.nw = G, orient, len(weights)
         return out
 
