@@ -814,7 +814,9 @@ def bench_unit(args):
         conv_form = _lt.backward_variant(B, 4, Cq, H, W, K, K)["conv_form"]
         # multiplies the forward kernel executes: Winograd F(2,3) = 4 frequencies x 3 row taps per 2 outputs (2/3 of the direct
         # sum's), F(4,3) = 6 x 3 per 4 outputs (1/2)
-        fwd_flops = alg_flops * 2 // 3 if conv_form == "winograd" else alg_flops // 2 if conv_form == "winograd4" else alg_flops
+        # (5x5: F(2,5) = 6 frequencies x 5 row taps per 2 outputs: 3/5)
+        fwd_flops = (alg_flops * 2 // 3 if conv_form == "winograd" else alg_flops // 2 if conv_form == "winograd4"
+                     else alg_flops * 3 // 5 if conv_form == "winograd25" else alg_flops)
         inv, fwd, smp = launch_stats(inv_per), launch_stats(fwd_per), launch_stats(smp_per)
         inv_launch_ms, fwd_launch_ms = inv["mean_ms"], fwd["mean_ms"]
         inv_gbs = alg_bytes / (inv_launch_ms * 1e-3) / 1e9
@@ -864,7 +866,9 @@ def bench_unit(args):
                                 f"HBM peak" + (f"; the Winograd F(2,3) kernel executes 2/3 of the direct multiplies, which lifts "
                                                f"that ceiling to {hbm_ceiling * 1.5:.0%}" if conv_form == "winograd" else
                                                f"; the Winograd F(4,3) kernel executes 1/2 of the direct multiplies, which lifts "
-                                               f"that ceiling to {hbm_ceiling * 2:.0%}" if conv_form == "winograd4" else "")},
+                                               f"that ceiling to {hbm_ceiling * 2:.0%}" if conv_form == "winograd4" else
+                                               f"; the Winograd F(2,5) kernel executes 3/5 of the direct multiplies, which lifts "
+                                               f"that ceiling to {hbm_ceiling / 0.6:.0%}" if conv_form == "winograd25" else "")},
             "training_step": {"what": "z = unit(x); z.backward(gz): forward + grad-input + grad-weight with the corner-tap mask "
                                       "(SURVEY 8 f1), HIP kernels under autograd", "ms_per_step": tr_dt / tr_steps * 1e3,
                               "steps": tr_steps, "launch": launch_stats(tr_per),

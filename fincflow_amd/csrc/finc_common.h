@@ -134,6 +134,12 @@ int finc_wino_launch(const float *in, const void *packed, float *out, const Finc
 int finc_wino_form(const FincShape &s);                                // 2: F(2,3), 4: F(4,3) -- which of the two a call runs
 int finc_wino_set_form(int form);                                      // 0 library's choice, 1 strip kernel, 2 F(2,3), 4 F(4,3)
 unsigned finc_build_flags_wino();
+// ---- 5x5 forward / grad-input with 0.6 x the multiplies (Winograd F(2,5) along W): finc_wino5.hip; bank behind the strip kernels'
+size_t finc_wino5_packed_bytes(int G, int Cq, int KH, int KW);         // 0: no such kernel for this bank
+bool finc_wino5_takes(const float *in, const float *out, const FincShape &s);
+int finc_wino5_pack(const float *wc, void *packed, int G, int Cq, bool transpose, hipStream_t st, const float *scale, const float *shift);
+int finc_wino5_launch(const float *in, const void *packed, float *out, const FincShape &s, hipStream_t st);
+unsigned finc_build_flags_wino5();
 size_t finc_gradw_workspace_bytes(const FincShape &s); // 0: no MFMA grad-weight kernel for this shape
 int finc_gradw_launch(const float *gz, const float *x, float *gw, void *workspace, const FincShape &s, hipStream_t st);
 int finc_gradw_variant(const FincShape &s);   // 0 direct, 1 dword MFMA, 2 staged, 3 tiled

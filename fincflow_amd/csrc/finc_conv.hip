@@ -628,7 +628,8 @@ static size_t conv_bank_bytes(const ConvInst *i, int G) { return (size_t)(i->nfr
 size_t finc_conv_packed_bytes(int G, int Cq, int KH, int KW)
 {
     const ConvInst *i = find_conv(Cq, KH, KW);
-    return i ? conv_bank_bytes(i, G) + finc_wino_packed_bytes(G, Cq, KH, KW) + finc_bigfwd_packed_bytes(G, Cq, KH, KW) : 0;
+    return i ? conv_bank_bytes(i, G) + finc_wino_packed_bytes(G, Cq, KH, KW) + finc_bigfwd_packed_bytes(G, Cq, KH, KW) +
+                   finc_wino5_packed_bytes(G, Cq, KH, KW) : 0;   // (at most one of the three exists for a bank)
 }
 
 int finc_conv_pack(const float *wc, void *packed, int G, int Cq, int KH, int KW, bool transpose, hipStream_t st,
@@ -646,6 +647,8 @@ int finc_conv_pack(const float *wc, void *packed, int G, int Cq, int KH, int KW,
         return finc_wino_pack(wc, (char *)packed + conv_bank_bytes(i, G), G, Cq, transpose, st, scale, shift);
     if (finc_bigfwd_packed_bytes(G, Cq, KH, KW))   // (the banks beyond the one-wave kernels: the M-split of finc_big.hip)
         return finc_bigfwd_pack(wc, (char *)packed + conv_bank_bytes(i, G), G, Cq, KH, KW, transpose, st, scale, shift);
+    if (finc_wino5_packed_bytes(G, Cq, KH, KW))    // (5x5: Winograd F(2,5) along W, finc_wino5.hip)
+        return finc_wino5_pack(wc, (char *)packed + conv_bank_bytes(i, G), G, Cq, transpose, st, scale, shift);
     return FINC_OK;
 }
 
@@ -658,6 +661,9 @@ int finc_conv_launch(const float *in, const void *packed, float *out, const Finc
         return finc_wino_launch(in, (const char *)packed + conv_bank_bytes(i, s.G), out, s, st);
     if (finc_bigfwd_packed_bytes(s.G, s.Cq, s.KH, s.KW) && finc_bigfwd_takes(in, out, s))
         return finc_bigfwd_launch(in, (const char *)packed + conv_bank_bytes(i, s.G), out, s, st);
+    // 5x5 with 0.6 x the multiplies (Winograd F(2,5) along W: finc_wino5.hip) where the call allows it
+    if (finc_wino5_packed_bytes(s.G, s.Cq, s.KH, s.KW) && finc_wino5_takes(in, out, s))
+        return finc_wino5_launch(in, (const char *)packed + conv_bank_bytes(i, s.G), out, s, st);
     const int NS = (s.W + 15) / 16;
     // about one wave per SIMD (measured: more chunks than that cost more in per-wave bank loads than they gain; 2 chunks
     // still pay up to 2 waves per SIMD), in chunks of at least 4 rows (every chunk recomputes KH-1 rows of operands)
@@ -690,6 +696,7 @@ int finc_conv_variant(int B, int G, int Cq, int H, int W, int KH, int KW, int *i
     const FincShape s{B, G, Cq, H, W, KH, KW, 0};
     if (finc_wino_packed_bytes(G, Cq, KH, KW) && finc_wino_takes(nullptr, nullptr, s)) info[1] = finc_wino_form(s) == 4 ? 4 : 2;   // (2: Winograd F(2,3), 4: F(4,3))
     if (finc_bigfwd_packed_bytes(G, Cq, KH, KW) && finc_bigfwd_takes(nullptr, nullptr, s)) info[1] = 3;   // (3: the big banks' M-split)
+    if (finc_wino5_packed_bytes(G, Cq, KH, KW) && finc_wino5_takes(nullptr, nullptr, s)) info[1] = 5;     // (5: Winograd F(2,5), 5x5)
     return FINC_OK;
 }
 

@@ -240,11 +240,12 @@ int finc_inverse_kernel_variant(int B, int G, int Cq, int H, int W, int KH, int 
 /* Which kernels finc_backward_f32 runs for this shape (16-byte aligned activations, full workspace): info[3] =
  * {grad-weight: 0 direct / 1 dword MFMA strip kernel / 2 staged (16-byte pieces through LDS) / 3 tiled (one tile pair per
  * workgroup), grad-input: waves per strip of the MFMA strip kernel (0 = direct kernel; > 1 = K-split), grad-input: staged form
- * (1) or dword form (0); 2 = Winograd F(2,3) along W, 3 = the big banks' M-split, 4 = Winograd F(4,3) along W}.  Lets a parity
+ * (1) or dword form (0); 2 = Winograd F(2,3) along W, 3 = the big banks' M-split, 4 = Winograd F(4,3) along W, 5 = Winograd
+ * F(2,5) along W (5x5 banks)}.  Lets a parity
  * test assert WHICH kernel its numbers came from. */
 int finc_debug_backward_variant(int B, int G, int Cq, int H, int W, int KH, int KW, int *info);
 /* Pins the kernel family of the 3x3 forward / grad-input for this process (tests and A/B timing of each form on one shape):
- * 0 = the library's choice (default), 1 = the direct strip kernel, 2 = Winograd F(2,3), 4 = Winograd F(4,3).  A form a call
+ * 0 = the library's choice (default), 1 = the direct strip kernels (3x3 and 5x5), 2 = Winograd F(2,3), 4 = Winograd F(4,3).  A form a call
  * cannot take (width not a multiple of 4, unaligned activations, bank too large) still falls back to the strip kernel. */
 int finc_debug_set_forward_form(int form);
 int finc_debug_inverse_table_row(int row, int *info);

@@ -267,3 +267,65 @@ def test_band_split_in_a_captured_graph_and_with_a_folded_affine_map(dev):
             torch.cuda.synchronize()
             assert torch.equal(out, ref)
     assert _lib.hlp_timeouts() == 0 and not _lib.fault_pending()
+
+
+# (B, C, H, W): every bank of finc_wino5.hip (Cq = 4 .. 48, padded channel counts among them: Cq = 20 on the 24-channel two-wave
+# bank, 40 on the 48-channel one), one and several strips of 32 columns, a partial last strip, maps shorter than the four-row
+# prologue, row chunks (few strips), the c5 bank at its per-GPU width
+FORWARD_55_CASES = [(1, 16, 12, 20), (2, 32, 9, 32), (2, 48, 3, 34), (3, 64, 17, 64), (2, 80, 20, 24), (2, 96, 33, 40), (1, 128, 16, 96),
+                    (2, 160, 7, 30), (2, 192, 24, 128), (1, 192, 40, 36)]
+
+
+@pytest.mark.parametrize("shape", FORWARD_55_CASES, ids=lambda c: "B%d_C%d_%dx%d" % c)
+def test_5x5_forward_with_fewer_multiplies(shape, dev):
+    """finc_wino5.hip: Winograd F(2,5) along W for the 5x5 banks (0.6 x the MFMAs of the direct sum; layers/conv.py:102-107 is free
+    to run any exact reformulation) -- forward, grad-input (the same kernel on transposed fragments) and the output-side affine fold
+    against fp64 F.pad + F.conv2d autograd on the CPU, all four corner orientations of a FastFlowUnit; the direct strip kernels
+    (finc_debug_set_forward_form(1)) beside it on the same data."""
+    import torch.nn.functional as F
+    from fincflow_amd import FastFlowUnit, _lib
+    B, C, H, W = shape
+    torch.manual_seed(sum(shape))
+    unit = FastFlowUnit(C, C, 5)
+    with torch.no_grad():
+        for m in (unit.conv_tl, unit.conv_tr, unit.conv_bl, unit.conv_br):
+            m.conv.weight.mul_(1 - 0.6 * m.get_mask())               # N(0, 0.02^2) free taps, as bench.py's c5 (DESIGN 4)
+    unit = unit.to(dev)
+    x = torch.randn(B, C, H, W, device=dev)
+    gz = torch.randn(B, C, H, W, device=dev)
+    xd = x.detach().cpu().double().requires_grad_(True)
+    ref = torch.cat([F.conv2d(F.pad(c, m.pad), m.conv.weight.detach().cpu().double()) for m, c in
+                     zip((unit.conv_tl, unit.conv_tr, unit.conv_bl, unit.conv_br), torch.chunk(xd, 4, 1))], 1)
+    ref.backward(gz.cpu().double())
+    log_scale, translation = 0.3 * torch.randn(C, device=dev), torch.randn(C, device=dev)
+    ref_aff = (ref.detach() - translation.cpu().double().view(1, -1, 1, 1)) * torch.exp(-log_scale).cpu().double().view(1, -1, 1, 1)
+    worst = {}
+    try:
+        for form, want in ((0, "winograd25"), (1, ("strip", "strip16"))):
+            _lib.set_forward_form(form)
+            got_form = _lib.backward_variant(B, 4, C // 4, H, W, 5, 5)["conv_form"]
+            assert got_form == want or got_form in want, (form, got_form)
+            xg = x.clone().requires_grad_(True)
+            z, logdet = unit(xg)
+            z.backward(gz)
+            assert logdet == 0.0
+            with torch.no_grad():
+                fused = unit.forward_affine(x, log_scale, translation)
+            assert fused is not None
+            e = (rel_err(z.detach().cpu().numpy(), ref.detach().numpy()), rel_err(xg.grad.cpu().numpy(), xd.grad.numpy()),
+                 rel_err(fused.cpu().numpy(), ref_aff.numpy()))
+            worst[form] = max(e)
+            assert worst[form] <= TOL, (form, e)
+    finally:
+        _lib.set_forward_form(0)
+    report("forward_5x5_forms", shape=list(shape), f25=worst[0], strip=worst[1])
+
+
+def test_5x5_forward_on_the_reference_fixture(dev):
+    """unit_B1_C16_12x20_k5 (reference-generated, tests/golden/make_golden.py): the F(2,5) kernel's forward against the reference's z."""
+    from fincflow_amd import _lib, ops
+    g = golden("unit_B1_C16_12x20_k5")
+    assert _lib.backward_variant(1, 4, 4, 12, 20, 5, 5)["conv_form"] == "winograd25"
+    wc = ops.canonicalize(t(unit_stored_weights(g), dev), 4, ORIENT_FASTFLOW)
+    z = ops.finc_forward(t(g["x"], dev), wc, 4, ORIENT_FASTFLOW).cpu().numpy()
+    assert rel_err(z, g["z"]) <= TOL

@@ -88,3 +88,57 @@ def test_f43_fp32_error_model_stays_within_the_margin_the_gpu_test_asserts():
     _check(textbook, 4, 3)
     e_ship, e_text = run(F43), run(textbook)
     assert e_ship < 2.5e-6 and e_ship < e_text, (e_ship, e_text)
+
+
+h = Fr(1, 2)                                                                              # points 0, +-1, +-1/2, infinity
+F25 = dict(
+    BT=[[1, 0, -5, 0, 4, 0],                                                              # d0 - 5 d2 + 4 d4
+        [0, -1, -1, 4, 4, 0],                                                             # (4 d4 - d2) + (4 d3 - d1)
+        [0, 1, -1, -4, 4, 0],                                                             # (4 d4 - d2) - (4 d3 - d1)
+        [0, 1, 2, -1, -2, 0],                                                             # 2 (d2 - d4) + (d1 - d3)
+        [0, -1, 2, 1, -2, 0],                                                             # 2 (d2 - d4) - (d1 - d3)
+        [0, 1, 0, -5, 0, 4]],                                                             # d1 - 5 d3 + 4 d5
+    G=[[1, 0, 0, 0, 0],
+       [Fr(1, 6)] * 5, [Fr(1, 6), Fr(-1, 6), Fr(1, 6), Fr(-1, 6), Fr(1, 6)],              # (g0 +- g1 + g2 +- g3 + g4) / 6
+       [Fr(16, 12), Fr(8, 12), Fr(4, 12), Fr(2, 12), Fr(1, 12)],                          # (16 g0 +- 8 g1 + 4 g2 +- 2 g3 + g4) / 12
+       [Fr(16, 12), Fr(-8, 12), Fr(4, 12), Fr(-2, 12), Fr(1, 12)],
+       [0, 0, 0, 0, Fr(1, 4)]],                                                           # g4 / 4
+    AT=[[1, 1, 1, 1, 1, 0], [0, 1, -1, h, -h, 1]],                                        # y0 = M0+..+M4, y1 = (M1-M2) + (M3-M4)/2 + M5
+)
+
+
+def test_f25_matrices_are_exact():
+    """finc_wino5.hip (5x5 banks): the comment block at the top of the file, wino5_walk's `transform`, its output transform and
+    wino5_pack_kernel."""
+    _check(F25, 2, 5)
+    for row in F25["BT"] + F25["AT"]:
+        for x in row:
+            x = Fr(x)
+            assert x.denominator & (x.denominator - 1) == 0 and np.float32(float(x)) == float(x)
+    # frequency 1 (the point +1) enters both outputs with weight 1: the folded shift rides in as its start value
+    assert [Fr(F25["AT"][i][1]) for i in range(2)] == [1, 1]
+
+
+def test_f25_fp32_error_model():
+    """The kernel's arithmetic in numpy fp32 at the c5 bank (Cq = 48, K = 240 accumulations per frequency, weights N(0, 0.02^2) as
+    bench.py's c5): far inside BASELINE.json's 1e-5."""
+    rng = np.random.default_rng(0)
+    Cq, N, r, m = 48, 1024, 5, 2
+    w = (rng.standard_normal((Cq, Cq, r, r)) * 0.02).astype(np.float32)
+    x = rng.standard_normal((Cq, r, N + r - 1)).astype(np.float32)
+    ref = np.zeros((Cq, N))
+    for a in range(r):
+        for k in range(r):
+            ref += w[:, :, a, k].astype(np.float64) @ x[:, a, k:k + N].astype(np.float64)
+    BT, G, AT = (np.array([[float(Fr(v)) for v in row] for row in F25[k]]) for k in ("BT", "G", "AT"))
+    n = m + r - 1
+    U = np.einsum("fk,oiak->oiaf", G, w.astype(np.float64)).astype(np.float32)
+    idx = (np.arange(N // m) * m)[:, None] + np.arange(n)[None, :]
+    V = np.einsum("fr,iatr->iatf", BT.astype(np.float32), x[:, :, idx]).astype(np.float32)
+    M = np.zeros((Cq, N // m, n), np.float32)
+    for a in range(r):
+        for i in range(Cq):
+            M += U[:, i, a, None, :] * V[None, i, a, :, :]
+    Y = np.einsum("mf,otf->otm", AT.astype(np.float32), M).astype(np.float32).reshape(Cq, N)
+    e = np.abs(Y - ref).max() / np.abs(ref).max()
+    assert e < 4e-6, e
