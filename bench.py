@@ -172,28 +172,33 @@ class Sensors:
 
         def run():
             while not self._stop.is_set():
+                ts = time.perf_counter()
                 if self.power_path:
                     v = self._read(self.power_path)
                     if v is not None:
-                        self._p.append(v * 1e-6)            # microwatts
+                        self._p.append((ts, v * 1e-6))      # microwatts
                 if self.freq_path:
                     v = self._read(self.freq_path)
                     if v is not None:
-                        self._f.append(v * 1e-6)            # hertz
+                        self._f.append((ts, v * 1e-6))      # hertz
                 self._stop.wait(0.004)
 
         self._thread = threading.Thread(target=run, daemon=True)
         self._thread.start()
 
-    def stop(self):
+    def stop(self, t0=None, t1=None):
+        """Stops the sampler; the statistics cover the samples taken in [t0, t1] (the timed region -- the sampler itself is started
+        before the leg's untimed spin-up, so that the first, slow, read of the driver's files does not fall into the timed steps)."""
         if self._thread is None:
             return {"power_w": None, "smi_sclk_mhz": None, "samples": 0, "source": self.note}
         self._stop.set()
         self._thread.join()
         self._thread = None
+        inside = lambda v: [x for ts, x in v if (t0 is None or ts >= t0) and (t1 is None or ts <= t1)] or [x for _, x in v[-1:]]
+        p, f = inside(self._p), inside(self._f)
         mean = lambda v: (sum(v) / len(v)) if v else None
-        return {"power_w": mean(self._p), "power_w_max": max(self._p) if self._p else None, "smi_sclk_mhz": mean(self._f),
-                "samples": max(len(self._p), len(self._f)), "source": self.note}
+        return {"power_w": mean(p), "power_w_max": max(p) if p else None, "smi_sclk_mhz": mean(f),
+                "samples": max(len(p), len(f)), "source": self.note}
 
 
 class Harness:
@@ -274,6 +279,8 @@ class Harness:
         the launch stream (torch's current stream IS the stream the ABI call launches on).  Returns the max-over-ranks
         wall time, every rank's wall time and the sorted per-launch milliseconds of this rank."""
         torch = self.torch
+        if self.sensors is not None and not self.stub:
+            self.sensors.start()
         self.spin_up(fn)
         for _ in range(warmup):
             fn()
@@ -291,8 +298,6 @@ class Harness:
         else:
             evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
             self.barrier()
-            if self.sensors is not None:
-                self.sensors.start()
             t0 = time.perf_counter()
             for a, b in evs:
                 a.record()
@@ -300,7 +305,7 @@ class Harness:
                 b.record()
             self.barrier()
             dt = time.perf_counter() - t0
-            self.last_sensors = self.sensors.stop() if self.sensors is not None else None
+            self.last_sensors = self.sensors.stop(t0, t0 + dt) if self.sensors is not None else None
             per = sorted(a.elapsed_time(b) for a, b in evs)
         ranks = [dt]
         if self.world > 1:
@@ -316,6 +321,7 @@ class Harness:
         stream; per-launch times are HIP events as everywhere.  Returns (launch stats, probe stats, sensor stats)."""
         torch = self.torch
         from fincflow_amd import _lib
+        self.sensors.start()
         self.spin_up(fn)
         for _ in range(warmup):
             fn()
@@ -323,13 +329,13 @@ class Harness:
         self.barrier()
         stream = torch.cuda.current_stream(self.dev)
         _lib.clock_probe_begin(period_us=100, max_ms=3000)
-        self.sensors.start()
+        t0 = time.perf_counter()
         for a, b in evs:
             a.record()
             fn()
             b.record()
         stream.synchronize()
-        sens = self.sensors.stop()
+        sens = self.sensors.stop(t0, time.perf_counter())
         probe = _lib.clock_probe_end()
         self.barrier()
         return launch_stats(sorted(a.elapsed_time(b) for a, b in evs)), probe, sens

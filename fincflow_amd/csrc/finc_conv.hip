@@ -600,7 +600,9 @@ const ConvInst g_conv[] = {
     make_conv<32, 2, 2>(),
     make_conv<4, 5, 5>(),  make_conv<8, 5, 5>(),  make_conv<12, 5, 5>(), make_conv<16, 5, 5>(), make_conv<24, 5, 5, 2>(), make_conv<32, 5, 5, 4>(),
     make_conv<48, 5, 5, 4>(),
-    make_conv<4, 3, 5>(),  make_conv<4, 1, 3>(),  make_conv<4, 3, 1>(),
+    make_conv<4, 3, 5>(),  make_conv<8, 3, 5>(),  make_conv<16, 3, 5>(),
+    make_conv<4, 2, 3>(),  make_conv<8, 2, 3>(),  make_conv<16, 2, 3>(),
+    make_conv<4, 1, 3>(),  make_conv<4, 3, 1>(),
 };
 // the smallest compiled bank that holds Cq channels (padded channels are masked in-kernel: one-wave banks hold up to 3 of
 // them -- the table has every multiple of 4 there --, the K-split banks any number)

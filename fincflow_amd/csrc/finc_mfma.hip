@@ -1517,7 +1517,9 @@ const Inst g_insts[] = {
     // (Cq = 17 .. 24 at 5x5 -- the 20-channel 5x5 layers of fastflow/test_examples.py:218-222 -- on two waves: the operands
     // of a 5x5 filter do not rotate in place, and their ageing copies beside 450 fragments do not fit one wave)
     make_inst<24, 5, 5, 2>(), make_inst<32, 5, 5, 4>(), make_inst<48, 5, 5, 4>(),
-    FINC_BOTH(4, 3, 5),
+    // non-square filters (PaddedConv2d takes a (K_H, K_W) tuple, layers/conv.py:30-36; the reference's fixtures have 3x5 and 2x3)
+    FINC_BOTH(4, 3, 5),  FINC_BOTH(8, 3, 5),  FINC_BOTH(16, 3, 5),
+    FINC_BOTH(4, 2, 3),  FINC_BOTH(8, 2, 3),  FINC_BOTH(16, 2, 3),
 };
 #endif
 
