@@ -15,8 +15,16 @@ for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursiv
             k = "forward_wino4"
         elif "finc_wino_kernel" in k:
             k = "forward_wino"
+        elif "finc_wino5_kernel" in k:
+            k = "forward_wino5"
         elif "finc_gradw_staged_kernel" in k:
             k = "gradw_staged"
+        elif "finc_gradw_tiled_kernel" in k:
+            k = "gradw_tiled"
+        elif "finc_big_kernel" in k:
+            k = "inverse_big"
+        elif "finc_bigfwd_kernel" in k:
+            k = "forward_big"
         else:
             continue
         acc[k][row["Counter_Name"]].append(float(row["Counter_Value"]))

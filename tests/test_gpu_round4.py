@@ -376,5 +376,5 @@ def test_non_square_filters_run_on_mfma(case, dev):
     assert rel_err(xg.grad[pick].cpu().numpy(), xd.grad.numpy()) <= TOL
     if len(pick) == B:                                                # (the weight gradient sums over the batch)
         for m, w in zip((unit.conv_tl, unit.conv_tr, unit.conv_bl, unit.conv_br), wds):
-            want = (w.grad * m.get_mask().double()).numpy()
+            want = (w.grad * m.get_mask().cpu().double()).numpy()
             assert rel_err(m.conv.weight.grad.cpu().numpy(), want) <= 1e-4
