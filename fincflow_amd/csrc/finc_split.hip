@@ -683,6 +683,12 @@ __global__ __launch_bounds__(64 * (1 + NBW)) void finc_split_kernel(const float 
         [&]<int... K>(std::integer_sequence<int, K...>) { ((bstep(IC<K>{}, t0 + K)), ...); }(std::make_integer_sequence<int, UNROLL>{});
     }
     // (the last window's store covers the last group of every lane: T + 1 >= NB*W + P and P/4 + fs >= -1)
+    if constexpr (BSP && NJ > 0) {
+        // the stores of the last windows are not yet accounted for in the progress word (a window's stores are said complete two
+        // windows later, and the loop ends with them): the consumer of this workgroup's LAST band waits for exactly those
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        publish(0xFFFFF);
+    }
 #ifdef FINC_SPLIT_STAMP
     if (blockIdx.x == 0 && lane == 0) finc_split_stamps[1 + bi] = st_busy;
 #else
