@@ -444,6 +444,23 @@ __global__ __launch_bounds__(64 * (1 + NBW)) void finc_split_kernel(const float 
         scol += 4; soff += dgrp;
         if (scol == W) { scol = 0; srow += band_rows; soff += drow; }
     };
+    // BSP: the rows that are handed over leave EARLY.  The group a lane of the last KH-1 rows stores in step 2 of a window is
+    // complete two steps before (lane 15 solves the last pixel of group w - 5 in step 4w - 2), so at step 0 those lanes store it
+    // already (the others do nothing; step 2 stores the whole instruction again, which is harmless): its completion is then
+    // covered by the window's one counted wait at step 3, and the progress word says so four steps sooner.
+    auto xstore_early = [&]() {
+        const bool ok = scol >= 0 && srow < H && p >= P - (KH - 1) && p < P;
+        const unsigned base = ok ? (unsigned)soff : OFF_INVALID;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            v4f v;
+            v.x = ld((xs0 ^ stog) + (JLO + j) * JSTRIDE);
+            v.y = ld((xs1 ^ stog) + (JLO + j) * JSTRIDE);
+            v.z = ld((xs2 ^ stog) + (JLO + j) * JSTRIDE);
+            v.w = ld((xs3 ^ stog) + (JLO + j) * JSTRIDE);
+            asm volatile("buffer_store_dwordx4 %0, %1, %2, 0 offen sc0 sc1\n\ts_nop 1" ::"v"(v), "v"(base + xmask[j]), "s"(rout) : "memory");
+        }
+    };
     // ---- BSP: the rows above a band, fetched from the output of the workgroup that solves the band above.
     // Lanes (q, p < KH-1) carry row a' = p + 1 above the band; a piece of 4 canonical columns goes to the 4 FIFO slots the chained
     // form pushes those pixels to: pixel (row -a', column c) of this workgroup's local band i = the push of lane P - a' at local
@@ -451,7 +468,8 @@ __global__ __launch_bounds__(64 * (1 + NBW)) void finc_split_kernel(const float 
     // slot of the previous content (DF steps earlier) was read by local step (i-1)*W + c + P + KH + KW - 2 at the latest and the
     // new one is first read at i*W + c - 1: the piece lands one window before that, two after it was requested.
     // Progress: producer B wave `bi` of workgroup wgp = (wg - 1) mod nwg publishes, in its word, the number of its local windows
-    // whose stores are complete; group gq of its local band i' leaves in its window i'*W/4 + gq + 5 (rows P-2, P-1: fs4 = -5).
+    // whose HANDED-OVER stores are complete; group gq of its local band i' leaves (early, step 0) in its window i'*W/4 + gq + 5
+    // (rows P-2, P-1: fs4 = -5) and is complete by that window's step 3: word >= i'*W/4 + gq + 6.
     const bool hl = BSP && p < KH - 1;
     int hcol = 0, hband = 0;
     int hoff = BSP ? piece_off(row0 - 1 - p, 0) : 0;
@@ -593,7 +611,8 @@ __global__ __launch_bounds__(64 * (1 + NBW)) void finc_split_kernel(const float 
             // vmcnt(2 NJ): everything up to the requests of step 0 is back (this step's z requests and stores stay in flight), so
             // the piece lands, the progress word is read, and the stores of the windows 0 .. w-1 are complete: w windows.
             zland(zin[WP], IC<63>{});
-            hreq();                            // (first: a progress wait that has to spin does so on vmcnt(0), and only last window's stores are in flight)
+            xstore_early();                    // (the rows handed over: this window's group of the last KH-1 lanes)
+            hreq();                            // (a progress wait that has to spin does so on vmcnt(0): only stores are in flight)
             progress_fetch();
             zreq(zin[WP]);
         }
@@ -601,7 +620,7 @@ __global__ __launch_bounds__(64 * (1 + NBW)) void finc_split_kernel(const float 
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NJ) : "memory");
             progress_take();
             hland();
-            publish((t + 1) >> 2);
+            publish(((t + 1) >> 2) + 1);       // the handed-over stores of the windows 0 .. w are complete: w + 1 windows
         }
         if constexpr (NJ > 0 && PH == 0 && !BSP) {
             // younger than the set that lands: the other set's requests (NJ) and the stores of the two windows in between

@@ -5,9 +5,9 @@ k - 1, which the OTHER workgroup solves.  The kernel's rules, restated (all in u
 workgroup; GR = W / 4 store groups per row):
   * at step 0 of its window w a B wave requests piece w + 1 of the rows above (group gq = (w + 1) % GR of its local band
     i = (w + 1) // GR) and, if that band has a band above it in the image, first WAITS until the producer's progress word is at
-    least  i' * GR + gq + 6  (i' = the producer's local index of the band above): the group leaves the producer in its window
-    i' * GR + gq + 5 (rows P-2, P-1: fs4 = -5) and is said complete one window later;
-  * at step 3 of window w it publishes w (the stores of the windows 0 .. w - 1 are complete);
+    least  i' * GR + gq + 6  (i' = the producer's local index of the band above): the group leaves the producer at step 0 of
+    its window i' * GR + gq + 5 (rows P-2, P-1: fs4 = -5; the handed-over rows are stored early) and is complete by its step 3;
+  * at step 3 of window w it publishes w + 1 (the handed-over stores of the windows 0 .. w are complete);
   * after its last window it drains its stores and publishes "all complete".
 A workgroup blocked in a wait publishes nothing further, so the two can wait for each other: band k + 2 starts GR windows after
 band k on the same workgroup, and by then band k + 1 must have delivered.  The model runs both workgroups to a fixpoint under
@@ -73,7 +73,7 @@ def run_model(H, W, final_publish=True, lookahead=1):
             need = need_for(wg, w)
             if need is not None and published[other] < need:
                 continue                             # blocked in progress_wait at step 0 of window w
-            published[wg] = max(published[wg], w)    # step 3 of window w
+            published[wg] = max(published[wg], w + 1)   # step 3 of window w
             window[wg] = w + 1
             progress = True
     return all(done)
@@ -85,19 +85,20 @@ def test_the_protocol_completes_on_every_map_the_library_splits(H, W):
     assert run_model(H, W)
 
 
-@pytest.mark.parametrize("W", [32, 40, 48, 56])
+@pytest.mark.parametrize("W", [32, 40, 48])
 def test_narrow_maps_dead_lock_which_is_why_the_library_does_not_split_them(W):
-    """band k + 2 starts W/4 windows after band k; the producer of band k + 1 is 8 windows behind its consumer's requests and
-    needs band k's groups up to 6 windows later: W/4 - 2 >= 13, i.e. W >= 60."""
+    """band k + 2 starts W/4 windows after band k; the producer of band k + 1 is 7 windows behind its consumer's requests and
+    needs band k's groups up to 5 windows later: W/4 - 1 >= 12, i.e. W >= 52."""
     assert not run_model(64, W)
 
 
 def test_the_tail_the_stress_test_found():
     """W = 68: 17 store groups per row; the loop of a one-band producer (H = 26: two bands, one each) ends at window 21 and has
-    published 21, the consumer's last piece needs 22.  Without the publish behind the loop the consumer waits forever."""
-    assert not run_model(26, 68, final_publish=False)
+    published 21 (that version said a window's stores complete one window later than today's), the consumer's last piece
+    needs 22.  Without the publish behind the loop the consumer waits forever.  (Today's early store of the handed-over rows
+    gives the tail one window of slack; the final publish stays -- a longer tail, e.g. W = 76, would need it again.)"""
     assert run_model(26, 68, final_publish=True)
-    assert run_model(26, 64, final_publish=False)     # (W = 64 had just enough windows: why the first tests passed)
+    assert run_model(26, 64, final_publish=False)
 
 
 def test_the_library_rule_matches_the_model():
