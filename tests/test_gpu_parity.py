@@ -984,4 +984,5 @@ def test_forward_form_the_library_picks(dev):
     assert form(256, 96, 64, 64) == "winograd4" and form(32, 96, 64, 64) == "winograd4" and form(256, 48, 64, 64) == "winograd4"
     assert form(8, 96, 128, 128) == "winograd4" and form(256, 96, 64, 96) == "winograd4"
     assert form(16, 96, 64, 64) == "winograd" and form(512, 48, 32, 32) == "winograd" and form(64, 48, 32, 32) == "winograd"
-    assert form(256, 96, 64, 62) in ("strip", "strip16") and form(64, 192, 128, 128, 5) in ("strip", "strip16")
+    assert form(256, 96, 64, 62) in ("strip", "strip16") and form(64, 192, 128, 128, 5) == "winograd25"      # (5x5: F(2,5), round 4)
+    assert form(64, 192, 128, 127, 5) in ("strip", "strip16")                                               # (an odd width has no pairs)

@@ -69,7 +69,7 @@ def run_inverse_case(dev, B, G, orient, Cq, H, W, KH, KW, seed, tag, expect_row=
     return e_max, e_elem
 
 
-@pytest.mark.parametrize("row", range(29))
+@pytest.mark.parametrize("row", range(34))
 def test_every_row_of_the_instantiation_table(row, dev):
     """Walks g_insts (finc_mfma.hip): each row is launched in its 64-byte sector-pairing form (W % 16 == 0, one-wave rows),
     its 32-byte-I/O form (W % 8 == 0) and its 16-byte form (W % 8 == 4), at problem counts on each side of max_problems and at odd and even counts (problems per workgroup),
@@ -77,7 +77,7 @@ def test_every_row_of_the_instantiation_table(row, dev):
     rows = _rows()
     if row >= len(rows):
         pytest.skip("table has fewer rows")
-    assert len(rows) <= 29, "extend the parametrisation: the table grew"
+    assert len(rows) <= 34, "extend the parametrisation: the table grew"
     i = rows[row]
     counts = problem_counts_for_row(rows, row)
     assert counts, f"no problem count selects row {row}: {i}"
@@ -119,7 +119,10 @@ def test_role_split_kernel(case, dev):
     B, G, Cq, H, W, KH, KW = case
     orient = ORIENT_FASTFLOW if G == 4 else (0x1B & ((1 << (2 * G)) - 1))
     v = _lib.inverse_variant(B, G, Cq, H, W, KH, KW)
-    assert v is not None and v["sec"] == 4 and v["nw"] == 4 and v["workgroups"] == B * G, v
+    # (round 4: with compute units to spare -- 2 B G <= 256 -- on a map of >= 2 bands and >= 64 columns the bands of a problem are
+    # dealt out to two workgroups: tests/test_gpu_round4.py walks that form)
+    per = 2 if (2 * B * G <= 256 and H > 16 and W >= 64 and KH > 1) else 1
+    assert v is not None and v["sec"] == 4 and v["nw"] == 4 and v["workgroups"] == per * B * G, v
     e_max, _ = run_inverse_case(dev, B, G, orient, Cq, H, W, KH, KW, seed=31 * Cq + H + W, tag="role_split")
     assert e_max <= TOL or Cq > 24                                          # (run_inverse_case holds the wider banks to 2x the reference's own fp32-fp64 gap)
     rng = np.random.default_rng(9)
@@ -565,7 +568,7 @@ def test_a_protocol_timeout_is_an_error_not_a_silent_wrong_answer(dev, tmp_path)
     if not shutil.which("hipcc"):
         pytest.skip("no hipcc on this box")
     csrc = os.path.join(REPO, "fincflow_amd", "csrc")
-    objs = [os.path.join(csrc, o) for o in ("finc_abi.o", "finc_generic.o", "finc_big.o", "finc_conv.o", "finc_wino.o", "finc_gradw.o", "finc_mix.o")]
+    objs = [os.path.join(csrc, o) for o in ("finc_abi.o", "finc_generic.o", "finc_big.o", "finc_conv.o", "finc_wino.o", "finc_gradw.o", "finc_mix.o", "finc_probe.o", "finc_wino5.o")]
     if not all(os.path.exists(o) for o in objs):
         pytest.skip("object files of the product build are not in the tree")
     lib = str(tmp_path / "libfinc_faulty.so")
