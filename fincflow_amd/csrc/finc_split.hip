@@ -112,11 +112,6 @@ __device__ unsigned long long finc_split_stamps[16];
 #define FINC_ST_END() do { } while (0)
 #endif
 
-#ifdef FINC_SPLIT_NOBAR   // TIMING-ONLY (results wrong): the loops without their per-step barrier -- what a barrier-free protocol could gain at most
-#define FINC_STEP_BARRIER() do { } while (0)
-#else
-#define FINC_STEP_BARRIER() __syncthreads()
-#endif
 constexpr int XSLOTS = 8;        // x ring: the pixels of the last 8 steps (taps reach back KH + KW - 2 <= 8 steps)
 constexpr int JSTRIDE = 2048;    // bytes between the k-steps of the x ring (8 slots x 64 lanes) AND of the FIFO: one immediate
 constexpr int ZJSTRIDE = 3072;   // bytes between the k-steps of the z ring (12 slots x 64 lanes)
@@ -311,7 +306,7 @@ __global__ __launch_bounds__(64 * (1 + NBW)) void finc_split_kernel(const float 
             ++fpush; if (fpush == DF) fpush = 0;
             ++fpop; if (fpop == DF) fpop = 0;
             FINC_ST_END();
-            FINC_STEP_BARRIER();
+            __syncthreads();
         }
 #ifdef FINC_SPLIT_STAMP
         if (blockIdx.x == 0 && lane == 0) { finc_split_stamps[0] = st_busy; finc_split_stamps[9] = T + 1; }
@@ -700,7 +695,7 @@ __global__ __launch_bounds__(64 * (1 + NBW)) void finc_split_kernel(const float 
         zn = zn == 11 ? 0 : zn + 1;
         prefetch(u + 1);
         FINC_ST_END();
-        FINC_STEP_BARRIER();
+        __syncthreads();
     };
     // iterations t = -1 .. T (u = t + 1 = 0 .. T + 1), unrolled by UNROLL: the host rounds T up so that T + 2 is a multiple of
     // it (the extra steps solve rows below the image: nothing is stored)
