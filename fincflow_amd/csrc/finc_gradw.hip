@@ -537,6 +537,421 @@ __global__ __launch_bounds__(256) void gradw_reduce_kernel(const float *__restri
     }
 }
 
+// -----------------------------------------------------------------------------------------------
+// grad_w with fewer multiplies (round 4): the Winograd F(4,3) of finc_wino.hip TRANSPOSED, for 3-wide filters.
+//
+// The forward's tile  y_i = sum_k g_k d_{i+k}  (4 outputs, 3 taps, 6 inputs) is the trilinear form
+//     T(y', g, d) = sum_f (A y')_f (G g)_f (B^T d)_f ,   A = (A^T)^T  (6 x 4),
+// so the filter's gradient is  dg_k = sum_f G[f][k] * (A gz)_f * (B^T x)_f : per tile of 4 columns SIX products per (o, i, filter
+// row) instead of 12.  The products are summed over all tiles, rows and images IN the frequency domain -- the sums are the
+// accumulators of this kernel, M[f][a][o][i] -- and G^T is applied once, by gradw_wino_reduce_kernel.  Points 0, +-1, +-3/2,
+// infinity as in the forward (tests/test_winograd_algebra.py checks the matrices exactly, this form included):
+//     U = A gz :  g0 | e + o | e - o | e' + o' | e' - o' | g3          e = g0 + g2, o = g1 + g3, e' = g0 + 2.25 g2, o' = 1.5 g1 + 3.375 g3
+//     V = B^T x:  2.25 d0 - 3.25 d2 + d4 | p + r | p - r | s + 1.5 u | s - 1.5 u | 2.25 d1 - 3.25 d3 + d5
+//                 p = d4 - 2.25 d2, r = d3 - 2.25 d1, s = d4 - d2, u = d3 - d1          (d_j = x[4t - 2 + j], gz tile = columns 4t .. 4t+3)
+//     dW[b = 2 - k] = dg_k:  k = 0: M0/2.25 - 0.4 (M1 + M2) + (8/45)(M3 + M4);  k = 1: -0.4 (M1 - M2) + (4/15)(M3 - M4);
+//                            k = 2: -0.4 (M1 + M2) + 0.4 (M3 + M4) + M5
+// The MFMA K dimension is the TILE: 16 columns are 4 tiles = the 4 k-slots of one MFMA per (frequency, filter row, o tile,
+// i tile); a strip is 16 or 32 columns (KS = 1 / 2 k-steps).  A wave walks (image, strip) units row by row like the staged
+// kernel.  The loads are wide -- lane = (channel, tile), so the 8 lanes of a channel ask for 128 contiguous bytes of a 32-column
+// strip and the pieces leave L2 as 128-byte requests: with 64-byte ones (16-column strips) the kernel's time followed its
+// fetched bytes at 45 G requests/s = 2.8 TB/s whatever else was changed (profiles/r04/notes/gradw_winograd.md) -- and land in
+// two raw LDS tiles as they came.  From there every lane reads, for each of its OPERAND registers (lane (q, n) = tile 4 ks + q
+// of channel n), the gz piece and the six x columns of that (channel, tile) and transforms them in place: U and V never exist
+// in memory, the stage of a row is ONE LDS round trip, and it sits between the MFMA groups of the row before (phase A | filter
+// row 0 | phase B | filter row 1 | phase C | filter row 2).  The loads are inline asm with a counted vmcnt.
+// Channels behind the last full 16 (Cq = 24: 8) run on 4x4x1 MFMAs without any
+// operand of their own: the block operand of gz holds channel 16 MTB + 4 ((n >> 3) & 1) + (n & 3) in lane (q, n), the one of x
+// channel 16 MTB + 4 ((n >> 2) & 1) + (n & 3), and then
+//     o block sb x i tile:   A = gz block operand, broadcast of block 2 sb (CBSZ = 2);  B = the x tile operand
+//     i block ig x o tile:   A = x block operand, broadcast of block ig;  B = the gz tile operand        (the transposed product)
+//     o blocks x i blocks:   ONE plain 4x4x1: block p of a lane row pairs o block p >> 1 with i block p & 1
+// -- 72 MFMA cycles per (frequency, filter row) at Cq = 24, no padding, 24 accumulator registers.  Those are what limits the
+// form: 6 frequencies x 3 rows x 24 = 432 registers, so the frequencies are split over FS = 2 waves (grid = G x FS x WPG; a
+// wave transforms only its own three) and the bank must be 16 (FS = 1), 24 or 32 channels.
+// Partial sums: part[((g * FS + fh) * WPG + w) * PER + ((fl * KH + a) * CQP + o) * CQP + i], PER = (6 / FS) KH CQP^2, complete values
+// (the 4-row blocks are transpose-reduced first).
+// -----------------------------------------------------------------------------------------------
+template <int CBSZ, int ABID>
+__device__ inline void gw_mma4(v4f &acc, float a, float b)
+{
+    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, acc, CBSZ, ABID, 0);
+}
+
+// FH: the frequencies of this wave (0: f0..f2, 1: f3..f5, 2: all six); FW: the group's strips are mirrored -- both are
+// uniform per workgroup and compile-time here (the kernel picks the body), so the loop is straight-line code: no selects, no
+// exec masks (lanes without a (channel, tile) park their transforms in a scratch word of their own), and the stage of row h+1
+// is cut into four phases that sit BETWEEN the MFMA groups of row h -- every LDS round trip of the chain
+// raw piece -> tile -> transform -> [frequency][channel][tile] -> operand has a filter row's MFMAs to complete behind.
+template <int CQP, int KH, int KS, int FH, bool FW>
+__device__ __forceinline__ void gradw_wino_body(const float *__restrict__ gz, const float *__restrict__ x, float *__restrict__ part,
+                                                int G, int CQ, int H, int W, int NS, int B, int WPG, int g, int wslot, bool fhh,
+                                                float *xt, float *gt)
+{
+    constexpr int MTB = CQP / 16, NSM = (CQP % 16) / 4, NF = FH == 2 ? 6 : 3, RS = KH + 1;
+    static_assert(MTB >= 1 && (NSM == 0 || NSM == 2), "see the comment above");
+    constexpr int NA = MTB + (NSM ? 1 : 0);                             // operand registers per side, frequency, k-step and row
+    constexpr int NT = 4 * KS, SWC = 16 * KS;                           // tiles / columns of a strip (KS MFMA k-steps of 4 tiles)
+    constexpr int XP = SWC + 4, GP = SWC + 4;                           // raw tiles: x [channel][4 halo + SWC], gz [channel][SWC + 4 pad]
+                                                                        // (pitch = 4 mod 32 floats: 8 lanes' 16-byte reads cover the banks)
+    constexpr int NPC = (NT * CQP + 63) / 64;                           // lane sets of (channel, tile): the loads
+    constexpr int NXI = ((NT + 1) * CQP + 63) / 64;                     // dwordx4 loads of x per row (tiles + halo pieces)
+    constexpr int PD = 2;                                               // rows of pieces in flight (4, 6, 8 measured: no faster)
+    static_assert(PD % 2 == 0, "the piece sets rotate with the gz buffers");
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    const int lane = threadIdx.x;
+    const int q = lane >> 4, n = lane & 15;
+    const int HW = H * W;
+    const unsigned slab_bytes = (unsigned)CQ * (unsigned)HW * 4u;
+    for (int i = lane; i < CQP * XP + 4; i += 64) xt[i] = 0.f;
+    for (int i = lane; i < CQP * GP + 4; i += 64) gt[i] = 0.f;
+
+    // accumulators per (filter row, frequency of this wave): tiles, o blocks x i tiles, i blocks x o tiles, blocks x blocks
+    constexpr int MS = NSM ? MTB : 1;
+    v4f accT[KH][NF][MTB][MTB], accO[KH][NF][2][MS], accI[KH][NF][2][MS], accB[KH][NF];
+#pragma unroll
+    for (int a = 0; a < KH; ++a)
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+#pragma unroll
+            for (int mo = 0; mo < MTB; ++mo)
+#pragma unroll
+                for (int mi = 0; mi < MTB; ++mi) accT[a][f][mo][mi] = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+                for (int mt = 0; mt < MS; ++mt) {
+                    accO[a][f][sb][mt] = (v4f){0.f, 0.f, 0.f, 0.f};
+                    accI[a][f][sb][mt] = (v4f){0.f, 0.f, 0.f, 0.f};
+                }
+            accB[a][f] = (v4f){0.f, 0.f, 0.f, 0.f};
+        }
+    // raw reads of lane (q, n) for operand register (k-step ks, set mt): channel ch(mt, n), CANONICAL tile 4 ks + q
+    int grd[KS][NA], xrd[KS][NA];
+#pragma unroll
+    for (int mt = 0; mt < NA; ++mt) {
+        const int chu = mt < MTB ? 16 * mt + n : 16 * MTB + 4 * ((n >> 3) & 1) + (n & 3);      // gz side
+        const int chv = mt < MTB ? 16 * mt + n : 16 * MTB + 4 * ((n >> 2) & 1) + (n & 3);      // x side
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int kc = 4 * ks + q;
+            grd[ks][mt] = chu * GP + 4 * (FW ? NT - 1 - kc : kc);       // the piece as it came from memory
+            // columns 4kc-2 .. 4kc+3: at 2 + 4kc .. (halo first); mirrored: at SWC + 1 - 4kc downwards (halo last) -- the address
+            // is the 16-byte part (columns 4kc .. 4kc+3), the 8-byte part sits 2 floats below it / 4 floats above it
+            xrd[ks][mt] = chv * XP + (FW ? SWC - 4 - 4 * kc : 4 + 4 * kc);
+        }
+    }
+    // load lanes: set i, lane -> (channel c, memory tile k); lanes behind the bank park their piece in the scratch piece
+    int lwg[NPC];
+#pragma unroll
+    for (int i = 0; i < NPC; ++i) {
+        const int t = 64 * i + lane;
+        lwg[i] = t < NT * CQP ? (t / NT) * GP + 4 * (t % NT) : CQP * GP;
+    }
+
+    for (int u = wslot; u < B * NS; u += WPG) {
+        const int b = u / NS, strip = u % NS;
+        const size_t slab = ((size_t)b * G + g) * CQ * HW;
+        auto rsrc = [&](const float *base, bool ok) {
+            return __builtin_amdgcn_make_buffer_rsrc((void *)(base + slab), 0, ok ? (int)slab_bytes : 0, 0x00020000);
+        };
+        const int ms = FW ? W - SWC - strip * SWC : strip * SWC;         // memory column where the strip starts
+        const int hm = FW ? ms + SWC : ms - 4;                          // ... and the piece holding the columns left of it
+        unsigned lvx[NXI], lvg[NPC];
+        int lwx[NXI];
+#pragma unroll
+        for (int i = 0; i < NXI; ++i) {
+            const int t = 64 * i + lane;
+            lvx[i] = OFF_BAD_CHANNEL;
+            lwx[i] = CQP * XP;                                          // scratch piece behind the tile
+            if (t < NT * CQP) {
+                const int c = t / NT, k = t % NT;
+                if (c < CQ && ms + 4 * k >= 0 && ms + 4 * k < W) lvx[i] = (unsigned)c * HW * 4u + (unsigned)(ms + 4 * k) * 4u;
+                lwx[i] = c * XP + (FW ? 0 : 4) + 4 * k;
+            } else if (t < (NT + 1) * CQP) {
+                const int c = t - NT * CQP;
+                if (c < CQ && hm >= 0 && hm < W) lvx[i] = (unsigned)c * HW * 4u + (unsigned)hm * 4u;
+                lwx[i] = c * XP + (FW ? SWC : 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NPC; ++i) {
+            const int t = 64 * i + lane;
+            lvg[i] = OFF_BAD_CHANNEL;
+            if (t < NT * CQP) {
+                const int c = t / NT, k = t % NT;
+                if (c < CQ && ms + 4 * k >= 0 && ms + 4 * k < W) lvg[i] = (unsigned)c * HW * 4u + (unsigned)(ms + 4 * k) * 4u;
+            }
+        }
+        auto rowbytes = [&](int h) { return (unsigned)((fhh ? H - 1 - h : h) * W) * 4u; };
+        v4u LX[PD][NXI], LG[PD][NPC];                                   // pieces in flight, PD rows ahead, by row % PD
+        auto issue = [&](auto par_c, int h) {
+            constexpr int PAR = decltype(par_c)::value;
+            const bool ok = h >= 0 && h < H;
+            const __amdgpu_buffer_rsrc_t rx = rsrc(x, ok), rg = rsrc(gz, ok);
+            const unsigned ro = ok ? rowbytes(h) : 0u;
+            // asm: hipcc's own vmcnt bookkeeping does not survive the unrolled loop (it waits for all but the newest row, which
+            // makes PD pointless); phase A waits for exactly the oldest row by count
+            auto &lx = LX[PAR]; auto &lg = LG[PAR]; auto &ovx = lvx; auto &ovg = lvg;   // (clang: asm operands do not capture by themselves)
+#pragma unroll
+            for (int i = 0; i < NXI; ++i)
+                asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(lx[i]) : "v"(ovx[i]), "s"(rx), "s"(ro) : "memory");
+#pragma unroll
+            for (int i = 0; i < NPC; ++i)
+                asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(lg[i]) : "v"(ovg[i]), "s"(rg), "s"(ro) : "memory");
+        };
+        float GA[2][NF][KS][NA];                                        // gz operands [arriving / current]
+        float XB[RS][NF][KS][NA];                                       // x operands by row slot
+        v4f RG[KS][NA], RX4[KS][NA];                                    // raw operands of a row, between two phases
+        v2f RX2[KS][NA];
+#pragma unroll
+        for (int sl = 0; sl < RS; ++sl)
+#pragma unroll
+            for (int f = 0; f < NF; ++f)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                    for (int mt = 0; mt < NA; ++mt) XB[sl][f][ks][mt] = 0.f;
+        // The stage of a row, in three phases.  A: its pieces (asked for PD steps ago) go to the raw tiles as they came; the
+        // pieces of row + PD are asked for.
+        auto phase_a = [&](auto ln_c, int row) {
+            constexpr int LN = decltype(ln_c)::value;
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PD - 1) * (NXI + NPC)) : "memory");   // rows row+1 .. row+PD-1 stay in flight
+            auto &lx = LX[LN]; auto &lg = LG[LN];
+#pragma unroll
+            for (int i = 0; i < NXI; ++i) asm volatile("" : "+v"(lx[i]));
+#pragma unroll
+            for (int i = 0; i < NPC; ++i) asm volatile("" : "+v"(lg[i]));
+#pragma unroll
+            for (int i = 0; i < NXI; ++i) reinterpret_cast<v4u *>(xt)[lwx[i] >> 2] = LX[LN][i];
+#pragma unroll
+            for (int i = 0; i < NPC; ++i) reinterpret_cast<v4u *>(gt)[lwg[i] >> 2] = LG[LN][i];
+            issue(IC<LN>{}, row + PD);                                  // into the set just emptied
+        };
+        // B: every lane reads, for each of its operand registers, the gz piece and the six x columns of that (channel, tile)
+        auto phase_b = [&]() {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int mt = 0; mt < NA; ++mt) {
+                    RG[ks][mt] = *reinterpret_cast<const v4f *>(&gt[grd[ks][mt]]);
+                    RX4[ks][mt] = *reinterpret_cast<const v4f *>(&xt[xrd[ks][mt]]);
+                    RX2[ks][mt] = *reinterpret_cast<const v2f *>(&xt[xrd[ks][mt] + (FW ? 4 : -2)]);
+                }
+        };
+        // C: U = A gz and V = B^T x in the operand layout: the registers the MFMAs of the next steps read
+        auto phase_c = [&](auto sn_c, auto pn_c) {
+            constexpr int SN = decltype(sn_c)::value, PN = decltype(pn_c)::value;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int mt = 0; mt < NA; ++mt) {
+                    const v4f rg = RG[ks][mt], r4 = RX4[ks][mt];
+                    const v2f r2 = RX2[ks][mt];
+                    const float m0 = rg.x, m1 = rg.y, m2 = rg.z, m3 = rg.w, b0 = r4.x, b1 = r4.y, b2 = r4.z, b3 = r4.w, c0 = r2.x,
+                                c1 = r2.y;
+                    const float g0 = FW ? m3 : m0, g1 = FW ? m2 : m1, g2 = FW ? m1 : m2, g3 = FW ? m0 : m3;
+                    // not mirrored: [d0 d1] = the 8-byte part, [d2 .. d5] the 16-byte part; mirrored: [d5 d4 d3 d2], [d1 d0]
+                    const float d0 = FW ? c1 : c0, d1 = FW ? c0 : c1, d2 = FW ? b3 : b0, d3 = FW ? b2 : b1, d4 = FW ? b1 : b2,
+                                d5 = FW ? b0 : b3;
+                    if constexpr (FH != 1) {
+                        const float e = g0 + g2, od = g1 + g3;
+                        GA[PN][0][ks][mt] = g0; GA[PN][1][ks][mt] = e + od; GA[PN][2][ks][mt] = e - od;
+                        const float pp = __builtin_fmaf(-2.25f, d2, d4), rr = __builtin_fmaf(-2.25f, d1, d3);
+                        XB[SN][0][ks][mt] = __builtin_fmaf(2.25f, d0, __builtin_fmaf(-3.25f, d2, d4));
+                        XB[SN][1][ks][mt] = pp + rr; XB[SN][2][ks][mt] = pp - rr;
+                    }
+                    if constexpr (FH != 0) {
+                        const float e = __builtin_fmaf(2.25f, g2, g0), od = __builtin_fmaf(3.375f, g3, 1.5f * g1);
+                        GA[PN][NF - 3][ks][mt] = e + od; GA[PN][NF - 2][ks][mt] = e - od; GA[PN][NF - 1][ks][mt] = g3;
+                        const float ss = d4 - d2, uq = d3 - d1;
+                        XB[SN][NF - 3][ks][mt] = __builtin_fmaf(1.5f, uq, ss); XB[SN][NF - 2][ks][mt] = __builtin_fmaf(-1.5f, uq, ss);
+                        XB[SN][NF - 1][ks][mt] = __builtin_fmaf(2.25f, d1, __builtin_fmaf(-3.25f, d3, d5));
+                    }
+                }
+        };
+        // the MFMAs of gz row h (buffer PC) against the x row a rows above it (slot SC - a)
+        auto mfmas = [&](auto sc_c, auto pc_c, auto a_c) {
+            constexpr int SC = decltype(sc_c)::value, PC = decltype(pc_c)::value, a = decltype(a_c)::value;
+            constexpr int sx = (SC + RS - a) % RS;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int f = 0; f < NF; ++f) {
+#pragma unroll
+                    for (int mo = 0; mo < MTB; ++mo)
+#pragma unroll
+                        for (int mi = 0; mi < MTB; ++mi)
+                            accT[a][f][mo][mi] = __builtin_amdgcn_mfma_f32_16x16x4f32(GA[PC][f][ks][mo], XB[sx][f][ks][mi],
+                                                                                      accT[a][f][mo][mi], 0, 0, 0);
+                    if constexpr (NSM != 0) {
+#pragma unroll
+                        for (int mt = 0; mt < MTB; ++mt) {
+                            gw_mma4<2, 0>(accO[a][f][0][mt], GA[PC][f][ks][MTB], XB[sx][f][ks][mt]);
+                            gw_mma4<2, 2>(accO[a][f][1][mt], GA[PC][f][ks][MTB], XB[sx][f][ks][mt]);
+                            gw_mma4<2, 0>(accI[a][f][0][mt], XB[sx][f][ks][MTB], GA[PC][f][ks][mt]);
+                            gw_mma4<2, 1>(accI[a][f][1][mt], XB[sx][f][ks][MTB], GA[PC][f][ks][mt]);
+                        }
+                        gw_mma4<0, 0>(accB[a][f], GA[PC][f][ks][MTB], XB[sx][f][ks][MTB]);
+                    }
+                }
+        };
+        // step of row h (slot h % RS, gz buffer h & 1): the phases of row h+1 between the MFMA groups of row h
+        // step of row h (slot h % RS, gz buffer h & 1): the phases of row h+1 between the MFMA groups of row h, so that the one
+        // LDS round trip of the stage has a filter row's MFMAs to complete behind
+        auto step = [&](auto i_c, int h) {
+            constexpr int I = decltype(i_c)::value;
+            constexpr int SC = I % RS, PC = I & 1;
+            phase_a(IC<(I + 1) % PD>{}, h + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(IC<SC>{}, IC<PC>{}, IC<0>{});
+            __builtin_amdgcn_sched_barrier(0);
+            phase_b();
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (KH > 1) mfmas(IC<SC>{}, IC<PC>{}, IC<1>{});
+            __builtin_amdgcn_sched_barrier(0);
+            phase_c(IC<(I + 1) % RS>{}, IC<PC ^ 1>{});
+            __builtin_amdgcn_sched_barrier(0);
+            [&]<int... A>(std::integer_sequence<int, A...>) {
+                ((mfmas(IC<SC>{}, IC<PC>{}, IC<A + 2>{})), ...);
+            }(std::make_integer_sequence<int, (KH > 2 ? KH - 2 : 0)>{});
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        static_assert(PD <= 8, "");
+        issue(IC<0>{}, 0);
+        issue(IC<1 % PD>{}, 1);
+        if constexpr (PD > 2) { issue(IC<2 % PD>{}, 2); issue(IC<3 % PD>{}, 3); }
+        if constexpr (PD > 4) { issue(IC<4 % PD>{}, 4); issue(IC<5 % PD>{}, 5); }
+        if constexpr (PD > 6) { issue(IC<6 % PD>{}, 6); issue(IC<7 % PD>{}, 7); }
+        phase_a(IC<0>{}, 0);                                            // row 0 into slot 0 (asks for row PD)
+        phase_b();
+        phase_c(IC<0>{}, IC<0>{});
+        // hipcc may park accumulators in scratch around this set-up; its wait for their reloads must not end up in the loop
+        // (a vmcnt(0) there drains the pieces in flight every step): every accumulator is "used" here, before the loop
+#pragma unroll
+        for (int a = 0; a < KH; ++a)
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+#pragma unroll
+                for (int mo = 0; mo < MTB; ++mo)
+#pragma unroll
+                    for (int mi = 0; mi < MTB; ++mi) asm volatile("" : "+a"(accT[a][f][mo][mi]));
+                if constexpr (NSM != 0) {
+#pragma unroll
+                    for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+                        for (int mt = 0; mt < MTB; ++mt) {
+                            asm volatile("" : "+a"(accO[a][f][sb][mt]));
+                            asm volatile("" : "+a"(accI[a][f][sb][mt]));
+                        }
+                    asm volatile("" : "+a"(accB[a][f]));
+                }
+            }
+        constexpr int UN0 = (RS % 2 == 0) ? RS : 2 * RS, UN = UN0 % PD == 0 ? UN0 : UN0 * PD / 2;
+        static_assert(UN % PD == 0 && UN % RS == 0 && UN % 2 == 0, "");
+        for (int h0 = 0; h0 < H; h0 += UN) {
+            [&]<int... I>(std::integer_sequence<int, I...>) {
+                ((h0 + I < H ? step(IC<I>{}, h0 + I) : (void)0), ...);
+            }(std::make_integer_sequence<int, UN>{});
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // the rows asked for beyond the image: their registers are free only now
+    }
+    float *dst = part + (size_t)blockIdx.x * (NF * KH * CQP * CQP);
+#pragma unroll
+    for (int a = 0; a < KH; ++a)
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+            float *d = dst + (size_t)(f * KH + a) * CQP * CQP;
+#pragma unroll
+            for (int mo = 0; mo < MTB; ++mo)
+#pragma unroll
+                for (int mi = 0; mi < MTB; ++mi) {
+                    const v4f v = accT[a][f][mo][mi];
+                    const float v0 = v.x, v1 = v.y, v2 = v.z, v3 = v.w;
+                    float *e = d + (16 * mo + 4 * q) * CQP + 16 * mi + n;
+                    e[0] = v0; e[CQP] = v1; e[2 * CQP] = v2; e[3 * CQP] = v3;
+                }
+            if constexpr (NSM != 0) {
+#pragma unroll
+                for (int sb = 0; sb < 2; ++sb)
+#pragma unroll
+                    for (int mt = 0; mt < MTB; ++mt) {
+                        const float vo = finc_block_reduce(accO[a][f][sb][mt]);     // lane row q: o = 16 MTB + 4 sb + q, i = 16 mt + n
+                        d[(16 * MTB + 4 * sb + q) * CQP + 16 * mt + n] = vo;
+                        const float vi = finc_block_reduce(accI[a][f][sb][mt]);     // lane row q: i = 16 MTB + 4 sb + q, o = 16 mt + n
+                        d[(16 * mt + n) * CQP + 16 * MTB + 4 * sb + q] = vi;
+                    }
+                const float vb = finc_block_reduce(accB[a][f]);                     // block p = n >> 2: o block p >> 1, i block p & 1
+                d[(16 * MTB + 4 * (n >> 3) + q) * CQP + 16 * MTB + 4 * ((n >> 2) & 1) + (n & 3)] = vb;
+            }
+        }
+}
+
+template <int CQP, int KH, int FS, int KS>
+__global__ __launch_bounds__(64) void finc_gradw_wino_kernel(const float *__restrict__ gz, const float *__restrict__ x,
+                                                             float *__restrict__ part, int G, int CQ, int H, int W, int NS,
+                                                             int B, int WPG, unsigned orient)
+{
+    __shared__ __attribute__((aligned(16))) float xt[CQP * (16 * KS + 4) + 4];
+    __shared__ __attribute__((aligned(16))) float gt[CQP * (16 * KS + 4) + 4];
+    int bi = blockIdx.x;
+    const int wslot = bi % WPG; bi /= WPG;
+    const int fh = bi % FS;
+    const int g = bi / FS;
+    const unsigned o = finc_group_orient(orient, g);
+    const bool fhh = (o & FINC_FLIP_H) != 0, fw = (o & FINC_FLIP_W) != 0;
+#define FINC_GW_BODY(FH, FW) gradw_wino_body<CQP, KH, KS, FH, FW>(gz, x, part, G, CQ, H, W, NS, B, WPG, g, wslot, fhh, xt, gt)
+    if constexpr (FS == 1) {
+        if (fw) FINC_GW_BODY(2, true); else FINC_GW_BODY(2, false);
+    } else if (fh == 0) {
+        if (fw) FINC_GW_BODY(0, true); else FINC_GW_BODY(0, false);
+    } else {
+        if (fw) FINC_GW_BODY(1, true); else FINC_GW_BODY(1, false);
+    }
+#undef FINC_GW_BODY
+}
+
+// gw[g][o][i][KH-1-a][k] = G^T applied to the sums of the partials (see above; k = 2 - b).  Same fixed-order slice scheme as
+// gradw_reduce_kernel: a block owns 32 consecutive (a, o, i) entries, its 8 thread groups sum 8 interleaved slices.
+__global__ __launch_bounds__(256) void gradw_wino_reduce_kernel(const float *__restrict__ part, float *__restrict__ gw, int Cq,
+                                                                int CQP, int KH, int FS, int WPG)
+{
+    __shared__ float slice[8][6][32];
+    const int g = blockIdx.y;
+    const int NF = 6 / FS;
+    const int per = NF * KH * CQP * CQP, plane = KH * CQP * CQP;
+    const int el = threadIdx.x & 31, j = threadIdx.x >> 5;
+    const int e = blockIdx.x * 32 + el;                    // (a, o, i) flat; plane is a multiple of 32
+    float s[6];
+#pragma unroll
+    for (int f = 0; f < 6; ++f) {
+        const int fhh = f / NF, fl = f % NF;
+        const float *p = part + ((size_t)(g * FS + fhh) * WPG) * per + (size_t)fl * plane + e;
+        float t = 0.f;
+        for (int w = j; w < WPG; w += 8) t += p[(size_t)w * per];
+        s[f] = t;
+    }
+#pragma unroll
+    for (int f = 0; f < 6; ++f) slice[j][f][el] = s[f];
+    __syncthreads();
+    if (j != 0) return;
+#pragma unroll
+    for (int f = 0; f < 6; ++f)
+        s[f] = ((slice[0][f][el] + slice[1][f][el]) + (slice[2][f][el] + slice[3][f][el])) +
+               ((slice[4][f][el] + slice[5][f][el]) + (slice[6][f][el] + slice[7][f][el]));
+    const int ic = e % CQP, oc = (e / CQP) % CQP, a = e / (CQP * CQP);
+    if (oc >= Cq || ic >= Cq) return;
+    const float s12 = s[1] + s[2], d12 = s[1] - s[2], s34 = s[3] + s[4], d34 = s[3] - s[4];
+    const float k0 = s[0] * (1.f / 2.25f) - 0.4f * s12 + (8.f / 45.f) * s34;
+    const float k1 = -0.4f * d12 + (4.f / 15.f) * d34;
+    const float k2 = 0.4f * (s34 - s12) + s[5];
+    float *o = gw + (((size_t)(g * Cq + oc) * Cq + ic) * KH + (KH - 1 - a)) * 3;
+    o[0] = k0;                                             // k = 0: tap b = 2
+    o[1] = k1;
+    o[2] = (a == 0 && ic >= oc) ? 0.f : k2;                // the corner tap's mask (b = 0; PaddedConv2d.reset_gradients)
+}
+
 typedef void (*gradw_fn)(const float *, const float *, float *, int, int, int, int, int, int, int, unsigned);
 typedef void (*gradw_tiled_fn)(const float *, const float *, float *, int, int, int, int, int, int, int, unsigned, int);
 struct GradwInst {
@@ -578,6 +993,31 @@ const GradwInst g_gradw[] = {
     make_gradw<48, 5, 5>(),
     make_gradw<4, 3, 5>(),  make_gradw<4, 1, 3>(),  make_gradw<4, 3, 1>(),
 };
+// the Winograd form: 3x3 banks of 16 (one wave holds all six frequencies), 24 and 32 channels (two waves, three each)
+struct GradwWinoInst {
+    int cqp, kh, fs;
+    gradw_fn fn, fn32;      // strips of 16 columns / of 32 (maps at least 32 wide: 128-byte rows per request, half the steps)
+};
+const GradwWinoInst g_gradw_wino[] = {
+    {16, 3, 1, finc_gradw_wino_kernel<16, 3, 1, 1>, finc_gradw_wino_kernel<16, 3, 1, 2>},
+    {24, 3, 2, finc_gradw_wino_kernel<24, 3, 2, 1>, finc_gradw_wino_kernel<24, 3, 2, 2>},
+    {32, 3, 2, finc_gradw_wino_kernel<32, 3, 2, 1>, finc_gradw_wino_kernel<32, 3, 2, 2>},
+};
+static int gradw_wino_strip(const FincShape &s)
+{
+    static const char *force = finc_env("FINC_GRADW_WINO_STRIP");             // experiment switch: 16 / 32
+    if (force) return atoi(force) == 32 ? 32 : 16;
+    return s.W >= 32 ? 32 : 16;
+}
+const GradwWinoInst *find_gradw_wino(const FincShape &s)
+{
+    static const bool off = finc_env("FINC_GRADW_NO_WINO") != nullptr;      // experiment switch
+    if (off || s.KW != 3 || s.W % 4 != 0 || s.Cq <= 12) return nullptr;
+    const GradwWinoInst *best = nullptr;
+    for (const GradwWinoInst &i : g_gradw_wino)
+        if (i.cqp >= s.Cq && i.kh == s.KH && (!best || i.cqp < best->cqp)) best = &i;
+    return best;
+}
 // the smallest compiled bank that holds Cq channels (every kernel here tests `channel < CQ` per lane: any padding is fine)
 const GradwInst *find_gradw(int Cq, int KH, int KW)
 {
@@ -603,12 +1043,31 @@ static int gradw_wpg_tiled(const FincShape &s, int mtt)
     if (w > 256) w = 256;
     return units < w ? units : w;
 }
+// Winograd form: G * FS * WPG workgroups of one wave, one per SIMD
+static int gradw_wpg_wino(const FincShape &s, int fs)
+{
+    const int sw = gradw_wino_strip(s);
+    const int units = s.B * ((s.W + sw - 1) / sw);
+    const int w = 256 / fs;
+    return units < w ? units : w;
+}
+static size_t gradw_wino_bytes(const FincShape &s, const GradwWinoInst *w)
+{
+    return (size_t)s.G * w->fs * gradw_wpg_wino(s, w->fs) * (6 / w->fs) * s.KH * w->cqp * w->cqp * sizeof(float);
+}
 static bool gradw_use_tiled(const GradwInst *i, const FincShape &s) { return i && !i->gw && i->gw_tiled && s.W % 4 == 0; }
 
 size_t finc_gradw_workspace_bytes(const FincShape &s)
 {
     const GradwInst *i = find_gradw(s.Cq, s.KH, s.KW);
     if (!i || !finc_conv_supported(s.Cq, s.H, s.W, s.KH, s.KW)) return 0;
+    if (const GradwWinoInst *w = find_gradw_wino(s)) {     // (unaligned activations fall back to the forms below: room for both)
+        size_t other = 0;
+        if (gradw_use_tiled(i, s)) other = (size_t)s.G * gradw_wpg_tiled(s, i->mtg) * s.KH * s.KW * i->mtg * i->mtg * 256 * sizeof(float);
+        else if (i->gw) other = (size_t)s.G * gradw_wpg(s) * s.KH * s.KW * i->mtg * i->mtg * 256 * sizeof(float);
+        const size_t mine = gradw_wino_bytes(s, w);
+        return mine > other ? mine : other;
+    }
     if (gradw_use_tiled(i, s)) return (size_t)s.G * gradw_wpg_tiled(s, i->mtg) * s.KH * s.KW * i->mtg * i->mtg * 256 * sizeof(float);
     if (!i->gw) return 0;
     return (size_t)s.G * gradw_wpg(s) * s.KH * s.KW * i->mtg * i->mtg * 256 * sizeof(float);
@@ -622,6 +1081,17 @@ int finc_gradw_launch(const float *gz, const float *x, float *gw, void *workspac
     const int NS = (s.W + 15) / 16;
     const bool aligned16 = (((uintptr_t)gz | (uintptr_t)x) & 15) == 0;
     int WPG;
+    if (const GradwWinoInst *w = aligned16 ? find_gradw_wino(s) : nullptr) {
+        WPG = gradw_wpg_wino(s, w->fs);
+        const int sw = gradw_wino_strip(s);
+        hipLaunchKernelGGL(sw == 32 ? w->fn32 : w->fn, dim3(s.G * w->fs * WPG), dim3(64), 0, st, gz, x, (float *)workspace, s.G,
+                           s.Cq, s.H, s.W, (s.W + sw - 1) / sw, s.B, WPG, s.orient);
+        FINC_CHECK_LAUNCH();
+        hipLaunchKernelGGL(gradw_wino_reduce_kernel, dim3(s.KH * w->cqp * w->cqp / 32, s.G), dim3(256), 0, st,
+                           (const float *)workspace, gw, s.Cq, w->cqp, s.KH, w->fs, WPG);
+        FINC_CHECK_LAUNCH();
+        return FINC_OK;
+    }
     if (gradw_use_tiled(i, s)) {
         if (!aligned16) return FINC_ERR_UNSUPPORTED;
         WPG = gradw_wpg_tiled(s, i->mtg);
@@ -645,11 +1115,13 @@ int finc_gradw_launch(const float *gz, const float *x, float *gw, void *workspac
 }
 
 // which grad-weight kernel finc_backward_f32 runs for this shape, given 16-byte aligned activations and a full workspace:
-// 0 direct (no MFMA instantiation), 1 dword MFMA kernel, 2 staged (16-byte pieces through LDS), 3 tiled (one tile pair per workgroup)
+// 0 direct (no MFMA instantiation), 1 dword MFMA kernel, 2 staged (16-byte pieces through LDS), 3 tiled (one tile pair per workgroup),
+// 4 Winograd (transposed F(4,3): half the multiplies)
 int finc_gradw_variant(const FincShape &s)
 {
     const GradwInst *i = find_gradw(s.Cq, s.KH, s.KW);
     if (!i || finc_gradw_workspace_bytes(s) == 0) return 0;
+    if (find_gradw_wino(s)) return 4;
     if (gradw_use_tiled(i, s)) return 3;
     if (!i->gw) return 0;
     static const bool no_staged = finc_env("FINC_GRADW_NO_STAGED") != nullptr;

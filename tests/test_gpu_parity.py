@@ -252,14 +252,18 @@ def test_autograd_matches_torch_conv(dev):
 BACKWARD_CASES = [
     # (B, C, H, W, K, grad-weight kernel, grad-input waves per strip): every MFMA backward kernel, named -- the staged and the
     # tiled grad-weight kernels (c3's and c5's), the dword one, and the K-split grad-input
-    (3, 96, 12, 32, 3, "staged", 1),       # c3's bank, W % 16 == 0: finc_gradw_staged_kernel
+    (3, 96, 12, 32, 3, "winograd", 1),     # c3's bank, W % 16 == 0: finc_gradw_wino_kernel<24,3,2> (transposed F(4,3), round 4)
     (2, 96, 9, 18, 3, "dword", 1),         # same bank, W % 4 != 0: finc_gradw_kernel (dword loads)
-    (2, 96, 9, 24, 3, "staged", 1),        # W % 4 == 0 but not % 16: the staged kernel with a partial last strip
-    (3, 96, 7, 44, 3, "staged", 1),        # ... three strips, the last one 12 columns
+    (2, 96, 9, 24, 3, "winograd", 1),      # W % 4 == 0 but not % 16: a partial last strip
+    (3, 96, 7, 44, 3, "winograd", 1),      # ... three strips, the last one 12 columns
+    (2, 80, 9, 36, 3, "winograd", 1),      # Cq = 20 on the 24-channel form (four padded channels)
+    (2, 64, 11, 32, 3, "winograd", 1),     # Cq = 16: one wave holds all six frequencies
+    (2, 128, 9, 16, 3, "winograd", 1),     # Cq = 32: two full tiles per side
     (2, 192, 10, 20, 3, "tiled", 2),       # the tiled kernel with a partial last strip
     (2, 192, 10, 16, 3, "tiled", 2),       # Cq = 48 3x3: finc_gradw_tiled_kernel, K-split grad-input (2 waves per strip)
     (2, 192, 7, 32, 5, "tiled", 4),        # Cq = 48 5x5 (the c5 bank): tiled grad-weight, K-split grad-input (4 waves)
-    (2, 128, 9, 16, 3, "staged", 1),       # Cq = 32 3x3: staged grad-weight
+    (2, 96, 9, 16, 2, "staged", 1),        # 2x2 at 24 channels: finc_gradw_staged_kernel (4-row blocks, FLAT tiles)
+    (2, 64, 7, 32, 5, "staged", 1),        # 5x5 at 16 channels: staged
     (2, 48, 33, 32, 3, "staged", 1),       # c2's bank, more than one band of rows
 ]
 

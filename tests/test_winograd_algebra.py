@@ -142,3 +142,47 @@ def test_f25_fp32_error_model():
     Y = np.einsum("mf,otf->otm", AT.astype(np.float32), M).astype(np.float32).reshape(Cq, N)
     e = np.abs(Y - ref).max() / np.abs(ref).max()
     assert e < 4e-6, e
+
+
+def test_f43_transposed_is_the_filter_gradient():
+    """finc_gradw_wino_kernel (finc_gradw.hip): the same F(4,3) matrices read as the trilinear form T(y', g, d) = sum_f (A y')_f
+    (G g)_f (B^T d)_f give the filter's gradient dg_k = sum_i y'_i d_{i+k} = sum_f G[f][k] (A y')_f (B^T d)_f with A = (A^T)^T --
+    exact for every basis pair, and with the constants the kernel and gradw_wino_reduce_kernel spell out."""
+    BT, G, AT = ([[Fr(x) for x in row] for row in F43[k]] for k in ("BT", "G", "AT"))
+    for i in range(4):                                    # gz tile = e_i
+        U = [AT[i][f] for f in range(6)]
+        for j in range(6):                                # x tile = e_j
+            V = [BT[f][j] for f in range(6)]
+            for k in range(3):
+                dg = sum(G[f][k] * U[f] * V[f] for f in range(6))
+                assert dg == (1 if j == i + k else 0), (i, j, k, dg)
+    # the kernel's U = A gz: g0 | e + o | e - o | e' + o' | e' - o' | g3 with e' = g0 + 2.25 g2, o' = 1.5 g1 + 3.375 g3
+    assert [[AT[i][f] for i in range(4)] for f in range(6)] == [
+        [1, 0, 0, 0], [1, 1, 1, 1], [1, -1, 1, -1], [1, b, b * b, b ** 3], [1, -b, b * b, -b ** 3], [0, 0, 0, 1]]
+    assert (b * b, b ** 3) == (Fr(9, 4), Fr(27, 8))
+    # the reduce kernel's G^T: k = 0: M0/2.25 - 0.4 (M1 + M2) + (8/45)(M3 + M4); k = 1: -0.4 (M1 - M2) + (4/15)(M3 - M4);
+    # k = 2: 0.4 ((M3 + M4) - (M1 + M2)) + M5
+    assert [G[f][0] for f in range(6)] == [Fr(4, 9), Fr(-2, 5), Fr(-2, 5), Fr(8, 45), Fr(8, 45), 0]
+    assert [G[f][1] for f in range(6)] == [0, Fr(-2, 5), Fr(2, 5), Fr(4, 15), Fr(-4, 15), 0]
+    assert [G[f][2] for f in range(6)] == [0, Fr(-2, 5), Fr(-2, 5), Fr(2, 5), Fr(2, 5), 1]
+
+
+def test_f43_transposed_fp32_error_model():
+    """The Winograd grad-weight's arithmetic in numpy fp32 -- frequency-domain sums over 8,192 tiles, G^T at the end -- against
+    fp64: inside the 2e-5 the GPU test allows a B*H*W-term fp32 reduction."""
+    rng = np.random.default_rng(1)
+    T, Co, Ci = 8192, 6, 5
+    gz = rng.standard_normal((Co, T, 4)).astype(np.float32)
+    x = rng.standard_normal((Ci, 4 * T + 2)).astype(np.float32)
+    BT, G, AT = (np.array([[float(Fr(v)) for v in row] for row in F43[k]]) for k in ("BT", "G", "AT"))
+    idx = (np.arange(T) * 4)[:, None] + np.arange(6)[None, :]
+    d = x[:, idx]                                                          # [Ci, T, 6]: d_j = x[4t - 2 + j] (x carries the 2-column halo)
+    ref = np.stack([np.einsum("oti,cti->oc", gz.astype(np.float64), d[:, :, k:k + 4].astype(np.float64)) for k in range(3)], -1)
+    U = np.einsum("if,oti->otf", AT.astype(np.float32), gz).astype(np.float32)
+    V = np.einsum("fj,ctj->ctf", BT.astype(np.float32), d).astype(np.float32)
+    M = np.zeros((Co, Ci, 6), np.float32)
+    for t in range(T):                                                     # fp32 accumulation, tile by tile
+        M += U[:, None, t, :] * V[None, :, t, :]
+    got = np.einsum("fk,ocf->ock", G.astype(np.float32), M).astype(np.float32)
+    e = np.abs(got - ref).max() / np.abs(ref).max()
+    assert e < 1e-5, e
