@@ -858,7 +858,10 @@ def bench_unit(args):
         E = B * C * H * W
         alg_bytes = 8 * E + 4 * C * Cq * K * K
         alg_flops = 2 * E * K * K * Cq
-        conv_form = _lt.backward_variant(B, 4, Cq, H, W, K, K)["conv_form"]
+        bvar = _lt.backward_variant(B, 4, Cq, H, W, K, K)
+        conv_form = bvar["conv_form"]
+        # grad-weight: the transposed F(4,3) executes 6 products per tile of 4 columns where the direct sum has 12
+        gw_flops = alg_flops // 2 if bvar["gradw"] == "winograd" else alg_flops
         # multiplies the forward kernel executes: Winograd F(2,3) = 4 frequencies x 3 row taps per 2 outputs (2/3 of the direct
         # sum's), F(4,3) = 6 x 3 per 4 outputs (1/2)
         # (5x5: F(2,5) = 6 frequencies x 5 row taps per 2 outputs: 3/5)
@@ -919,7 +922,8 @@ def bench_unit(args):
             "training_step": {"what": "z = unit(x); z.backward(gz): forward + grad-input + grad-weight with the corner-tap mask "
                                       "(SURVEY 8 f1), HIP kernels under autograd", "ms_per_step": tr_dt / tr_steps * 1e3,
                               "steps": tr_steps, "launch": launch_stats(tr_per),
-                              "frac_fp32_peak": (alg_flops + 2 * fwd_flops) / (tr_dt / tr_steps) / 1e12 / FP32_PEAK_TFLOPS,
+                              "grad_weight_kernel": bvar["gradw"],
+                              "frac_fp32_peak": (gw_flops + 2 * fwd_flops) / (tr_dt / tr_steps) / 1e12 / FP32_PEAK_TFLOPS,
                               "direct_equivalent_frac_fp32_peak": 3 * alg_flops / (tr_dt / tr_steps) / 1e12 / FP32_PEAK_TFLOPS},
             "roofline": {"kernel": inverse_kernel_name(B, Cq, H, W, K), "bound": "hbm", "achieved": inv_gbs,
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": inv_gbs / HBM_PEAK_GBS,
