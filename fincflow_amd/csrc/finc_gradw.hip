@@ -567,8 +567,9 @@ __global__ __launch_bounds__(256) void gradw_reduce_kernel(const float *__restri
 //     i block ig x o tile:   A = x block operand, broadcast of block ig;  B = the gz tile operand        (the transposed product)
 //     o blocks x i blocks:   ONE plain 4x4x1: block p of a lane row pairs o block p >> 1 with i block p & 1
 // -- 72 MFMA cycles per (frequency, filter row) at Cq = 24, no padding, 24 accumulator registers.  Those are what limits the
-// form: 6 frequencies x 3 rows x 24 = 432 registers, so the frequencies are split over FS = 2 waves (grid = G x FS x WPG; a
-// wave transforms only its own three) and the bank must be 16 (FS = 1), 24 or 32 channels.
+// form: 6 frequencies x 3 rows x 24 = 432 registers, so the frequencies are split over FS = 2 waves -- the two waves of one
+// workgroup, which share the raw tiles (each loads half of the pieces; one barrier per row) and transform only their own three
+// frequencies -- and the bank must be 16 (FS = 1), 24 or 32 channels.
 // Partial sums: part[((g * FS + fh) * WPG + w) * PER + ((fl * KH + a) * CQP + o) * CQP + i], PER = (6 / FS) KH CQP^2, complete values
 // (the 4-row blocks are transpose-reduced first).
 // -----------------------------------------------------------------------------------------------
@@ -583,10 +584,10 @@ __device__ inline void gw_mma4(v4f &acc, float a, float b)
 // exec masks (lanes without a (channel, tile) park their transforms in a scratch word of their own), and the stage of row h+1
 // is cut into four phases that sit BETWEEN the MFMA groups of row h -- every LDS round trip of the chain
 // raw piece -> tile -> transform -> [frequency][channel][tile] -> operand has a filter row's MFMAs to complete behind.
-template <int CQP, int KH, int KS, int FH, bool FW>
+template <int CQP, int KH, int KS, int FH, bool FW, bool SH>
 __device__ __forceinline__ void gradw_wino_body(const float *__restrict__ gz, const float *__restrict__ x, float *__restrict__ part,
                                                 int G, int CQ, int H, int W, int NS, int B, int WPG, int g, int wslot, bool fhh,
-                                                float *xt, float *gt)
+                                                float *part_dst, float *xt, float *gt)
 {
     constexpr int MTB = CQP / 16, NSM = (CQP % 16) / 4, NF = FH == 2 ? 6 : 3, RS = KH + 1;
     static_assert(MTB >= 1 && (NSM == 0 || NSM == 2), "see the comment above");
@@ -598,14 +599,27 @@ __device__ __forceinline__ void gradw_wino_body(const float *__restrict__ gz, co
     constexpr int NXI = ((NT + 1) * CQP + 63) / 64;                     // dwordx4 loads of x per row (tiles + halo pieces)
     constexpr int PD = 2;                                               // rows of pieces in flight (4, 6, 8 measured: no faster)
     static_assert(PD % 2 == 0, "the piece sets rotate with the gz buffers");
+    // SH: the two frequency halves of a strip are the two waves of ONE workgroup and share the raw tiles -- wave 0 loads the gz
+    // pieces, wave 1 the x pieces, every byte crosses the fabric and L2 once; the tiles are double-buffered by row parity and one
+    // barrier per row (behind filter row 0's MFMAs) says "row h+1 is in its tiles"
+    constexpr bool LOADX = !SH || FH == 1, LOADG = !SH || FH == 0;
+    constexpr int NLD = (LOADX ? NXI : 0) + (LOADG ? NPC : 0);          // loads of this wave per row
+    constexpr int TST = CQP * XP + 4;                                   // floats per tile buffer (XP == GP)
+    static_assert(XP == GP && (TST * 4) % 16 == 0, "");
     typedef unsigned v4u __attribute__((ext_vector_type(4)));
     typedef float v2f __attribute__((ext_vector_type(2)));
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const int q = lane >> 4, n = lane & 15;
     const int HW = H * W;
     const unsigned slab_bytes = (unsigned)CQ * (unsigned)HW * 4u;
-    for (int i = lane; i < CQP * XP + 4; i += 64) xt[i] = 0.f;
-    for (int i = lane; i < CQP * GP + 4; i += 64) gt[i] = 0.f;
+    for (int i = lane; i < (SH ? 2 : 1) * TST; i += 64) { xt[i] = 0.f; gt[i] = 0.f; }     // (SH: both waves, the same zeros)
+    auto pair_barrier = [&]() {
+        if constexpr (SH) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // my tile writes are done (not __syncthreads: its fence would
+            __builtin_amdgcn_s_barrier();                               //  also drain the pieces in flight)
+            asm volatile("" ::: "memory");
+        }
+    };
 
     // accumulators per (filter row, frequency of this wave): tiles, o blocks x i tiles, i blocks x o tiles, blocks x blocks
     constexpr int MS = NSM ? MTB : 1;
@@ -694,12 +708,16 @@ __device__ __forceinline__ void gradw_wino_body(const float *__restrict__ gz, co
             // asm: hipcc's own vmcnt bookkeeping does not survive the unrolled loop (it waits for all but the newest row, which
             // makes PD pointless); phase A waits for exactly the oldest row by count
             auto &lx = LX[PAR]; auto &lg = LG[PAR]; auto &ovx = lvx; auto &ovg = lvg;   // (clang: asm operands do not capture by themselves)
+            if constexpr (LOADX) {
 #pragma unroll
-            for (int i = 0; i < NXI; ++i)
-                asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(lx[i]) : "v"(ovx[i]), "s"(rx), "s"(ro) : "memory");
+                for (int i = 0; i < NXI; ++i)
+                    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(lx[i]) : "v"(ovx[i]), "s"(rx), "s"(ro) : "memory");
+            }
+            if constexpr (LOADG) {
 #pragma unroll
-            for (int i = 0; i < NPC; ++i)
-                asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(lg[i]) : "v"(ovg[i]), "s"(rg), "s"(ro) : "memory");
+                for (int i = 0; i < NPC; ++i)
+                    asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(lg[i]) : "v"(ovg[i]), "s"(rg), "s"(ro) : "memory");
+            }
         };
         float GA[2][NF][KS][NA];                                        // gz operands [arriving / current]
         float XB[RS][NF][KS][NA];                                       // x operands by row slot
@@ -715,29 +733,34 @@ __device__ __forceinline__ void gradw_wino_body(const float *__restrict__ gz, co
                     for (int mt = 0; mt < NA; ++mt) XB[sl][f][ks][mt] = 0.f;
         // The stage of a row, in three phases.  A: its pieces (asked for PD steps ago) go to the raw tiles as they came; the
         // pieces of row + PD are asked for.
-        auto phase_a = [&](auto ln_c, int row) {
-            constexpr int LN = decltype(ln_c)::value;
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PD - 1) * (NXI + NPC)) : "memory");   // rows row+1 .. row+PD-1 stay in flight
+        auto phase_a = [&](auto ln_c, auto tb_c, int row) {              // TB: the tile buffer of the row (its parity when SH)
+            constexpr int LN = decltype(ln_c)::value, TB = decltype(tb_c)::value;
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PD - 1) * NLD) : "memory");   // rows row+1 .. row+PD-1 stay in flight
             auto &lx = LX[LN]; auto &lg = LG[LN];
+            if constexpr (LOADX) {
 #pragma unroll
-            for (int i = 0; i < NXI; ++i) asm volatile("" : "+v"(lx[i]));
+                for (int i = 0; i < NXI; ++i) asm volatile("" : "+v"(lx[i]));
 #pragma unroll
-            for (int i = 0; i < NPC; ++i) asm volatile("" : "+v"(lg[i]));
+                for (int i = 0; i < NXI; ++i) reinterpret_cast<v4u *>(xt + TB * TST)[lwx[i] >> 2] = LX[LN][i];
+            }
+            if constexpr (LOADG) {
 #pragma unroll
-            for (int i = 0; i < NXI; ++i) reinterpret_cast<v4u *>(xt)[lwx[i] >> 2] = LX[LN][i];
+                for (int i = 0; i < NPC; ++i) asm volatile("" : "+v"(lg[i]));
 #pragma unroll
-            for (int i = 0; i < NPC; ++i) reinterpret_cast<v4u *>(gt)[lwg[i] >> 2] = LG[LN][i];
+                for (int i = 0; i < NPC; ++i) reinterpret_cast<v4u *>(gt + TB * TST)[lwg[i] >> 2] = LG[LN][i];
+            }
             issue(IC<LN>{}, row + PD);                                  // into the set just emptied
         };
         // B: every lane reads, for each of its operand registers, the gz piece and the six x columns of that (channel, tile)
-        auto phase_b = [&]() {
+        auto phase_b = [&](auto tb_c) {
+            constexpr int TB = decltype(tb_c)::value;
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
                 for (int mt = 0; mt < NA; ++mt) {
-                    RG[ks][mt] = *reinterpret_cast<const v4f *>(&gt[grd[ks][mt]]);
-                    RX4[ks][mt] = *reinterpret_cast<const v4f *>(&xt[xrd[ks][mt]]);
-                    RX2[ks][mt] = *reinterpret_cast<const v2f *>(&xt[xrd[ks][mt] + (FW ? 4 : -2)]);
+                    RG[ks][mt] = *reinterpret_cast<const v4f *>(&gt[TB * TST + grd[ks][mt]]);
+                    RX4[ks][mt] = *reinterpret_cast<const v4f *>(&xt[TB * TST + xrd[ks][mt]]);
+                    RX2[ks][mt] = *reinterpret_cast<const v2f *>(&xt[TB * TST + xrd[ks][mt] + (FW ? 4 : -2)]);
                 }
         };
         // C: U = A gz and V = B^T x in the operand layout: the registers the MFMAs of the next steps read
@@ -803,11 +826,13 @@ __device__ __forceinline__ void gradw_wino_body(const float *__restrict__ gz, co
         auto step = [&](auto i_c, int h) {
             constexpr int I = decltype(i_c)::value;
             constexpr int SC = I % RS, PC = I & 1;
-            phase_a(IC<(I + 1) % PD>{}, h + 1);
+            constexpr int TB = SH ? (I + 1) & 1 : 0;
+            phase_a(IC<(I + 1) % PD>{}, IC<TB>{}, h + 1);
             __builtin_amdgcn_sched_barrier(0);
             mfmas(IC<SC>{}, IC<PC>{}, IC<0>{});
             __builtin_amdgcn_sched_barrier(0);
-            phase_b();
+            pair_barrier();
+            phase_b(IC<TB>{});
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (KH > 1) mfmas(IC<SC>{}, IC<PC>{}, IC<1>{});
             __builtin_amdgcn_sched_barrier(0);
@@ -824,8 +849,10 @@ __device__ __forceinline__ void gradw_wino_body(const float *__restrict__ gz, co
         if constexpr (PD > 2) { issue(IC<2 % PD>{}, 2); issue(IC<3 % PD>{}, 3); }
         if constexpr (PD > 4) { issue(IC<4 % PD>{}, 4); issue(IC<5 % PD>{}, 5); }
         if constexpr (PD > 6) { issue(IC<6 % PD>{}, 6); issue(IC<7 % PD>{}, 7); }
-        phase_a(IC<0>{}, 0);                                            // row 0 into slot 0 (asks for row PD)
-        phase_b();
+        pair_barrier();                                                 // (SH: the partner is done with the tiles of the unit before)
+        phase_a(IC<0>{}, IC<0>{}, 0);                                   // row 0 into slot 0 (asks for row PD)
+        pair_barrier();
+        phase_b(IC<0>{});
         phase_c(IC<0>{}, IC<0>{});
         // hipcc may park accumulators in scratch around this set-up; its wait for their reloads must not end up in the loop
         // (a vmcnt(0) there drains the pieces in flight every step): every accumulator is "used" here, before the loop
@@ -857,7 +884,7 @@ __device__ __forceinline__ void gradw_wino_body(const float *__restrict__ gz, co
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // the rows asked for beyond the image: their registers are free only now
     }
-    float *dst = part + (size_t)blockIdx.x * (NF * KH * CQP * CQP);
+    float *dst = part_dst;
 #pragma unroll
     for (int a = 0; a < KH; ++a)
 #pragma unroll
@@ -889,19 +916,20 @@ __device__ __forceinline__ void gradw_wino_body(const float *__restrict__ gz, co
 }
 
 template <int CQP, int KH, int FS, int KS>
-__global__ __launch_bounds__(64) void finc_gradw_wino_kernel(const float *__restrict__ gz, const float *__restrict__ x,
-                                                             float *__restrict__ part, int G, int CQ, int H, int W, int NS,
-                                                             int B, int WPG, unsigned orient)
+__global__ __launch_bounds__(64 * FS) __attribute__((amdgpu_waves_per_eu(1, 1))) void finc_gradw_wino_kernel(
+    const float *__restrict__ gz, const float *__restrict__ x, float *__restrict__ part, int G, int CQ, int H, int W, int NS, int B,
+    int WPG, unsigned orient)
 {
-    __shared__ __attribute__((aligned(16))) float xt[CQP * (16 * KS + 4) + 4];
-    __shared__ __attribute__((aligned(16))) float gt[CQP * (16 * KS + 4) + 4];
-    int bi = blockIdx.x;
-    const int wslot = bi % WPG; bi /= WPG;
-    const int fh = bi % FS;
-    const int g = bi / FS;
+    constexpr int NF = 6 / FS, TST = CQP * (16 * KS + 4) + 4;
+    __shared__ __attribute__((aligned(16))) float xt[FS * TST];         // (FS = 2: the pair's two tile buffers)
+    __shared__ __attribute__((aligned(16))) float gt[FS * TST];
+    const int wslot = blockIdx.x % WPG, g = blockIdx.x / WPG;
+    const int fh = threadIdx.x >> 6;                                     // FS = 2: wave 0 has f0..f2, wave 1 f3..f5
     const unsigned o = finc_group_orient(orient, g);
     const bool fhh = (o & FINC_FLIP_H) != 0, fw = (o & FINC_FLIP_W) != 0;
-#define FINC_GW_BODY(FH, FW) gradw_wino_body<CQP, KH, KS, FH, FW>(gz, x, part, G, CQ, H, W, NS, B, WPG, g, wslot, fhh, xt, gt)
+    float *dst = part + ((size_t)(g * FS + fh) * WPG + wslot) * (NF * KH * CQP * CQP);
+#define FINC_GW_BODY(FH, FW) \
+    gradw_wino_body<CQP, KH, KS, FH, FW, FS == 2>(gz, x, part, G, CQ, H, W, NS, B, WPG, g, wslot, fhh, dst, xt, gt)
     if constexpr (FS == 1) {
         if (fw) FINC_GW_BODY(2, true); else FINC_GW_BODY(2, false);
     } else if (fh == 0) {
@@ -1084,7 +1112,7 @@ int finc_gradw_launch(const float *gz, const float *x, float *gw, void *workspac
     if (const GradwWinoInst *w = aligned16 ? find_gradw_wino(s) : nullptr) {
         WPG = gradw_wpg_wino(s, w->fs);
         const int sw = gradw_wino_strip(s);
-        hipLaunchKernelGGL(sw == 32 ? w->fn32 : w->fn, dim3(s.G * w->fs * WPG), dim3(64), 0, st, gz, x, (float *)workspace, s.G,
+        hipLaunchKernelGGL(sw == 32 ? w->fn32 : w->fn, dim3(s.G * WPG), dim3(64 * w->fs), 0, st, gz, x, (float *)workspace, s.G,
                            s.Cq, s.H, s.W, (s.W + sw - 1) / sw, s.B, WPG, s.orient);
         FINC_CHECK_LAUNCH();
         hipLaunchKernelGGL(gradw_wino_reduce_kernel, dim3(s.KH * w->cqp * w->cqp / 32, s.G), dim3(256), 0, st,
