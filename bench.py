@@ -861,7 +861,9 @@ def bench_unit(args):
         bvar = _lt.backward_variant(B, 4, Cq, H, W, K, K)
         conv_form = bvar["conv_form"]
         # grad-weight: the transposed F(4,3) executes 6 products per tile of 4 columns where the direct sum has 12
-        gw_flops = alg_flops // 2 if bvar["gradw"] == "winograd" else alg_flops
+        # (5x5 on tile pairs: the transposed F(2,5), 6 products per tile of 2 columns where the direct sum has 10)
+        gw_flops = (alg_flops // 2 if bvar["gradw"] == "winograd" or (bvar["gradw"] == "winograd_tiled" and K == 3)
+                    else alg_flops * 3 // 5 if bvar["gradw"] == "winograd_tiled" else alg_flops)
         # multiplies the forward kernel executes: Winograd F(2,3) = 4 frequencies x 3 row taps per 2 outputs (2/3 of the direct
         # sum's), F(4,3) = 6 x 3 per 4 outputs (1/2)
         # (5x5: F(2,5) = 6 frequencies x 5 row taps per 2 outputs: 3/5)

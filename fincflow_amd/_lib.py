@@ -128,7 +128,7 @@ def backward_variant(B, G, Cq, H, W, KH, KW):
     info = (ctypes.c_int * 3)()
     check(lib().finc_debug_backward_variant(B, G, Cq, H, W, KH, KW, info), "finc_debug_backward_variant")
     form = "scalar" if info[1] == 0 else ("strip", "strip16", "winograd", "msplit", "winograd4", "winograd25")[info[2]]
-    return {"gradw": ("direct", "dword", "staged", "tiled", "winograd")[info[0]], "gradx_waves": info[1], "gradx_staged": bool(info[2]),
+    return {"gradw": ("direct", "dword", "staged", "tiled", "winograd", "winograd_tiled")[info[0]], "gradx_waves": info[1], "gradx_staged": bool(info[2]),
             "conv_form": form}
 
 

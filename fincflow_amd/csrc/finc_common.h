@@ -142,7 +142,7 @@ int finc_wino5_launch(const float *in, const void *packed, float *out, const Fin
 unsigned finc_build_flags_wino5();
 size_t finc_gradw_workspace_bytes(const FincShape &s); // 0: no MFMA grad-weight kernel for this shape
 int finc_gradw_launch(const float *gz, const float *x, float *gw, void *workspace, const FincShape &s, hipStream_t st);
-int finc_gradw_variant(const FincShape &s);   // 0 direct, 1 dword MFMA, 2 staged, 3 tiled, 4 Winograd
+int finc_gradw_variant(const FincShape &s);   // 0 direct, 1 dword MFMA, 2 staged, 3 tiled, 4 Winograd, 5 Winograd tiled
 // info[0..2] = {waves per strip (K-split), staged form (1) or dword form (0), strips per slab}; FINC_ERR_UNSUPPORTED: direct kernel
 int finc_conv_variant(int B, int G, int Cq, int H, int W, int KH, int KW, int *info);
 

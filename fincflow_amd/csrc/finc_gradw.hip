@@ -980,6 +980,299 @@ __global__ __launch_bounds__(256) void gradw_wino_reduce_kernel(const float *__r
     o[2] = (a == 0 && ic >= oc) ? 0.f : k2;                // the corner tap's mask (b = 0; PaddedConv2d.reset_gradients)
 }
 
+// -----------------------------------------------------------------------------------------------
+// The Winograd grad-weight for the banks one wave cannot hold (Cq > 32 at 3x3, Cq > 16 at 5x5 -- the c5 bank): ONE 16x16 (o, i)
+// tile pair per wave as in finc_gradw_tiled_kernel, six frequency accumulators per filter row.  3-wide filters: F(4,3)
+// transposed as above (tiles of 4 columns, 32-column strips); 5-wide filters: F(2,5) of finc_wino5.hip transposed -- tiles of
+// TWO columns, d_j = x[2t - 4 + j], six products per tile, filter row and (o, i) instead of ten (16-column strips):
+//     U = A gz :  g0 | g0 + g1 | g0 - g1 | g0 + g1/2 | g0 - g1/2 | g1
+//     V = B^T x:  d0 - 5 d2 + 4 d4 | p + r | p - r | 2 s + u | 2 s - u | d1 - 5 d3 + 4 d5      p = 4 d4 - d2, r = 4 d3 - d1, s = d2 - d4, u = d1 - d3
+//     dW[b = 4 - k]:  k0 = M0 + S/6 + 4 T/3;  k1 = D/6 + 2 E/3;  k2 = S/6 + T/3;  k3 = D/6 + E/6;  k4 = S/6 + T/12 + M5/4
+//                     S = M1 + M2, D = M1 - M2, T = M3 + M4, E = M3 - M4
+// Same stage as the pair kernel (raw tiles, operands transformed in place, phases between the MFMA groups, asm loads), one wave
+// per workgroup.  blockIdx = (((g * MTT + mo) * MTT + mi) * WPG + wslot); partials part[blockIdx][f][a][o][i] (16 x 16, complete).
+// -----------------------------------------------------------------------------------------------
+template <int KH, int KW, bool FW>
+__device__ __forceinline__ void gradw_winot_body(const float *__restrict__ gz, const float *__restrict__ x, float *__restrict__ dst,
+                                                 int G, int CQ, int H, int W, int NS, int B, int WPG, int g, int wslot, int cg, int cx,
+                                                 bool fhh, float *xt, float *gt)
+{
+    static_assert(KW == 3 || KW == 5, "");
+    constexpr int KS = 2, TW = KW == 3 ? 4 : 2, HL = 6 - TW, NTW = 4 * KS, SWC = TW * NTW, NP = SWC / 4, RS = KH + 1;
+    constexpr int XP = SWC + 4, GP = SWC + 4;
+    constexpr int NGI = (16 * NP + 63) / 64, NXI = (16 * (NP + 1) + 63) / 64, NLD = NGI + NXI;
+    constexpr int PD = 2;
+    typedef unsigned v4u __attribute__((ext_vector_type(4)));
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    const int lane = threadIdx.x;
+    const int q = lane >> 4, n = lane & 15;
+    const int HW = H * W;
+    const unsigned slab_bytes = (unsigned)CQ * (unsigned)HW * 4u;
+    for (int i = lane; i < 16 * XP + 4; i += 64) { xt[i] = 0.f; gt[i] = 0.f; }
+    v4f acc[KH][6];
+#pragma unroll
+    for (int a = 0; a < KH; ++a)
+#pragma unroll
+        for (int f = 0; f < 6; ++f) acc[a][f] = (v4f){0.f, 0.f, 0.f, 0.f};
+    // raw reads of lane (q, n): channel n, canonical tile 4 ks + q: the gz tile as it lies in memory, the six x columns ascending
+    int grd[KS], xrd[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+        const int kc = 4 * ks + q;
+        grd[ks] = n * GP + (FW ? SWC - TW - TW * kc : TW * kc);
+        xrd[ks] = n * XP + (FW ? SWC - 6 - TW * kc + HL : 4 + TW * kc - HL);
+    }
+    int lwg[NGI];
+#pragma unroll
+    for (int i = 0; i < NGI; ++i) {
+        const int t = 64 * i + lane;
+        lwg[i] = t < 16 * NP ? (t / NP) * GP + 4 * (t % NP) : 16 * GP;
+    }
+    for (int u = wslot; u < B * NS; u += WPG) {
+        const int b = u / NS, strip = u % NS;
+        const size_t slab = ((size_t)b * G + g) * CQ * HW;
+        auto rsrc = [&](const float *base, bool ok) {
+            return __builtin_amdgcn_make_buffer_rsrc((void *)(base + slab), 0, ok ? (int)slab_bytes : 0, 0x00020000);
+        };
+        const int ms = FW ? W - SWC - strip * SWC : strip * SWC;
+        const int hm = FW ? ms + SWC : ms - 4;
+        unsigned lvx[NXI], lvg[NGI];
+        int lwx[NXI];
+#pragma unroll
+        for (int i = 0; i < NXI; ++i) {
+            const int t = 64 * i + lane;
+            lvx[i] = OFF_BAD_CHANNEL;
+            lwx[i] = 16 * XP;
+            if (t < 16 * NP) {
+                const int c = t / NP, k = t % NP;
+                if (cx + c < CQ && ms + 4 * k >= 0 && ms + 4 * k < W) lvx[i] = (unsigned)(cx + c) * HW * 4u + (unsigned)(ms + 4 * k) * 4u;
+                lwx[i] = c * XP + (FW ? 0 : 4) + 4 * k;
+            } else if (t < 16 * (NP + 1)) {
+                const int c = t - 16 * NP;
+                if (cx + c < CQ && hm >= 0 && hm < W) lvx[i] = (unsigned)(cx + c) * HW * 4u + (unsigned)hm * 4u;
+                lwx[i] = c * XP + (FW ? SWC : 0);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < NGI; ++i) {
+            const int t = 64 * i + lane;
+            lvg[i] = OFF_BAD_CHANNEL;
+            if (t < 16 * NP) {
+                const int c = t / NP, k = t % NP;
+                if (cg + c < CQ && ms + 4 * k >= 0 && ms + 4 * k < W) lvg[i] = (unsigned)(cg + c) * HW * 4u + (unsigned)(ms + 4 * k) * 4u;
+            }
+        }
+        auto rowbytes = [&](int h) { return (unsigned)((fhh ? H - 1 - h : h) * W) * 4u; };
+        v4u LX[PD][NXI], LG[PD][NGI];
+        auto issue = [&](auto par_c, int h) {
+            constexpr int PAR = decltype(par_c)::value;
+            const bool ok = h >= 0 && h < H;
+            const __amdgpu_buffer_rsrc_t rx = rsrc(x, ok), rg = rsrc(gz, ok);
+            const unsigned ro = ok ? rowbytes(h) : 0u;
+            auto &lx = LX[PAR]; auto &lg = LG[PAR]; auto &ovx = lvx; auto &ovg = lvg;   // (clang: asm operands do not capture by themselves)
+#pragma unroll
+            for (int i = 0; i < NXI; ++i)
+                asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(lx[i]) : "v"(ovx[i]), "s"(rx), "s"(ro) : "memory");
+#pragma unroll
+            for (int i = 0; i < NGI; ++i)
+                asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(lg[i]) : "v"(ovg[i]), "s"(rg), "s"(ro) : "memory");
+        };
+        float GA[2][6][KS], XB[RS][6][KS];
+        float RGZ[KS][TW];
+        v2f RXR[KS][3];
+#pragma unroll
+        for (int sl = 0; sl < RS; ++sl)
+#pragma unroll
+            for (int f = 0; f < 6; ++f)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) XB[sl][f][ks] = 0.f;
+        auto phase_a = [&](auto ln_c, int row) {
+            constexpr int LN = decltype(ln_c)::value;
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((PD - 1) * NLD) : "memory");
+            auto &lx = LX[LN]; auto &lg = LG[LN];
+#pragma unroll
+            for (int i = 0; i < NXI; ++i) asm volatile("" : "+v"(lx[i]));
+#pragma unroll
+            for (int i = 0; i < NGI; ++i) asm volatile("" : "+v"(lg[i]));
+#pragma unroll
+            for (int i = 0; i < NXI; ++i) reinterpret_cast<v4u *>(xt)[lwx[i] >> 2] = LX[LN][i];
+#pragma unroll
+            for (int i = 0; i < NGI; ++i) reinterpret_cast<v4u *>(gt)[lwg[i] >> 2] = LG[LN][i];
+            issue(IC<LN>{}, row + PD);
+        };
+        auto phase_b = [&]() {
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                if constexpr (TW == 4) {
+                    const v4f r = *reinterpret_cast<const v4f *>(&gt[grd[ks]]);
+                    RGZ[ks][0] = r.x; RGZ[ks][1] = r.y; RGZ[ks][2] = r.z; RGZ[ks][3] = r.w;
+                } else {
+                    const v2f r = *reinterpret_cast<const v2f *>(&gt[grd[ks]]);
+                    RGZ[ks][0] = r.x; RGZ[ks][1] = r.y;
+                }
+#pragma unroll
+                for (int j = 0; j < 3; ++j) RXR[ks][j] = *reinterpret_cast<const v2f *>(&xt[xrd[ks] + 2 * j]);
+            }
+        };
+        auto phase_c = [&](auto sn_c, auto pn_c) {
+            constexpr int SN = decltype(sn_c)::value, PN = decltype(pn_c)::value;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                float r[6];
+#pragma unroll
+                for (int j = 0; j < 3; ++j) { const v2f t = RXR[ks][j]; r[2 * j] = t.x; r[2 * j + 1] = t.y; }
+                const float d0 = r[FW ? 5 : 0], d1 = r[FW ? 4 : 1], d2 = r[FW ? 3 : 2], d3 = r[FW ? 2 : 3], d4 = r[FW ? 1 : 4],
+                            d5 = r[FW ? 0 : 5];
+                if constexpr (KW == 3) {
+                    const float g0 = RGZ[ks][FW ? 3 : 0], g1 = RGZ[ks][FW ? 2 : 1], g2 = RGZ[ks][FW ? 1 : 2], g3 = RGZ[ks][FW ? 0 : 3];
+                    const float e = g0 + g2, od = g1 + g3;
+                    const float e2 = __builtin_fmaf(2.25f, g2, g0), o2 = __builtin_fmaf(3.375f, g3, 1.5f * g1);
+                    GA[PN][0][ks] = g0; GA[PN][1][ks] = e + od; GA[PN][2][ks] = e - od;
+                    GA[PN][3][ks] = e2 + o2; GA[PN][4][ks] = e2 - o2; GA[PN][5][ks] = g3;
+                    const float pp = __builtin_fmaf(-2.25f, d2, d4), rr = __builtin_fmaf(-2.25f, d1, d3);
+                    const float ss = d4 - d2, uq = d3 - d1;
+                    XB[SN][0][ks] = __builtin_fmaf(2.25f, d0, __builtin_fmaf(-3.25f, d2, d4));
+                    XB[SN][1][ks] = pp + rr; XB[SN][2][ks] = pp - rr;
+                    XB[SN][3][ks] = __builtin_fmaf(1.5f, uq, ss); XB[SN][4][ks] = __builtin_fmaf(-1.5f, uq, ss);
+                    XB[SN][5][ks] = __builtin_fmaf(2.25f, d1, __builtin_fmaf(-3.25f, d3, d5));
+                } else {
+                    const float g0 = RGZ[ks][FW ? 1 : 0], g1 = RGZ[ks][FW ? 0 : 1];
+                    const float hg = 0.5f * g1;
+                    GA[PN][0][ks] = g0; GA[PN][1][ks] = g0 + g1; GA[PN][2][ks] = g0 - g1;
+                    GA[PN][3][ks] = g0 + hg; GA[PN][4][ks] = g0 - hg; GA[PN][5][ks] = g1;
+                    const float pp = __builtin_fmaf(4.f, d4, -d2), rr = __builtin_fmaf(4.f, d3, -d1);
+                    const float ss = d2 - d4, uq = d1 - d3;
+                    XB[SN][0][ks] = __builtin_fmaf(4.f, d4, __builtin_fmaf(-5.f, d2, d0));
+                    XB[SN][1][ks] = pp + rr; XB[SN][2][ks] = pp - rr;
+                    XB[SN][3][ks] = __builtin_fmaf(2.f, ss, uq); XB[SN][4][ks] = __builtin_fmaf(2.f, ss, -uq);
+                    XB[SN][5][ks] = __builtin_fmaf(4.f, d5, __builtin_fmaf(-5.f, d3, d1));
+                }
+            }
+        };
+        auto mfmas = [&](auto sc_c, auto pc_c, auto a_c) {
+            constexpr int SC = decltype(sc_c)::value, PC = decltype(pc_c)::value, a = decltype(a_c)::value;
+            constexpr int sx = (SC + RS - a) % RS;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int f = 0; f < 6; ++f)
+                    acc[a][f] = __builtin_amdgcn_mfma_f32_16x16x4f32(GA[PC][f][ks], XB[sx][f][ks], acc[a][f], 0, 0, 0);
+        };
+        auto step = [&](auto i_c, int h) {
+            constexpr int I = decltype(i_c)::value;
+            constexpr int SC = I % RS, PC = I & 1;
+            phase_a(IC<(I + 1) % PD>{}, h + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfmas(IC<SC>{}, IC<PC>{}, IC<0>{});
+            __builtin_amdgcn_sched_barrier(0);
+            phase_b();
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (KH > 1) mfmas(IC<SC>{}, IC<PC>{}, IC<1>{});
+            __builtin_amdgcn_sched_barrier(0);
+            phase_c(IC<(I + 1) % RS>{}, IC<PC ^ 1>{});
+            __builtin_amdgcn_sched_barrier(0);
+            [&]<int... A>(std::integer_sequence<int, A...>) {
+                ((mfmas(IC<SC>{}, IC<PC>{}, IC<A + 2>{})), ...);
+            }(std::make_integer_sequence<int, (KH > 2 ? KH - 2 : 0)>{});
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        issue(IC<0>{}, 0);
+        issue(IC<1>{}, 1);
+        phase_a(IC<0>{}, 0);
+        phase_b();
+        phase_c(IC<0>{}, IC<0>{});
+#pragma unroll
+        for (int a = 0; a < KH; ++a)
+#pragma unroll
+            for (int f = 0; f < 6; ++f) asm volatile("" : "+a"(acc[a][f]));      // (see the pair kernel: no compiler wait inside the loop)
+        constexpr int UN = (RS % 2 == 0) ? RS : 2 * RS;
+        for (int h0 = 0; h0 < H; h0 += UN) {
+            [&]<int... I>(std::integer_sequence<int, I...>) {
+                ((h0 + I < H ? step(IC<I>{}, h0 + I) : (void)0), ...);
+            }(std::make_integer_sequence<int, UN>{});
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+#pragma unroll
+    for (int a = 0; a < KH; ++a)
+#pragma unroll
+        for (int f = 0; f < 6; ++f) {
+            const v4f v = acc[a][f];
+            const float v0 = v.x, v1 = v.y, v2 = v.z, v3 = v.w;
+            float *e = dst + (f * KH + a) * 256 + (4 * q) * 16 + n;
+            e[0] = v0; e[16] = v1; e[32] = v2; e[48] = v3;
+        }
+}
+
+template <int KH, int KW>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 2))) void finc_gradw_winot_kernel(
+    const float *__restrict__ gz, const float *__restrict__ x, float *__restrict__ part, int G, int CQ, int H, int W, int NS, int B,
+    int WPG, unsigned orient, int MTT)
+{
+    constexpr int SWC = (KW == 3 ? 4 : 2) * 8;
+    __shared__ __attribute__((aligned(16))) float xt[16 * (SWC + 4) + 4];
+    __shared__ __attribute__((aligned(16))) float gt[16 * (SWC + 4) + 4];
+    int bi = blockIdx.x;
+    const int wslot = bi % WPG; bi /= WPG;
+    const int mi = bi % MTT; bi /= MTT;
+    const int mo = bi % MTT;
+    const int g = bi / MTT;
+    const unsigned o = finc_group_orient(orient, g);
+    const bool fhh = (o & FINC_FLIP_H) != 0, fw = (o & FINC_FLIP_W) != 0;
+    float *dst = part + (size_t)blockIdx.x * (6 * KH * 256);
+    if (fw) gradw_winot_body<KH, KW, true>(gz, x, dst, G, CQ, H, W, NS, B, WPG, g, wslot, 16 * mo, 16 * mi, fhh, xt, gt);
+    else gradw_winot_body<KH, KW, false>(gz, x, dst, G, CQ, H, W, NS, B, WPG, g, wslot, 16 * mo, 16 * mi, fhh, xt, gt);
+}
+
+// G^T over the summed partials of finc_gradw_winot_kernel; entries e = ((mo * MTT + mi) * KH + a) * 256 + o * 16 + i per group.
+template <int KW>
+__global__ __launch_bounds__(256) void gradw_winot_reduce_kernel(const float *__restrict__ part, float *__restrict__ gw, int Cq, int KH,
+                                                                 int MTT, int WPG)
+{
+    __shared__ float slice[8][6][32];
+    const int g = blockIdx.y;
+    const int per = 6 * KH * 256;
+    const int el = threadIdx.x & 31, j = threadIdx.x >> 5;
+    const int e = blockIdx.x * 32 + el;
+    const int oi = e & 255, a = (e >> 8) % KH, tile = (e >> 8) / KH;       // tile = mo * MTT + mi
+    float s[6];
+#pragma unroll
+    for (int f = 0; f < 6; ++f) {
+        const float *p = part + ((size_t)(g * MTT * MTT + tile) * WPG) * per + (size_t)(f * KH + a) * 256 + oi;
+        float t = 0.f;
+        for (int w = j; w < WPG; w += 8) t += p[(size_t)w * per];
+        s[f] = t;
+    }
+#pragma unroll
+    for (int f = 0; f < 6; ++f) slice[j][f][el] = s[f];
+    __syncthreads();
+    if (j != 0) return;
+#pragma unroll
+    for (int f = 0; f < 6; ++f)
+        s[f] = ((slice[0][f][el] + slice[1][f][el]) + (slice[2][f][el] + slice[3][f][el])) +
+               ((slice[4][f][el] + slice[5][f][el]) + (slice[6][f][el] + slice[7][f][el]));
+    const int oc = 16 * (tile / MTT) + (oi >> 4), ic = 16 * (tile % MTT) + (oi & 15);
+    if (oc >= Cq || ic >= Cq) return;
+    const float s12 = s[1] + s[2], d12 = s[1] - s[2], s34 = s[3] + s[4], d34 = s[3] - s[4];
+    float k[KW];
+    if constexpr (KW == 3) {
+        k[0] = s[0] * (1.f / 2.25f) - 0.4f * s12 + (8.f / 45.f) * s34;
+        k[1] = -0.4f * d12 + (4.f / 15.f) * d34;
+        k[2] = 0.4f * (s34 - s12) + s[5];
+    } else {
+        const float s6 = s12 * (1.f / 6.f), d6 = d12 * (1.f / 6.f);
+        k[0] = s[0] + s6 + (4.f / 3.f) * s34;
+        k[1] = d6 + (2.f / 3.f) * d34;
+        k[2] = s6 + (1.f / 3.f) * s34;
+        k[3] = d6 + (1.f / 6.f) * d34;
+        k[4] = s6 + (1.f / 12.f) * s34 + 0.25f * s[5];
+    }
+    if (a == 0 && ic >= oc) k[KW - 1] = 0.f;                // the corner tap's mask (b = 0; PaddedConv2d.reset_gradients)
+    float *o = gw + (((size_t)(g * Cq + oc) * Cq + ic) * KH + (KH - 1 - a)) * KW;
+#pragma unroll
+    for (int t = 0; t < KW; ++t) o[t] = k[t];
+}
+
 typedef void (*gradw_fn)(const float *, const float *, float *, int, int, int, int, int, int, int, unsigned);
 typedef void (*gradw_tiled_fn)(const float *, const float *, float *, int, int, int, int, int, int, int, unsigned, int);
 struct GradwInst {
@@ -1084,6 +1377,22 @@ static size_t gradw_wino_bytes(const FincShape &s, const GradwWinoInst *w)
     return (size_t)s.G * w->fs * gradw_wpg_wino(s, w->fs) * (6 / w->fs) * s.KH * w->cqp * w->cqp * sizeof(float);
 }
 static bool gradw_use_tiled(const GradwInst *i, const FincShape &s) { return i && !i->gw && i->gw_tiled && s.W % 4 == 0; }
+// ... and its Winograd form: 3x3 (strips of 32 columns) and 5x5 (strips of 16)
+static int gradw_winot_strip(const FincShape &s) { return s.KW == 3 ? 32 : 16; }
+static bool gradw_use_winot(const GradwInst *i, const FincShape &s)
+{
+    static const bool off = finc_env("FINC_GRADW_NO_WINO") != nullptr;
+    return !off && gradw_use_tiled(i, s) && ((s.KH == 3 && s.KW == 3) || (s.KH == 5 && s.KW == 5)) && s.W >= gradw_winot_strip(s);
+}
+static int gradw_wpg_winot(const FincShape &s, int mtt)
+{
+    const int sw = gradw_winot_strip(s);
+    const int units = s.B * ((s.W + sw - 1) / sw);
+    int w = 2048 / (s.G * mtt * mtt);
+    if (w < 1) w = 1;
+    if (w > 256) w = 256;
+    return units < w ? units : w;
+}
 
 size_t finc_gradw_workspace_bytes(const FincShape &s)
 {
@@ -1096,7 +1405,11 @@ size_t finc_gradw_workspace_bytes(const FincShape &s)
         const size_t mine = gradw_wino_bytes(s, w);
         return mine > other ? mine : other;
     }
-    if (gradw_use_tiled(i, s)) return (size_t)s.G * gradw_wpg_tiled(s, i->mtg) * s.KH * s.KW * i->mtg * i->mtg * 256 * sizeof(float);
+    if (gradw_use_tiled(i, s)) {
+        const size_t direct = (size_t)s.G * gradw_wpg_tiled(s, i->mtg) * s.KH * s.KW * i->mtg * i->mtg * 256 * sizeof(float);
+        const size_t wino = gradw_use_winot(i, s) ? (size_t)s.G * gradw_wpg_winot(s, i->mtg) * 6 * s.KH * i->mtg * i->mtg * 256 * sizeof(float) : 0;
+        return wino > direct ? wino : direct;
+    }
     if (!i->gw) return 0;
     return (size_t)s.G * gradw_wpg(s) * s.KH * s.KW * i->mtg * i->mtg * 256 * sizeof(float);
 }
@@ -1117,6 +1430,27 @@ int finc_gradw_launch(const float *gz, const float *x, float *gw, void *workspac
         FINC_CHECK_LAUNCH();
         hipLaunchKernelGGL(gradw_wino_reduce_kernel, dim3(s.KH * w->cqp * w->cqp / 32, s.G), dim3(256), 0, st,
                            (const float *)workspace, gw, s.Cq, w->cqp, s.KH, w->fs, WPG);
+        FINC_CHECK_LAUNCH();
+        return FINC_OK;
+    }
+    if (aligned16 && gradw_use_winot(i, s)) {
+        WPG = gradw_wpg_winot(s, i->mtg);
+        const int sw = gradw_winot_strip(s);
+        const dim3 grid(s.G * i->mtg * i->mtg * WPG);
+        const int entries = i->mtg * i->mtg * s.KH * 256;
+        if (s.KW == 3) {
+            hipLaunchKernelGGL((finc_gradw_winot_kernel<3, 3>), grid, dim3(64), 0, st, gz, x, (float *)workspace, s.G, s.Cq, s.H, s.W,
+                               (s.W + sw - 1) / sw, s.B, WPG, s.orient, i->mtg);
+            FINC_CHECK_LAUNCH();
+            hipLaunchKernelGGL(gradw_winot_reduce_kernel<3>, dim3(entries / 32, s.G), dim3(256), 0, st, (const float *)workspace, gw, s.Cq,
+                               s.KH, i->mtg, WPG);
+        } else {
+            hipLaunchKernelGGL((finc_gradw_winot_kernel<5, 5>), grid, dim3(64), 0, st, gz, x, (float *)workspace, s.G, s.Cq, s.H, s.W,
+                               (s.W + sw - 1) / sw, s.B, WPG, s.orient, i->mtg);
+            FINC_CHECK_LAUNCH();
+            hipLaunchKernelGGL(gradw_winot_reduce_kernel<5>, dim3(entries / 32, s.G), dim3(256), 0, st, (const float *)workspace, gw, s.Cq,
+                               s.KH, i->mtg, WPG);
+        }
         FINC_CHECK_LAUNCH();
         return FINC_OK;
     }
@@ -1144,12 +1478,13 @@ int finc_gradw_launch(const float *gz, const float *x, float *gw, void *workspac
 
 // which grad-weight kernel finc_backward_f32 runs for this shape, given 16-byte aligned activations and a full workspace:
 // 0 direct (no MFMA instantiation), 1 dword MFMA kernel, 2 staged (16-byte pieces through LDS), 3 tiled (one tile pair per workgroup),
-// 4 Winograd (transposed F(4,3): half the multiplies)
+// 4 Winograd (transposed F(4,3): half the multiplies), 5 Winograd on one tile pair per wave (3x3: F(4,3), 5x5: F(2,5))
 int finc_gradw_variant(const FincShape &s)
 {
     const GradwInst *i = find_gradw(s.Cq, s.KH, s.KW);
     if (!i || finc_gradw_workspace_bytes(s) == 0) return 0;
     if (find_gradw_wino(s)) return 4;
+    if (gradw_use_winot(i, s)) return 5;
     if (gradw_use_tiled(i, s)) return 3;
     if (!i->gw) return 0;
     static const bool no_staged = finc_env("FINC_GRADW_NO_STAGED") != nullptr;

@@ -261,7 +261,11 @@ BACKWARD_CASES = [
     (2, 128, 9, 16, 3, "winograd", 1),     # Cq = 32: two full tiles per side
     (2, 192, 10, 20, 3, "tiled", 2),       # the tiled kernel with a partial last strip
     (2, 192, 10, 16, 3, "tiled", 2),       # Cq = 48 3x3: finc_gradw_tiled_kernel, K-split grad-input (2 waves per strip)
-    (2, 192, 7, 32, 5, "tiled", 4),        # Cq = 48 5x5 (the c5 bank): tiled grad-weight, K-split grad-input (4 waves)
+    (2, 192, 7, 32, 5, "winograd_tiled", 4),   # Cq = 48 5x5 (the c5 bank): F(2,5) transposed, one tile pair per wave; K-split grad-input
+    (2, 192, 6, 40, 5, "winograd_tiled", 4),   # ... two and a half strips of 16 columns
+    (2, 128, 9, 20, 5, "winograd_tiled", 4),   # Cq = 32 5x5, a partial second strip
+    (2, 192, 10, 36, 3, "winograd_tiled", 2),  # Cq = 48 3x3 from 32 columns up: F(4,3) transposed on tile pairs, partial second strip
+    (2, 256, 5, 64, 3, "winograd_tiled", 4),   # Cq = 64 3x3
     (2, 96, 9, 16, 2, "staged", 1),        # 2x2 at 24 channels: finc_gradw_staged_kernel (4-row blocks, FLAT tiles)
     (2, 64, 7, 32, 5, "staged", 1),        # 5x5 at 16 channels: staged
     (2, 48, 33, 32, 3, "staged", 1),       # c2's bank, more than one band of rows

@@ -186,3 +186,23 @@ def test_f43_transposed_fp32_error_model():
     got = np.einsum("fk,ocf->ock", G.astype(np.float32), M).astype(np.float32)
     e = np.abs(got - ref).max() / np.abs(ref).max()
     assert e < 1e-5, e
+
+
+def test_f25_transposed_is_the_filter_gradient():
+    """finc_gradw_winot_kernel<5,5> (finc_gradw.hip): F(2,5) read as a trilinear form gives the 5-tap filter's gradient from tiles of
+    two columns; the constants of the kernel's U = A gz and of gradw_winot_reduce_kernel<5>'s G^T."""
+    BT, G, AT = ([[Fr(x) for x in row] for row in F25[k]] for k in ("BT", "G", "AT"))
+    for i in range(2):
+        U = [AT[i][f] for f in range(6)]
+        for j in range(6):
+            V = [BT[f][j] for f in range(6)]
+            for k in range(5):
+                dg = sum(G[f][k] * U[f] * V[f] for f in range(6))
+                assert dg == (1 if j == i + k else 0), (i, j, k, dg)
+    assert [[AT[i][f] for i in range(2)] for f in range(6)] == [[1, 0], [1, 1], [1, -1], [1, h], [1, -h], [0, 1]]
+    # k0 = M0 + S/6 + 4T/3; k1 = D/6 + 2E/3; k2 = S/6 + T/3; k3 = D/6 + E/6; k4 = S/6 + T/12 + M5/4  (S, D = M1 +- M2; T, E = M3 +- M4)
+    assert [G[f][0] for f in range(6)] == [1, Fr(1, 6), Fr(1, 6), Fr(4, 3), Fr(4, 3), 0]
+    assert [G[f][1] for f in range(6)] == [0, Fr(1, 6), Fr(-1, 6), Fr(2, 3), Fr(-2, 3), 0]
+    assert [G[f][2] for f in range(6)] == [0, Fr(1, 6), Fr(1, 6), Fr(1, 3), Fr(1, 3), 0]
+    assert [G[f][3] for f in range(6)] == [0, Fr(1, 6), Fr(-1, 6), Fr(1, 6), Fr(-1, 6), 0]
+    assert [G[f][4] for f in range(6)] == [0, Fr(1, 6), Fr(1, 6), Fr(1, 12), Fr(1, 12), Fr(1, 4)]
