@@ -1382,7 +1382,9 @@ static int gradw_winot_strip(const FincShape &s) { return s.KW == 3 ? 32 : 16; }
 static bool gradw_use_winot(const GradwInst *i, const FincShape &s)
 {
     static const bool off = finc_env("FINC_GRADW_NO_WINO") != nullptr;
-    return !off && gradw_use_tiled(i, s) && ((s.KH == 3 && s.KW == 3) || (s.KH == 5 && s.KW == 5)) && s.W >= gradw_winot_strip(s);
+    if (off || !i || s.W % 4 != 0 || s.W < gradw_winot_strip(s)) return false;
+    if (s.KH == 5 && s.KW == 5 && s.Cq > 12 && s.Cq <= 16) return true;   // one full tile: beats the staged direct kernel too
+    return gradw_use_tiled(i, s) && ((s.KH == 3 && s.KW == 3) || (s.KH == 5 && s.KW == 5));
 }
 static int gradw_wpg_winot(const FincShape &s, int mtt)
 {
@@ -1398,20 +1400,14 @@ size_t finc_gradw_workspace_bytes(const FincShape &s)
 {
     const GradwInst *i = find_gradw(s.Cq, s.KH, s.KW);
     if (!i || !finc_conv_supported(s.Cq, s.H, s.W, s.KH, s.KW)) return 0;
-    if (const GradwWinoInst *w = find_gradw_wino(s)) {     // (unaligned activations fall back to the forms below: room for both)
-        size_t other = 0;
-        if (gradw_use_tiled(i, s)) other = (size_t)s.G * gradw_wpg_tiled(s, i->mtg) * s.KH * s.KW * i->mtg * i->mtg * 256 * sizeof(float);
-        else if (i->gw) other = (size_t)s.G * gradw_wpg(s) * s.KH * s.KW * i->mtg * i->mtg * 256 * sizeof(float);
-        const size_t mine = gradw_wino_bytes(s, w);
-        return mine > other ? mine : other;
-    }
-    if (gradw_use_tiled(i, s)) {
-        const size_t direct = (size_t)s.G * gradw_wpg_tiled(s, i->mtg) * s.KH * s.KW * i->mtg * i->mtg * 256 * sizeof(float);
-        const size_t wino = gradw_use_winot(i, s) ? (size_t)s.G * gradw_wpg_winot(s, i->mtg) * 6 * s.KH * i->mtg * i->mtg * 256 * sizeof(float) : 0;
-        return wino > direct ? wino : direct;
-    }
-    if (!i->gw) return 0;
-    return (size_t)s.G * gradw_wpg(s) * s.KH * s.KW * i->mtg * i->mtg * 256 * sizeof(float);
+    // room for the form the launch picks AND the one it falls back to on unaligned activations
+    size_t need = 0;
+    auto grow = [&](size_t n) { need = n > need ? n : need; };
+    if (const GradwWinoInst *w = find_gradw_wino(s)) grow(gradw_wino_bytes(s, w));
+    if (gradw_use_winot(i, s)) grow((size_t)s.G * gradw_wpg_winot(s, i->mtg) * 6 * s.KH * i->mtg * i->mtg * 256 * sizeof(float));
+    if (gradw_use_tiled(i, s)) grow((size_t)s.G * gradw_wpg_tiled(s, i->mtg) * s.KH * s.KW * i->mtg * i->mtg * 256 * sizeof(float));
+    else if (i->gw) grow((size_t)s.G * gradw_wpg(s) * s.KH * s.KW * i->mtg * i->mtg * 256 * sizeof(float));
+    return need;
 }
 
 // FINC_ERR_UNSUPPORTED: no MFMA grad-weight kernel for this call (the caller falls back to the direct kernel)

@@ -267,7 +267,8 @@ BACKWARD_CASES = [
     (2, 192, 10, 36, 3, "winograd_tiled", 2),  # Cq = 48 3x3 from 32 columns up: F(4,3) transposed on tile pairs, partial second strip
     (2, 256, 5, 64, 3, "winograd_tiled", 4),   # Cq = 64 3x3
     (2, 96, 9, 16, 2, "staged", 1),        # 2x2 at 24 channels: finc_gradw_staged_kernel (4-row blocks, FLAT tiles)
-    (2, 64, 7, 32, 5, "staged", 1),        # 5x5 at 16 channels: staged
+    (2, 48, 7, 32, 5, "staged", 1),        # 5x5 at 12 channels: staged
+    (2, 64, 7, 32, 5, "winograd_tiled", 1),    # 5x5 at 16 channels: one full tile pair
     (2, 48, 33, 32, 3, "staged", 1),       # c2's bank, more than one band of rows
 ]
 
