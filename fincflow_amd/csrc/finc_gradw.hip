@@ -1333,7 +1333,8 @@ static int gradw_wino_strip(const FincShape &s)
 const GradwWinoInst *find_gradw_wino(const FincShape &s)
 {
     static const bool off = finc_env("FINC_GRADW_NO_WINO") != nullptr;      // experiment switch
-    if (off || s.KW != 3 || s.W % 4 != 0 || s.Cq <= 12) return nullptr;
+    static const char *pmax = finc_env("FINC_GRADW_WINO_PAIR_MAX");         // experiment switch: larger banks go to the tile-pair form
+    if (off || s.KW != 3 || s.W % 4 != 0 || s.Cq <= 12 || (pmax && s.Cq > atoi(pmax))) return nullptr;
     const GradwWinoInst *best = nullptr;
     for (const GradwWinoInst &i : g_gradw_wino)
         if (i.cqp >= s.Cq && i.kh == s.KH && (!best || i.cqp < best->cqp)) best = &i;
@@ -1384,6 +1385,7 @@ static bool gradw_use_winot(const GradwInst *i, const FincShape &s)
     static const bool off = finc_env("FINC_GRADW_NO_WINO") != nullptr;
     if (off || !i || s.W % 4 != 0 || s.W < gradw_winot_strip(s)) return false;
     if (s.KH == 5 && s.KW == 5 && s.Cq > 12 && s.Cq <= 16) return true;   // one full tile: beats the staged direct kernel too
+    if (s.KH == 3 && s.KW == 3 && s.Cq > 12 && !find_gradw_wino(s)) return true;   // (only with FINC_GRADW_WINO_PAIR_MAX)
     return gradw_use_tiled(i, s) && ((s.KH == 3 && s.KW == 3) || (s.KH == 5 && s.KW == 5));
 }
 static int gradw_wpg_winot(const FincShape &s, int mtt)

@@ -8,6 +8,8 @@ dev = torch.device("cuda:0")
 shapes = ((256, 96, 64, 64, 3), (64, 96, 64, 64, 3), (256, 64, 64, 64, 3), (128, 128, 64, 64, 3), (256, 80, 32, 32, 3))
 if len(sys.argv) > 1 and sys.argv[1] == "c3":
     shapes = shapes[:1]
+elif len(sys.argv) > 1 and sys.argv[1] == "mid":        # the pair kernel's banks
+    shapes = ((256, 64, 64, 64, 3), (256, 80, 64, 64, 3), (256, 96, 64, 64, 3), (128, 112, 64, 64, 3), (128, 128, 64, 64, 3))
 elif len(sys.argv) > 1 and sys.argv[1] == "big":        # the banks on one tile pair per wave
     shapes = ((64, 192, 128, 128, 5), (128, 64, 64, 64, 5), (64, 128, 64, 64, 5), (64, 192, 64, 64, 3), (64, 256, 64, 64, 3), (32, 384, 64, 64, 3))
 for (B, C, H, W, K) in shapes:
