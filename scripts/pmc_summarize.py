@@ -19,6 +19,8 @@ for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursiv
             k = "forward_wino5"
         elif "finc_gradw_wino_kernel" in k:
             k = "gradw_wino"
+        elif "finc_gradw_winot_kernel" in k:
+            k = "gradw_wino_tiled"
         elif "finc_gradw_staged_kernel" in k:
             k = "gradw_staged"
         elif "finc_gradw_tiled_kernel" in k:
