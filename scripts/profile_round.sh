@@ -42,4 +42,4 @@ else
     echo "pmc $w done"
   done
 fi
-ls -la gpurun_out/${TAG}
+ls -la $ROOT/gpurun_out/${TAG}
