@@ -239,7 +239,8 @@ int finc_mix_f32(const float *in, const float *mat, const float *bias, float *ou
 int finc_inverse_kernel_variant(int B, int G, int Cq, int H, int W, int KH, int KW, int *info);
 /* Which kernels finc_backward_f32 runs for this shape (16-byte aligned activations, full workspace): info[3] =
  * {grad-weight: 0 direct / 1 dword MFMA strip kernel / 2 staged (16-byte pieces through LDS) / 3 tiled (one tile pair per
- * workgroup), grad-input: waves per strip of the MFMA strip kernel (0 = direct kernel; > 1 = K-split), grad-input: staged form
+ * workgroup) / 4 Winograd (3x3 banks of 13..32 channels: F(4,3) transposed, half the multiplies) / 5 Winograd on one tile pair
+ * per wave (3x3 above 32 channels: F(4,3) transposed; 5x5 above 12: F(2,5) transposed), grad-input: waves per strip of the MFMA strip kernel (0 = direct kernel; > 1 = K-split), grad-input: staged form
  * (1) or dword form (0); 2 = Winograd F(2,3) along W, 3 = the big banks' M-split, 4 = Winograd F(4,3) along W, 5 = Winograd
  * F(2,5) along W (5x5 banks)}.  Lets a parity
  * test assert WHICH kernel its numbers came from. */
