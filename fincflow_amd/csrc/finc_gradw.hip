@@ -1363,7 +1363,9 @@ const GradwInst *find_gradw(int Cq, int KH, int KW)
 static int gradw_wpg(const FincShape &s)
 {
     const int units = s.B * ((s.W + 15) / 16);
-    return units < 256 ? units : 256;
+    int w = 1024 / s.G;                                   // one wave per SIMD over all groups (G = 4: 256 per group)
+    if (w < 1) w = 1;
+    return units < w ? units : w;
 }
 // tiled form: G * MTT^2 * WPG workgroups of one wave; about two per SIMD
 static int gradw_wpg_tiled(const FincShape &s, int mtt)
@@ -1379,7 +1381,8 @@ static int gradw_wpg_wino(const FincShape &s, int fs)
 {
     const int sw = gradw_wino_strip(s);
     const int units = s.B * ((s.W + sw - 1) / sw);
-    const int w = 256 / fs;
+    int w = 1024 / (s.G * fs);                            // one wave per SIMD over all groups (G = 4, two waves per strip: 128)
+    if (w < 1) w = 1;
     return units < w ? units : w;
 }
 static size_t gradw_wino_bytes(const FincShape &s, const GradwWinoInst *w)

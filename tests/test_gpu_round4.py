@@ -381,3 +381,40 @@ def test_non_square_filters_run_on_mfma(case, dev):
         for m, w in zip((unit.conv_tl, unit.conv_tr, unit.conv_bl, unit.conv_br), wds):
             want = (w.grad * m.get_mask().cpu().double()).numpy()
             assert rel_err(m.conv.weight.grad.cpu().numpy(), want) <= 1e-4
+
+
+# ------------------------------------------------------------------ Winograd weight gradients (finc_gradw.hip)
+ONE_GROUP_GRADW_CASES = [
+    # (B, Cq, H, W, K, order, grad-weight kernel): a single PaddedConv2d (G = 1: its waves spread over the whole chip, not a
+    # quarter of it), every storage order -- the mirrored strips and the row walk from the bottom
+    (3, 24, 9, 64, 3, "TL", "winograd"), (2, 24, 7, 36, 3, "TR", "winograd"), (2, 20, 5, 32, 3, "BL", "winograd"),
+    (2, 32, 6, 48, 3, "BR", "winograd"), (2, 16, 4, 16, 3, "TR", "winograd"),
+    (2, 48, 5, 40, 3, "BR", "winograd_tiled"), (1, 80, 4, 32, 3, "TR", "winograd_tiled"),
+    (2, 48, 6, 24, 5, "TR", "winograd_tiled"), (2, 16, 5, 20, 5, "BL", "winograd_tiled"), (1, 40, 3, 16, 5, "BR", "winograd_tiled"),
+]
+
+
+@pytest.mark.parametrize("case", ONE_GROUP_GRADW_CASES, ids=lambda c: "B%d_Cq%d_%dx%d_k%d_%s_%s" % c)
+def test_winograd_weight_gradient_of_one_padded_conv(case, dev):
+    """The transposed-Winograd grad-weight kernels with G = 1 (`PaddedConv2d`, layers/conv.py:30-107), entry by entry against
+    CPU fp64 autograd through F.pad + F.conv2d times the gradient mask (layers/conv.py:98-99)."""
+    import torch.nn.functional as F
+    from fincflow_amd import PaddedConv2d, _lib
+    B, Cq, H, W, K, order, want = case
+    assert _lib.backward_variant(B, 1, Cq, H, W, K, K)["gradw"] == want
+    torch.manual_seed(sum(case[:5]))
+    m = PaddedConv2d(Cq, Cq, (K, K), order=order).to(dev)
+    x = torch.randn(B, Cq, H, W, device=dev, requires_grad=True)
+    z, _ = m(x)
+    gz = torch.randn_like(z)
+    z.backward(gz)
+    xc = x.detach().cpu().double().requires_grad_(True)
+    w = m.conv.weight.detach().cpu().double().requires_grad_(True)
+    F.conv2d(F.pad(xc, m.pad), w).backward(gz.cpu().double())
+    expect = (w.grad * m.mask.double()).numpy()
+    got = m.conv.weight.grad.cpu().numpy()
+    ew = rel_err(got, expect)
+    report("grad_w_" + want, case="B%d_Cq%d_%dx%d_k%d_%s" % case[:6], max_normalised=ew)
+    assert ew <= 2e-5, ew
+    assert np.all(got[m.mask.numpy() == 0] == 0)
+    assert rel_err(x.grad.cpu().numpy(), xc.grad.numpy()) <= TOL
