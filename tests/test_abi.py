@@ -228,3 +228,21 @@ def test_library_override_is_announced():
     assert "'env_override': False" in r.stdout and "'build_flags': 0" in r.stdout and "FINCFLOW_LIB" not in r.stderr
     r = subprocess.run([sys.executable, "-c", code], env=dict(clean, FINCFLOW_LIB=_lib.LIB_PATH), capture_output=True, text=True, check=True)
     assert "'env_override': True" in r.stdout and "FINCFLOW_LIB override" in r.stderr
+
+
+def test_grad_weight_form_is_host_side_and_follows_the_documented_rules():
+    """finc_debug_backward_variant (no launch): which grad-weight kernel a shape gets -- DESIGN 3.10's rules, spelled out: the pair
+    kernel for 3x3 banks of 13..32 channels (W % 4 == 0), the tile-pair kernel above that from 32 columns up and for 5x5 banks
+    above 12 channels from 16 columns up, the direct kernels everywhere else."""
+    from fincflow_amd import _lib
+    want = {
+        (256, 4, 24, 64, 64, 3, 3): "winograd",        # c3
+        (64, 4, 12, 32, 32, 3, 3): "staged",           # c2: below the Winograd banks
+        (64, 4, 48, 128, 128, 5, 5): "winograd_tiled", # c5
+        (8, 4, 13, 8, 4, 3, 3): "winograd", (8, 4, 32, 8, 16, 3, 3): "winograd", (8, 4, 24, 8, 18, 3, 3): "dword",
+        (8, 4, 33, 8, 32, 3, 3): "winograd_tiled", (8, 4, 33, 8, 28, 3, 3): "tiled", (8, 1, 96, 8, 64, 3, 3): "winograd_tiled",
+        (8, 4, 16, 8, 16, 5, 5): "winograd_tiled", (8, 4, 12, 8, 16, 5, 5): "staged", (8, 4, 48, 8, 12, 5, 5): "tiled",
+        (8, 4, 24, 8, 32, 2, 2): "staged", (8, 4, 4, 8, 32, 3, 5): "staged", (8, 4, 128, 8, 32, 3, 3): "direct",
+    }
+    got = {k: _lib.backward_variant(*k)["gradw"] for k in want}
+    assert got == want, {k: (got[k], want[k]) for k in want if got[k] != want[k]}
