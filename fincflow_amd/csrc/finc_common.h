@@ -131,6 +131,15 @@ size_t finc_wino_packed_bytes(int G, int Cq, int KH, int KW);          // 0: no 
 bool finc_wino_takes(const float *in, const float *out, const FincShape &s);
 int finc_wino_pack(const float *wc, void *packed, int G, int Cq, bool transpose, hipStream_t st, const float *scale, const float *shift);
 int finc_wino_launch(const float *in, const void *packed, float *out, const FincShape &s, hipStream_t st);
+bool finc_wino_disabled();                                          // FINC_NO_WINO / finc_debug_set_forward_form(1)
+int finc_wino_pack_bank(const float *wc, float *packed, int G, int Cq, int MT, int MTB, int NK, int NF, bool transpose, hipStream_t st,
+                        const float *scale, const float *shift);
+// 3x3 banks of 28 .. 64 channels: F(4,3) along W, M-split over the waves of a workgroup (finc_wino4m.hip)
+size_t finc_wino4m_packed_bytes(int G, int Cq, int KH, int KW);        // 0: no such kernel for this bank
+bool finc_wino4m_takes(const float *in, const float *out, const FincShape &s);
+int finc_wino4m_pack(const float *wc, void *packed, int G, int Cq, bool transpose, hipStream_t st, const float *scale, const float *shift);
+int finc_wino4m_launch(const float *in, const void *packed, float *out, const FincShape &s, hipStream_t st);
+unsigned finc_build_flags_wino4m();
 int finc_wino_form(const FincShape &s);                                // 2: F(2,3), 4: F(4,3) -- which of the two a call runs
 int finc_wino_set_form(int form);                                      // 0 library's choice, 1 strip kernel, 2 F(2,3), 4 F(4,3)
 unsigned finc_build_flags_wino();

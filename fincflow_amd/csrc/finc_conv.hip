@@ -631,7 +631,7 @@ size_t finc_conv_packed_bytes(int G, int Cq, int KH, int KW)
 {
     const ConvInst *i = find_conv(Cq, KH, KW);
     return i ? conv_bank_bytes(i, G) + finc_wino_packed_bytes(G, Cq, KH, KW) + finc_bigfwd_packed_bytes(G, Cq, KH, KW) +
-                   finc_wino5_packed_bytes(G, Cq, KH, KW) : 0;   // (at most one of the three exists for a bank)
+                   finc_wino5_packed_bytes(G, Cq, KH, KW) + finc_wino4m_packed_bytes(G, Cq, KH, KW) : 0;   // (at most one of the four exists for a bank)
 }
 
 int finc_conv_pack(const float *wc, void *packed, int G, int Cq, int KH, int KW, bool transpose, hipStream_t st,
@@ -651,6 +651,8 @@ int finc_conv_pack(const float *wc, void *packed, int G, int Cq, int KH, int KW,
         return finc_bigfwd_pack(wc, (char *)packed + conv_bank_bytes(i, G), G, Cq, KH, KW, transpose, st, scale, shift);
     if (finc_wino5_packed_bytes(G, Cq, KH, KW))    // (5x5: Winograd F(2,5) along W, finc_wino5.hip)
         return finc_wino5_pack(wc, (char *)packed + conv_bank_bytes(i, G), G, Cq, transpose, st, scale, shift);
+    if (finc_wino4m_packed_bytes(G, Cq, KH, KW))   // (3x3 banks of 28 .. 64 channels: F(4,3), M-split, finc_wino4m.hip)
+        return finc_wino4m_pack(wc, (char *)packed + conv_bank_bytes(i, G), G, Cq, transpose, st, scale, shift);
     return FINC_OK;
 }
 
@@ -666,6 +668,9 @@ int finc_conv_launch(const float *in, const void *packed, float *out, const Finc
     // 5x5 with 0.6 x the multiplies (Winograd F(2,5) along W: finc_wino5.hip) where the call allows it
     if (finc_wino5_packed_bytes(s.G, s.Cq, s.KH, s.KW) && finc_wino5_takes(in, out, s))
         return finc_wino5_launch(in, (const char *)packed + conv_bank_bytes(i, s.G), out, s, st);
+    // 3x3 banks of 28 .. 64 channels with half the multiplies (F(4,3), M-split over a workgroup's waves: finc_wino4m.hip)
+    if (finc_wino4m_packed_bytes(s.G, s.Cq, s.KH, s.KW) && finc_wino4m_takes(in, out, s))
+        return finc_wino4m_launch(in, (const char *)packed + conv_bank_bytes(i, s.G), out, s, st);
     const int NS = (s.W + 15) / 16;
     // about one wave per SIMD (measured: more chunks than that cost more in per-wave bank loads than they gain; 2 chunks
     // still pay up to 2 waves per SIMD), in chunks of at least 4 rows (every chunk recomputes KH-1 rows of operands)
@@ -699,6 +704,7 @@ int finc_conv_variant(int B, int G, int Cq, int H, int W, int KH, int KW, int *i
     if (finc_wino_packed_bytes(G, Cq, KH, KW) && finc_wino_takes(nullptr, nullptr, s)) info[1] = finc_wino_form(s) == 4 ? 4 : 2;   // (2: Winograd F(2,3), 4: F(4,3))
     if (finc_bigfwd_packed_bytes(G, Cq, KH, KW) && finc_bigfwd_takes(nullptr, nullptr, s)) info[1] = 3;   // (3: the big banks' M-split)
     if (finc_wino5_packed_bytes(G, Cq, KH, KW) && finc_wino5_takes(nullptr, nullptr, s)) info[1] = 5;     // (5: Winograd F(2,5), 5x5)
+    if (finc_wino4m_packed_bytes(G, Cq, KH, KW) && finc_wino4m_takes(nullptr, nullptr, s)) info[1] = 6;   // (6: Winograd F(4,3), M-split)
     return FINC_OK;
 }
 

@@ -760,6 +760,19 @@ int finc_wino_launch(const float *in, const void *packed, float *out, const Finc
 
 int finc_wino_form_override() { return g_form_override.load(std::memory_order_relaxed); }
 
+// (for finc_wino4m.hip: the same switches and the same bank, M-split)
+bool finc_wino_disabled() { return finc_no_wino(); }
+int finc_wino_pack_bank(const float *wc, float *packed, int G, int Cq, int MT, int MTB, int NK, int NF, bool transpose, hipStream_t st,
+                        const float *scale, const float *shift)
+{
+    const int total = 3 * NF * NK * MT * 64;
+    int blocks = (total + 255) / 256;
+    if (blocks > 128) blocks = 128;
+    hipLaunchKernelGGL(wino_pack_kernel, dim3(blocks, G), dim3(256), 0, st, wc, scale, shift, packed, Cq, MT, MTB, NK, NF, transpose ? 1 : 0);
+    FINC_CHECK_LAUNCH();
+    return FINC_OK;
+}
+
 int finc_wino_set_form(int form)
 {
     if (form != 0 && form != 1 && form != 2 && form != 4) return FINC_ERR_BAD_DIMS;

@@ -418,3 +418,50 @@ def test_winograd_weight_gradient_of_one_padded_conv(case, dev):
     assert ew <= 2e-5, ew
     assert np.all(got[m.mask.numpy() == 0] == 0)
     assert rel_err(x.grad.cpu().numpy(), xc.grad.numpy()) <= TOL
+
+
+# (B, C, H, W): the banks of finc_wino4m.hip (32, 48, 64 channels per group; 28, 40 and 52 padded onto them), strips of 64 columns
+# whole and three quarters full, a second strip, maps shorter than the prologue, row chunks (few strips) and none
+FORWARD_4M_CASES = [(8, 128, 12, 64), (8, 112, 9, 48), (8, 192, 20, 64), (9, 160, 3, 64), (4, 208, 17, 128), (8, 256, 24, 64),
+                    (40, 192, 8, 64), (2, 192, 40, 112)]
+
+
+@pytest.mark.parametrize("shape", FORWARD_4M_CASES, ids=lambda c: "B%d_C%d_%dx%d" % c)
+def test_3x3_forward_of_the_wide_banks_with_fewer_multiplies(shape, dev):
+    """finc_wino4m.hip: Winograd F(4,3) along W, M-split over the waves of a workgroup, for 3x3 banks of 28 .. 64 channels per group
+    (layers/conv.py:102-107 is free to run any exact reformulation) -- forward, grad-input (the same kernel on transposed
+    fragments) and the output-side affine fold against fp64 F.pad + F.conv2d autograd on the CPU, all four corner orientations;
+    the direct strip kernels (finc_debug_set_forward_form(1)) beside it on the same data."""
+    import torch.nn.functional as F
+    from fincflow_amd import FastFlowUnit, _lib
+    B, C, H, W = shape
+    torch.manual_seed(sum(shape))
+    unit = FastFlowUnit(C, C, 3).to(dev)
+    x = torch.randn(B, C, H, W, device=dev)
+    gz = torch.randn(B, C, H, W, device=dev)
+    xd = x.detach().cpu().double().requires_grad_(True)
+    ref = torch.cat([F.conv2d(F.pad(c, m.pad), m.conv.weight.detach().cpu().double()) for m, c in
+                     zip((unit.conv_tl, unit.conv_tr, unit.conv_bl, unit.conv_br), torch.chunk(xd, 4, 1))], 1)
+    ref.backward(gz.cpu().double())
+    log_scale, translation = 0.3 * torch.randn(C, device=dev), torch.randn(C, device=dev)
+    ref_aff = (ref.detach() - translation.cpu().double().view(1, -1, 1, 1)) * torch.exp(-log_scale).cpu().double().view(1, -1, 1, 1)
+    worst = {}
+    try:
+        for form, want in ((0, ("winograd4m",)), (1, ("strip", "strip16"))):
+            _lib.set_forward_form(form)
+            got_form = _lib.backward_variant(B, 4, C // 4, H, W, 3, 3)["conv_form"]
+            assert got_form in want, (form, got_form)
+            xg = x.clone().requires_grad_(True)
+            z, logdet = unit(xg)
+            z.backward(gz)
+            assert logdet == 0.0
+            with torch.no_grad():
+                fused = unit.forward_affine(x, log_scale, translation)
+            assert fused is not None
+            e = (rel_err(z.detach().cpu().numpy(), ref.detach().numpy()), rel_err(xg.grad.cpu().numpy(), xd.grad.numpy()),
+                 rel_err(fused.cpu().numpy(), ref_aff.numpy()))
+            worst[form] = max(e)
+            assert worst[form] <= TOL, (form, e)
+    finally:
+        _lib.set_forward_form(0)
+    report("forward_3x3_wide_bank_forms", shape=list(shape), f43_msplit=worst[0], strip=worst[1])
