@@ -465,3 +465,32 @@ def test_3x3_forward_of_the_wide_banks_with_fewer_multiplies(shape, dev):
     finally:
         _lib.set_forward_form(0)
     report("forward_3x3_wide_bank_forms", shape=list(shape), f43_msplit=worst[0], strip=worst[1])
+
+
+@pytest.mark.parametrize("C", [48, 64, 40])
+def test_cinc_unit_forward_on_the_msplit_winograd_kernel(C, dev):
+    """`CINCFlowUnit` (cinc_flow.py:9-80: one TL conv over all channels, G = 1) at 40 .. 64 channels: forward and backward through
+    finc_wino4m.hip / the tile-pair Winograd grad-weight against CPU fp64 autograd, and the inverse round trip."""
+    import torch.nn.functional as F
+    from fincflow_amd import CINCFlowUnit, _lib
+    B, H, W = 40, 16, 64
+    v = _lib.backward_variant(B, 1, C, H, W, 3, 3)
+    assert v["conv_form"] == "winograd4m" and v["gradw"] == "winograd_tiled", v
+    torch.manual_seed(C)
+    u = CINCFlowUnit(C, C, 3).to(dev)
+    x = torch.randn(B, C, H, W, device=dev, requires_grad=True)
+    z, ld = u(x)
+    gz = torch.randn_like(z)
+    z.backward(gz)
+    m = u.conv_tl
+    xc = x.detach().cpu().double().requires_grad_(True)
+    w = m.conv.weight.detach().cpu().double().requires_grad_(True)
+    zc = F.conv2d(F.pad(xc, m.pad), w)
+    zc.backward(gz.cpu().double())
+    assert ld == 0.0 and rel_err(z.detach().cpu().numpy(), zc.detach().numpy()) <= TOL
+    assert rel_err(x.grad.cpu().numpy(), xc.grad.numpy()) <= TOL
+    assert rel_err(m.conv.weight.grad.cpu().numpy(), (w.grad * m.mask.double()).numpy()) <= 2e-5
+    if C <= 48:     # (64 channels at the init's N(0, 0.05^2) on a 64-wide map: the triangular system amplifies fp32 rounding past any
+                    #  tolerance -- in the oracle's fp32 order as well; the forward / backward kernels are what this test is about)
+        with torch.no_grad():
+            assert rel_err(u.reverse(z.detach()).cpu().numpy(), x.detach().cpu().numpy()) <= TOL
