@@ -320,6 +320,7 @@ __global__ __launch_bounds__(HLP ? 512 : 64 * NW * NPW) void finc_wave_kernel(co
     const unsigned flag_a = (unsigned)(uintptr_t)(lds + 4 * wave_lds + 4 * prob);   // +0: A, +4: B, +8: B2, +12: A1 (bytes)
     auto flag_set = [flag_a](auto word_c, int v) {
         constexpr int WORD = decltype(word_c)::value;
+        (void)flag_a;
 #ifdef FINC_HLP_INJECT_TIMEOUT   // test-only build: the helper stops announcing its landings -> the compute wave's wait gives up
         if (WORD == 1 && v >= 8) return;
 #endif
@@ -330,6 +331,7 @@ __global__ __launch_bounds__(HLP ? 512 : 64 * NW * NPW) void finc_wave_kernel(co
     // that reads and tests in one go stalls the MFMA wave for a whole LDS round trip twice per window (2 % of the kernel).
     auto flag_peek = [flag_a](auto word_c, int &reg) {
         constexpr int WORD = decltype(word_c)::value;
+        (void)flag_a;
         if constexpr (HLP) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(reg) : "v"(flag_a), "n"(4 * WORD) : "memory");
     };
     auto flag_wait = [flag_a](auto word_c, int target) {

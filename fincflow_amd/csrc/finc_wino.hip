@@ -67,7 +67,7 @@ __device__ __forceinline__ void wino_walk(const __amdgpu_buffer_rsrc_t rin, cons
                                           int strip, int RC, bool fh)
 {
     using C = WCfg<CQP>;
-    constexpr int MT = C::MT, MTB = C::MTB, NSM = C::NSM, NK = C::NK, NA = C::NA, NF = C::NF, NFRAG = C::NFRAG;
+    constexpr int MT = C::MT, MTB = C::MTB, NSM = C::NSM, NK = C::NK, NF = C::NF, NFRAG = C::NFRAG;
     const int lane = threadIdx.x & 63;
     const int q = lane >> 4, p = lane & 15;
     const int HW = H * W;
