@@ -11,6 +11,8 @@ for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursiv
             k = "inverse_split"
         elif "finc_conv_kernel" in k:
             k = "forward"
+        elif "finc_wino4m_kernel" in k:
+            k = "forward_wino4_msplit"
         elif "finc_wino4_kernel" in k:
             k = "forward_wino4"
         elif "finc_wino_kernel" in k:
