@@ -1398,6 +1398,9 @@ static bool gradw_use_winot(const GradwInst *i, const FincShape &s)
     if (off || !i || s.W % 4 != 0 || s.W < gradw_winot_strip(s)) return false;
     if (s.KH == 5 && s.KW == 5 && s.Cq > 12 && s.Cq <= 16) return true;   // one full tile: beats the staged direct kernel too
     if (s.KH == 3 && s.KW == 3 && s.Cq > 12 && !find_gradw_wino(s)) return true;   // (only with FINC_GRADW_WINO_PAIR_MAX)
+    // 9 .. 12 channels on one (3/4 full) tile pair: from a chip's worth of strips on (C = 48, 64x64, B = 256: 193 -> 125 us; c2's 64
+    // images stay on the staged direct kernel: 26 against 30 us)
+    if (s.KH == 3 && s.KW == 3 && s.Cq > 8 && s.Cq <= 12 && (long long)s.B * ((s.W + 31) / 32) >= 256) return true;
     return gradw_use_tiled(i, s) && ((s.KH == 3 && s.KW == 3) || (s.KH == 5 && s.KW == 5));
 }
 static int gradw_wpg_winot(const FincShape &s, int mtt)

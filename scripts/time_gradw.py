@@ -8,6 +8,8 @@ dev = torch.device("cuda:0")
 shapes = ((256, 96, 64, 64, 3), (64, 96, 64, 64, 3), (256, 64, 64, 64, 3), (128, 128, 64, 64, 3), (256, 80, 32, 32, 3))
 if len(sys.argv) > 1 and sys.argv[1] == "c3":
     shapes = shapes[:1]
+elif len(sys.argv) > 1 and sys.argv[1] == "small":      # c2's bank
+    shapes = ((64, 48, 32, 32, 3), (256, 48, 32, 32, 3), (64, 48, 64, 64, 3), (256, 48, 64, 64, 3))
 elif len(sys.argv) > 1 and sys.argv[1] == "mid":        # the pair kernel's banks
     shapes = ((256, 64, 64, 64, 3), (256, 80, 64, 64, 3), (256, 96, 64, 64, 3), (128, 112, 64, 64, 3), (128, 128, 64, 64, 3))
 elif len(sys.argv) > 1 and sys.argv[1] == "big":        # the banks on one tile pair per wave

@@ -237,7 +237,8 @@ def test_grad_weight_form_is_host_side_and_follows_the_documented_rules():
     from fincflow_amd import _lib
     want = {
         (256, 4, 24, 64, 64, 3, 3): "winograd",        # c3
-        (64, 4, 12, 32, 32, 3, 3): "staged",           # c2: below the Winograd banks
+        (64, 4, 12, 32, 32, 3, 3): "staged",           # c2: too few strips for the tile-pair form
+        (256, 4, 12, 32, 32, 3, 3): "winograd_tiled", (256, 4, 8, 32, 32, 3, 3): "staged",
         (64, 4, 48, 128, 128, 5, 5): "winograd_tiled", # c5
         (8, 4, 13, 8, 4, 3, 3): "winograd", (8, 4, 32, 8, 16, 3, 3): "winograd", (8, 4, 24, 8, 18, 3, 3): "dword",
         (8, 4, 33, 8, 32, 3, 3): "winograd_tiled", (8, 4, 33, 8, 28, 3, 3): "tiled", (8, 1, 96, 8, 64, 3, 3): "winograd_tiled",

@@ -270,6 +270,8 @@ BACKWARD_CASES = [
     (2, 48, 7, 32, 5, "staged", 1),        # 5x5 at 12 channels: staged
     (2, 64, 7, 32, 5, "winograd_tiled", 1),    # 5x5 at 16 channels: one full tile pair
     (2, 48, 33, 32, 3, "staged", 1),       # c2's bank, more than one band of rows
+    (130, 48, 5, 64, 3, "winograd_tiled", 1),  # ... with a chip's worth of strips: one 3/4-full tile pair per wave
+    (260, 40, 4, 32, 3, "winograd_tiled", 1),  # 10 channels
 ]
 
 
