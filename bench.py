@@ -29,10 +29,11 @@ Extra objects on the JSON line:
                 / mean launch duration from HIP events on the launch stream, vs 8 TB/s HBM peak; `traffic`
                 = HBM bytes per launch from rocprofv3 PMC passes (profiles/traffic_*.json; a profiler pass, not
                 measured in this run) or null.
-  cpu_baseline  the reference's own Cython solver (compiled from the reference's source in the build container into
-                oracle/_ref, which travels with the snapshot) timed on this box's host cores, one thread as the reference
-                runs it, on a bounded sample of the same workload (kind "reference"); beside it the pinned CPU port
-                (oracle/finc_oracle.c), one thread and all cores.
+  cpu_baseline  the pinned CPU port of the reference's Cython solver (oracle/finc_oracle.c, bit-equal to it on the golden
+                vectors) timed on this box's host cores, one thread as the reference runs its solver, on a bounded sample of
+                the same workload (kind "port"); beside it the same solve on all cores, and -- as constants measured in the
+                build container, because the compiled reference never travels -- the reference's own rate and the
+                port / reference ratio on one core there.
 
 Self-diagnosis (round 4): every leg carries the board power read from sysfs while it ran (`power_w`), and the `clock` object
 re-runs the two inverse legs -- z = forward(x) and z ~ N(0,1) -- in both orders with a one-wave clock probe beside them
@@ -73,7 +74,7 @@ WORKLOADS = {
 }
 CONFIG_INDEX = {"c3": 2, "c2": 1, "c5": 4, "c3_share8": 2}
 # single-thread CPU sample sizes (images): about 10-20 s of host work per workload
-CPU_SAMPLE_1T = {"c3": 48, "c2": 64, "c5": 2, "c3_share8": 32}
+CPU_SAMPLE_1T = {"c3": 160, "c2": 64, "c5": 3, "c3_share8": 32}
 
 
 def parse(argv=None):
@@ -355,42 +356,14 @@ def launch_stats(per):
 # ----------------------------------------------------------------------------------------------------------------
 # CPU baseline
 # ----------------------------------------------------------------------------------------------------------------
-def reference_cpu_leg(z, x, wc, Cq, K, seconds=12.0):
-    """The REFERENCE's own CPU solver on this box: fastflow/utils/fastflow_inverse/solve_parallel_mc.pyx compiled in the build
-    container by oracle/build_ref.py (oracle/_ref/*.so travels with the snapshot like the library itself; nothing of
-    /root/reference is read here), called as FastFlowUnit.reverse_level1 calls it (fastflow.py:57-76 -> layers/conv.py:113-163):
-    one fp64 in-place solve per (image, group), single thread (setup.py:1-5 builds without OpenMP).  Bounded: images until
-    `seconds` have passed.  None when the compiled solver is not there."""
-    import numpy as np
-    try:
-        from oracle import build_ref
-        solve = build_ref.load()
-    except Exception:
-        solve = None
-    if solve is None:
-        return None
-    n = 0
-    t0 = time.perf_counter()
-    worst = 0.0
-    while n < len(z) and (n == 0 or time.perf_counter() - t0 < seconds):
-        sol = np.empty((1,) + z.shape[1:], dtype=np.float64)
-        for g in range(4):
-            zz = np.ascontiguousarray(z[n:n + 1, g * Cq:(g + 1) * Cq], dtype=np.float64)
-            solve(zz, np.ascontiguousarray(wc[g * Cq:(g + 1) * Cq], dtype=np.float64), (K, K))
-            sol[:, g * Cq:(g + 1) * Cq] = zz
-        # (group 0 is TL: canonical = image orientation, so its solution is directly comparable)
-        worst = max(worst, float(np.abs(sol[0, :Cq] - x[n, :Cq]).max() / np.abs(x[n, :Cq]).max()))
-        n += 1
-    dt = time.perf_counter() - t0
-    return {"value": n / dt, "images": n, "seconds": dt, "round_trip_rel_err_TL_group": worst}
-
-
 def cpu_baseline(workload, B, C, H, W, K, std, sample_1t):
-    """`value`: the reference's own Cython solver (oracle/_ref, compiled from the reference's source in the build container),
-    timed HERE on this box's host cores, one thread as the reference runs it -- kind "reference".  Beside it the pinned port
-    (oracle/finc_oracle.c: a restatement of solve_parallel_mc.pyx:77-126, bit-equal to that solver on the golden vectors): one
-    thread fp64, and `all_cores`: OpenMP over (image, group).  If the compiled reference is absent, `value` is the port's
-    one-thread rate and kind is "port"."""
+    """`value`: the pinned CPU port (oracle/finc_oracle.c: a restatement of solve_parallel_mc.pyx:77-126, bit-equal to the
+    reference's Cython solver on the golden vectors and, in the build container, on fresh data), timed HERE on this box's host
+    cores on ONE thread, as the reference runs its solver (setup.py:1-5 builds without OpenMP) -- kind "port".  `all_cores`: the
+    same solve with OpenMP over (image, group).  The compiled reference itself never travels to the GPU box (BASELINE.md 2,
+    SURVEY 8c): its rate is carried as a constant measured in the build container (`reference_in_build_container`,
+    scripts/measure_reference_cpu.py) with the port's rate on the same core beside it, so `port_over_reference` lets a
+    reader scale `value` to the reference's own solver."""
     import numpy as np
     from oracle import oracle
     ws = oracle.make_stored_weights(4, C // 4, K, K, std=std)
@@ -412,15 +385,7 @@ def cpu_baseline(workload, B, C, H, W, K, std, sample_1t):
     port = {"value": n1 / t_1, "unit": "images/s", "cores": 1, "kind": "port",
             "sample": f"{n1} images of the bench workload, fp64 solve (oracle/finc_oracle.c), single thread as the "
                       f"reference runs its solver"}
-    ref_leg = reference_cpu_leg(z, x, wc, C // 4, K)
-    if ref_leg is not None:
-        out = {"value": ref_leg["value"], "unit": "images/s", "cores": 1, "kind": "reference",
-               "sample": f"{ref_leg['images']} images of the bench workload ({ref_leg['seconds']:.1f} s): the reference's own "
-                         f"solve_parallel_mc.pyx (compiled in the build container into oracle/_ref), one fp64 solve per (image, group), "
-                         f"single thread as the reference runs it",
-               "round_trip_rel_err_TL_group": ref_leg["round_trip_rel_err_TL_group"], "port_1thread": port}
-    else:
-        out = dict(port)
+    out = dict(port)
     out["all_cores"] = {"value": n_all / t_all, "unit": "images/s", "cores": nthreads, "kind": "port",
                         "sample": f"{n_all} images, same solve, OpenMP over image x group"}
     path = os.path.join(REPO, "profiles", "reference_cpu_container.json")
@@ -434,6 +399,7 @@ def cpu_baseline(workload, B, C, H, W, K, std, sample_1t):
                 "port_same_host_1thread": r["port_1thread_images_per_s"],
                 "provenance": ref.get("source"), "host_cpu_count": ref.get("cpu_count"),
                 "note": "constant, not measured in this run: the compiled reference does not travel to the GPU box"}
+            out["port_over_reference"] = r["port_1thread_images_per_s"] / r["reference_images_per_s"]
     return out
 
 

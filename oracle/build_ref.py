@@ -10,8 +10,9 @@ the image's Cython -- the same step the reference's setup.py performs
 (fastflow/utils/fastflow_inverse/setup.py:1-5), plus the numpy include dir the
 reference omits.
 
-When /root/reference is absent (the GPU box) this is a no-op: the prebuilt
-.so travels with the snapshot.
+When /root/reference is absent (the GPU box) this is a no-op, and load()
+returns None there: oracle/_ref/ is excluded from the gpurun snapshot
+(.gpurunignore) -- the compiled reference runs in the build container only.
 """
 import os
 import subprocess

@@ -189,3 +189,22 @@ def test_config5_init_std_is_unstable_in_the_reference_arithmetic():
         xr = oracle.inverse_via_f64(zz, wc, 1, 0)
         err[std] = float(np.abs(xr - x).max() / np.abs(x).max())
     assert err[0.05] > 1e-3 and err[0.02] < 1e-5, err
+
+
+def test_the_compiled_reference_never_travels_to_the_gpu_box():
+    """BASELINE.md 2 / SURVEY 8c: the reference runs only in the build container.  oracle/_ref/ (the reference's .pyx, cythonised
+    and compiled by oracle/build_ref.py) must stay excluded from the gpurun snapshot AND from history, and nothing that runs on
+    the GPU box may load it: bench.py's cpu_baseline is the pinned port (kind "port")."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ignore = [l.strip() for l in open(os.path.join(root, ".gpurunignore")) if l.strip() and not l.startswith("#")]
+    assert "oracle/_ref/" in ignore or "oracle/_ref" in ignore, ignore
+    assert not any(l.startswith("oracle/_ref/") and l != "oracle/_ref/" for l in ignore), ignore   # (no narrower pattern instead)
+    git_ignore = [l.strip() for l in open(os.path.join(root, ".gitignore"))]
+    assert "oracle/_ref/" in git_ignore
+    bench = open(os.path.join(root, "bench.py")).read()
+    assert "build_ref" not in bench and not re.search(r"kind\W+reference\W+sample", bench)
+    for name in ("__init__.py", "_lib.py", "ops.py", "layers.py", "glow.py", "dist.py"):
+        src = open(os.path.join(root, "fincflow_amd", name)).read()
+        assert "oracle" not in src, name
