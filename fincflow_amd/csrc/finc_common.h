@@ -117,6 +117,13 @@ int finc_split_prepare(hipStream_t st);          // allocates the band split's p
 int finc_split_timeouts_count(unsigned *count);  // progress waits of the band split that gave up (must be 0)
 unsigned *finc_fault_device_word();              // device pointer to the current device's (armed) fault word, or nullptr
 int finc_split_launch(const float *in, const void *packed, float *out, const FincShape &s, hipStream_t st);
+// finc_chain.hip: the short-step form of the same idea for the banks of up to 16 channels (output channels, not taps, shared out
+// over the preparing waves); finc_split_launch / finc_split_info hand over to it
+bool finc_chain_takes(const FincShape &s);        // (can run it; finc_split_uses_chain: does run it)
+bool finc_split_uses_chain(const FincShape &s);
+int finc_chain_info(const FincShape &s, int *waves, int *lds_bytes, int *steps);
+int finc_chain_launch(const float *in, const void *packed, float *out, const FincShape &s, hipStream_t st);
+unsigned finc_build_flags_chain();
 
 // ---- forward / grad-input, MFMA strip kernel: finc_conv.hip ----
 bool finc_conv_supported(int Cq, int H, int W, int KH, int KW);

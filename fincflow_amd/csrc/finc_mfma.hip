@@ -1731,7 +1731,7 @@ int finc_mfma_variant(int B, int G, int Cq, int H, int W, int KH, int KW, int *i
     if (finc_split_takes(fs)) {                // form 4: the role-split kernel, info[5] / (B*G) workgroups of info[1] waves per problem
         int waves = 0, lds = 0, steps = 0, nwg = 1;
         if (int e = finc_split_info(fs, &waves, &lds, &steps, &nwg)) return e;
-        info[0] = i->cqp; info[1] = waves; info[2] = 1; info[3] = 4; info[4] = lds; info[5] = B * G * nwg;
+        info[0] = i->cqp; info[1] = waves; info[2] = 1; info[3] = finc_split_uses_chain(fs) ? 6 : 4; info[4] = lds; info[5] = B * G * nwg;   // (6: its short-step form for the small banks, finc_chain.hip)
         info[6] = -1; info[7] = (int)(sizeof(g_insts) / sizeof(g_insts[0]));
         return FINC_OK;
     }

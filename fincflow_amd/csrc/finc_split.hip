@@ -844,9 +844,22 @@ int finc_split_timeouts_count(unsigned *count)
 extern "C" int finc_debug_split_stamps(unsigned long long *h) { return (int)hipMemcpyFromSymbol(h, HIP_SYMBOL(finc_split_stamps), sizeof(finc_split_stamps)); }
 #endif
 
+// the short-step form (finc_chain.hip) runs the banks of up to 16 channels -- except where this kernel would deal the bands of a
+// 16-channel problem out to two workgroups: there the band split is the faster one (C = 64, 64x64: 85 against 90 us; 128x64: 141
+// against 168; profiles/r05/notes/chain_vs_split.txt), while the 12-channel banks win on one workgroup (64x64: 76 against 80 us)
+bool finc_split_uses_chain(const FincShape &s)
+{
+    if (!finc_chain_takes(s)) return false;
+    const SInst *i = find_sinst(s.Cq, s.KH, s.KW);
+    const int P = s.W < 16 ? s.W : 16;
+    if (i && i->cqp == 16 && fifo_fits(*i, s.W, P) && bsp_nwg(*i, s) > 1) return false;
+    return true;
+}
+
 bool finc_split_takes(const FincShape &s)
 {
     if ((long long)s.B * s.G > split_max_problems()) return false;
+    if (finc_split_uses_chain(s)) return true;                             // (the small banks' short-step form: no FIFO-width limit)
     const SInst *i = find_sinst(s.Cq, s.KH, s.KW);
     if (!i || s.H < 1 || s.W < 1) return false;
     const int P = s.W < 16 ? s.W : 16;
@@ -858,6 +871,10 @@ bool finc_split_takes(const FincShape &s)
 
 int finc_split_info(const FincShape &s, int *waves, int *lds, int *steps, int *nwg)
 {
+    if (finc_split_uses_chain(s)) {
+        if (nwg) *nwg = 1;
+        return finc_chain_info(s, waves, lds, steps);
+    }
     const SInst *i = find_sinst(s.Cq, s.KH, s.KW);
     if (!i) return FINC_ERR_UNSUPPORTED;
     const int P = s.W < 16 ? s.W : 16;
@@ -872,6 +889,7 @@ int finc_split_info(const FincShape &s, int *waves, int *lds, int *steps, int *n
 
 int finc_split_launch(const float *in, const void *packed, float *out, const FincShape &s, hipStream_t st)
 {
+    if (finc_split_uses_chain(s)) return finc_chain_launch(in, packed, out, s, st);   // the small banks' short-step form (finc_chain.hip)
     const SInst *i = find_sinst(s.Cq, s.KH, s.KW);
     if (!i) return FINC_ERR_UNSUPPORTED;
     const int P = s.W < 16 ? s.W : 16;

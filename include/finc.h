@@ -228,6 +228,8 @@ int finc_mix_f32(const float *in, const float *mat, const float *bias, float *ou
  *   helper waves (8-wave workgroups of 4 problems) / 2 = 64-byte sector pairing / 1 = 32-byte pieces / 0 = 16-byte
  *   groups, LDS bytes per workgroup, workgroups, row of the instantiation table, rows in the table}.
  *   info[3] = 4: the role-split kernel (problem sets that do not outnumber the compute units; row = -1);
+ *   info[3] = 6: its short-step form for the banks of up to 16 channels (finc_chain.hip: one wave carries the recurrence on a
+ *     16-row tile, one wave per tap with a + b == 2 prepares the rest, one wave owns the HBM side; row = -1);
  *   info[3] = 5: the big-bank kernel (3x3 banks with 64 < Cq <= 96, 8 waves per problem; row = -2).
  *   FINC_ERR_UNSUPPORTED when the shape runs on the strict kernel.
  * finc_debug_attr_table_insert: the (device, kernel) table behind the once-per-device kernel attributes; returns 1 if

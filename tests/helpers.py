@@ -109,9 +109,27 @@ SPLIT_MAX_PROBLEMS = 256      # finc_split.hip split_max_problems()
 SPLIT_BANKS = {(3, 3): (4, 8, 12, 16, 20, 24, 28, 32), (2, 2): (4, 8, 12, 16, 24, 32)}
 
 
+def chain_takes(cqp, kh, kw, problems, H, W):
+    """Mirror of finc_chain.hip finc_chain_takes (inside finc_split_takes): the short-step form of the role-split kernel takes the
+    2x2 / 3x3 banks of up to 16 channels on any map whose width is a multiple of 4 (its hand-over FIFO is 128 bytes per step)."""
+    if problems > SPLIT_MAX_PROBLEMS or cqp > 16 or cqp not in SPLIT_BANKS.get((kh, kw), ()) or H < 1 or W < 4 or W % 4:
+        return False
+    P = min(16, W)
+    nbw = sum(1 for a in range(kh) for b in range(kw) if a + b == 2)
+    fixed = 8 * (64 + 8 + 1 + 8) * 16 + 2 * nbw * 1024 + (cqp // 4) * 8 * 1024
+    if not (P >= kh - 1 and fixed + 2 * (W - P + 2) * 128 <= 160 * 1024):
+        return False
+    # (finc_split_uses_chain: a 16-channel problem whose bands the role-split kernel would deal out to two workgroups stays there)
+    band_split = 2 * problems <= 256 and H > 16 and W >= 64 and kh > 1 and (W - P + kh + kw - 2) * 4 * (kh - 1) * 4 <= 2048 - 4
+    return not (cqp == 16 and band_split)
+
+
 def split_takes(cqp, kh, kw, problems, H, W):
     """Mirror of finc_split.hip finc_split_takes: the role-split kernel runs the problem sets that do not outnumber the
-    compute units, for the 2x2 / 3x3 banks one wave holds, on maps whose hand-over FIFO fits its 2 KB per k-step."""
+    compute units, for the 2x2 / 3x3 banks one wave holds, on maps whose hand-over FIFO fits its 2 KB per k-step (the banks of
+    up to 16 channels, on the short-step form: any width)."""
+    if chain_takes(cqp, kh, kw, problems, H, W):
+        return True
     if problems > SPLIT_MAX_PROBLEMS or cqp not in SPLIT_BANKS.get((kh, kw), ()) or H < 1 or W < 4 or W % 4:
         return False
     P = min(16, W)

@@ -129,18 +129,25 @@ def test_variant_plan_covers_every_row_and_agrees_with_the_library():
 
 def test_role_split_kernel_takes_the_under_filled_chip():
     """finc_split.hip: problem sets that do not outnumber the compute units (c2; c3 at the per-GPU batch of a 4- or 8-way
-    split; the c4 units) run on the role-split kernel -- form 4, one workgroup of four waves per problem; everything else
-    stays with the wavefront kernel's table (host-only calls)."""
-    from helpers import split_takes
+    split; the c4 units) run on the role-split kernel -- form 4, one workgroup of four waves per problem; the banks of up to 16
+    channels on its short-step form (finc_chain.hip, form 6: the recurrence wave, one wave per tap with a + b == 2, the I/O
+    wave); everything else stays with the wavefront kernel's table (host-only calls)."""
+    from helpers import split_takes, chain_takes
     for (B, G, Cq, H, W, K), want in (((64, 4, 12, 32, 32, 3), True), ((32, 4, 24, 64, 64, 3), True), ((64, 4, 24, 64, 64, 3), True),
                                       ((65, 4, 24, 64, 64, 3), False), ((128, 4, 3, 16, 16, 3), False), ((64, 4, 3, 16, 16, 3), True),
                                       ((16, 4, 12, 4, 4, 3), True), ((1, 1, 23, 40, 36, 3), True), ((8, 4, 24, 8, 80, 3), False),
-                                      ((8, 4, 16, 30, 44, 2), True), ((8, 4, 16, 32, 32, 5), False), ((8, 4, 40, 32, 32, 3), False)):
+                                      ((8, 4, 16, 30, 44, 2), True), ((8, 4, 16, 32, 32, 5), False), ((8, 4, 40, 32, 32, 3), False),
+                                      ((8, 4, 12, 8, 80, 3), True), ((2, 4, 16, 16, 256, 3), True), ((8, 4, 20, 8, 80, 3), False)):
         v = _lib.inverse_variant(B, G, Cq, H, W, K, K)
         assert v is not None, (B, G, Cq, H, W, K)
-        assert (v["sec"] == 4) == want, (B, G, Cq, H, W, K, v)
+        assert (v["sec"] in (4, 6)) == want, (B, G, Cq, H, W, K, v)
         assert split_takes(v["cqp"], K, K, B * G, H, W) == want
-        if want:
+        chain = chain_takes(v["cqp"], K, K, B * G, H, W)
+        assert (v["sec"] == 6) == chain, (B, G, Cq, H, W, K, v)
+        if chain:
+            assert v["cqp"] <= 16 and v["nw"] == (5 if K == 3 else 3) and v["workgroups"] == B * G and v["row"] == -1, v
+            assert v["lds_bytes"] <= 64 * 1024 + 2 * (W - min(16, W) + 2) * 128, v
+        elif want:
             # (round 4: with compute units to spare -- 2 B G <= 256 -- on a map of >= 2 bands and >= 64 columns the bands of a
             # problem are dealt out to two workgroups)
             per = 2 if (2 * B * G <= 256 and H > 16 and W >= 64 and K > 1) else 1

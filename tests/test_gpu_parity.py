@@ -910,7 +910,7 @@ def test_unaligned_activations_fall_back(dev):
     L = _lib.lib()
     for B, split in ((80, False), (2, True)):
         C, H, W, K = 16, 8, 8, 3
-        assert (_lib.inverse_variant(B, 4, C // 4, H, W, K, K)["sec"] == 4) == split
+        assert (_lib.inverse_variant(B, 4, C // 4, H, W, K, K)["sec"] in (4, 6)) == split
         ws = oracle.make_stored_weights(4, C // 4, K, K, seed=5)
         wco = oracle.canonicalize(ws, 4, ORIENT_FASTFLOW)
         wc = canon(ws, 4, ORIENT_FASTFLOW, dev)

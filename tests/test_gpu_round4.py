@@ -202,11 +202,12 @@ def test_fault_gate_is_consulted_by_every_launching_entry_point(dev):
 
 # (B, C, H, W, K): problem sets the band split takes (2 * B * 4 workgroups <= compute units, >= 2 bands, W >= 64): 2 .. 8 bands,
 # partial last bands, an odd number of bands, a padded bank (Cq = 22), 2x2 taps, widths beyond 64
-BAND_SPLIT_CASES = [(32, 96, 64, 64, 3), (4, 96, 64, 64, 3), (3, 96, 48, 64, 3), (2, 96, 33, 64, 3), (8, 48, 17, 72, 3),
+# (round 5: the banks of up to 12 channels left the band split for the short-step kernel, finc_chain.hip -- C = 48 became C = 80)
+BAND_SPLIT_CASES = [(32, 96, 64, 64, 3), (4, 96, 64, 64, 3), (3, 96, 48, 64, 3), (2, 96, 33, 64, 3), (8, 80, 17, 72, 3),
                     (1, 128, 40, 72, 3), (7, 88, 31, 64, 3), (5, 64, 128, 64, 3), (6, 64, 50, 64, 2),
                     # W = 68: 17 store windows per row -- the producer's loop ends before the stores of its last window are said
                     # complete (scripts/stress_bands.py found the consumer of a workgroup's last band waiting for them forever)
-                    (3, 48, 26, 68, 3), (5, 64, 85, 68, 2), (18, 96, 82, 68, 3)]
+                    (3, 80, 26, 68, 3), (5, 64, 85, 68, 2), (18, 96, 82, 68, 3)]
 
 
 @pytest.mark.parametrize("shape", BAND_SPLIT_CASES, ids=lambda c: "B%d_C%d_%dx%d_k%d" % c)

@@ -1,0 +1,123 @@
+"""Round 5: the short-step inverse of the small banks (finc_chain.hip) -- every bank, every hand-over form, the widths the
+role-split kernel could not take -- through the C ABI against the oracle; the band split under contention and on two streams.
+
+Recurrence under test: cinc_cuda_kernel_level2.cu:59-72; visitation: cinc_cuda_kernel_level2.cu:49-56,98-111.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle
+from helpers import ORIENT_FASTFLOW, rel_err
+from test_gpu_variants import bank_std, run_inverse_case
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    from fincflow_amd import _lib
+    _lib.lib()
+    return torch.device("cuda:0")
+
+
+def t(a, dev):
+    return torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+
+# (B, G, Cq, H, W, KH, KW).  The bench shapes (c2, the c4 units); every bank (4, 8, 12, 16 channels; padded counts 1, 3, 6, 7, 11, 13,
+# 15) at 3x3 and 2x2; W == P (the recurrence wave writes the rows above the next band itself: 4, 8, 12, 16 columns) and W > P (the I/O
+# wave copies them from the FIFO: 20 .. 256 columns, beyond the 72 the role-split kernel's FIFO block holds); one band, partial last
+# bands, many bands; a single row; G = 1, 2, 3 (orientation codes other than FastFlow's); 256 problems (one per compute unit)
+CHAIN_CASES = [
+    (64, 4, 12, 32, 32, 3, 3), (32, 4, 3, 16, 16, 3, 3), (16, 4, 6, 8, 8, 3, 3), (8, 4, 12, 4, 4, 3, 3),
+    (2, 4, 4, 33, 20, 3, 3), (3, 4, 8, 17, 24, 3, 3), (2, 4, 16, 40, 36, 3, 3), (2, 4, 1, 9, 12, 3, 3), (5, 1, 7, 50, 16, 3, 3),
+    (2, 2, 11, 5, 44, 3, 3), (1, 3, 13, 21, 28, 3, 3), (2, 4, 15, 1, 32, 3, 3), (3, 4, 12, 100, 8, 3, 3), (2, 4, 10, 7, 4, 3, 3),
+    (1, 4, 12, 24, 128, 3, 3), (1, 2, 16, 18, 256, 3, 3), (2, 4, 8, 35, 80, 3, 3), (4, 4, 12, 64, 64, 3, 3), (1, 4, 5, 130, 12, 3, 3),
+    (4, 4, 2, 6, 8, 2, 2), (2, 4, 8, 23, 32, 2, 2), (3, 1, 12, 16, 16, 2, 2), (2, 4, 15, 37, 20, 2, 2), (1, 4, 16, 12, 96, 2, 2),
+    (64, 4, 16, 16, 16, 3, 3),
+]
+
+
+@pytest.mark.parametrize("case", CHAIN_CASES, ids=lambda c: "B%d_G%d_Cq%d_%dx%d_k%dx%d" % c)
+def test_short_step_kernel(case, dev):
+    """finc_chain.hip against the oracle's fp64 path (<= 1e-5 of the largest entry), the strict kernel bit-exact beside it, repeated
+    launches bit-identical, and the library says which kernel it was (form 6: the recurrence wave, one wave per tap with
+    a + b == 2, the I/O wave)."""
+    from fincflow_amd import _lib, ops
+    B, G, Cq, H, W, KH, KW = case
+    orient = ORIENT_FASTFLOW if G == 4 else (0x1B & ((1 << (2 * G)) - 1))
+    v = _lib.inverse_variant(B, G, Cq, H, W, KH, KW)
+    assert v is not None and v["sec"] == 6 and v["nw"] == (5 if KH == 3 else 3) and v["workgroups"] == B * G and v["row"] == -1, v
+    e_max, _ = run_inverse_case(dev, B, G, orient, Cq, H, W, KH, KW, seed=17 * Cq + H + W, tag="short_step")
+    assert e_max <= TOL
+    rng = np.random.default_rng(5)
+    ws = oracle.make_stored_weights(G, Cq, KH, KW, orient=orient, seed=4, std=bank_std(Cq, max(KH, KW)))
+    wc = ops.canonicalize(t(ws, dev), G, orient)
+    z = t(rng.standard_normal((B, G * Cq, H, W)).astype(np.float32), dev)
+    first = ops.finc_inverse(z, wc, G, orient)
+    for _ in range(10):
+        assert torch.equal(ops.finc_inverse(z, wc, G, orient), first)
+    assert _lib.hlp_timeouts() == 0 and not _lib.fault_pending()
+
+
+def test_short_step_kernel_on_sampling_input_and_in_a_graph(dev):
+    """z ~ N(0,1) (the sampling distribution, train/losses.py:42-45) through the module at c2's shape, eager and replayed from a
+    captured graph; a folded affine map (scale and shift: the shift enters masked, B wave 0) against the two-launch form."""
+    from fincflow_amd import FastFlowUnit, _lib, glow
+    B, C, H, W = 64, 48, 32, 32
+    assert _lib.inverse_variant(B, 4, C // 4, H, W, 3, 3)["sec"] == 6
+    torch.manual_seed(11)
+    unit = FastFlowUnit(C, C, 3).to(dev)
+    an = glow.ActNorm(C).to(dev)
+    with torch.no_grad():
+        an.log_scale.copy_(0.2 * torch.randn(C, device=dev))
+        an.translation.copy_(torch.randn(C, device=dev))
+        an.initialized.fill_(1)
+    y = torch.randn(B, C, H, W, device=dev)
+    with torch.no_grad():
+        ref = unit.reverse(y)
+        ws = torch.cat(unit._weights()).detach().cpu().numpy()
+        wco = oracle.canonicalize(ws, 4, ORIENT_FASTFLOW)
+        want = oracle.inverse_via_f64(y[:4].cpu().numpy(), wco, 4, ORIENT_FASTFLOW, nthreads=8)
+        assert rel_err(ref[:4].cpu().numpy(), want) <= TOL
+        two = unit.reverse(an.reverse(y))
+        fused = unit.reverse_affine(y, an.log_scale, an.translation)
+        assert fused is not None and rel_err(fused.cpu().numpy(), two.cpu().numpy()) <= TOL
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = unit.reverse(y)
+        for _ in range(5):
+            out.zero_()
+            g.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(out, ref)
+    assert _lib.hlp_timeouts() == 0 and not _lib.fault_pending()
+
+
+def test_short_step_kernel_on_a_dword_aligned_view(dev):
+    """Activations that are 4-byte but not 16-byte aligned (a view one float into a buffer): the kernel's 16-byte pieces -- LDS-DMA
+    requests and stores -- are buffer accesses, which need dword alignment only (as on the role-split kernel)."""
+    from fincflow_amd import _lib, ops
+    B, G, Cq, H, W, K = 3, 4, 12, 20, 24, 3
+    assert _lib.inverse_variant(B, G, Cq, H, W, K, K)["sec"] == 6
+    ws = oracle.make_stored_weights(G, Cq, K, K, seed=5)
+    wco = oracle.canonicalize(ws, G, ORIENT_FASTFLOW)
+    wc = ops.canonicalize(t(ws, dev), G, ORIENT_FASTFLOW)
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((B, G * Cq, H, W)).astype(np.float32)
+    z = oracle.forward_f32(x, wco, G, ORIENT_FASTFLOW)
+    n = z.size
+    buf_in = torch.zeros(n + 1, device=dev)
+    buf_out = torch.zeros(n + 1, device=dev)
+    zin = buf_in[1:].view(B, G * Cq, H, W)
+    zin.copy_(t(z, dev))
+    out = buf_out[1:].view(B, G * Cq, H, W)
+    assert zin.data_ptr() % 16 == 4 and out.data_ptr() % 16 == 4
+    ops.finc_inverse(zin, wc, G, ORIENT_FASTFLOW, out=out)
+    want = oracle.inverse_via_f64(z, wco, G, ORIENT_FASTFLOW)
+    assert rel_err(out.cpu().numpy(), want) <= TOL
