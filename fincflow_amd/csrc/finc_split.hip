@@ -44,7 +44,6 @@
 
 #include <stdlib.h>
 
-#include <atomic>
 #include <mutex>
 
 #include <type_traits>
@@ -151,14 +150,24 @@ __global__ __launch_bounds__(64 * (1 + NBW)) void finc_split_kernel(const float 
     const int role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // 0: A, 1..NBW: B
     const int lane = threadIdx.x & 63;
     const int q = lane >> 4, p = lane & 15;
-    // BSP: workgroup `wg` of the problem owns the bands wg, wg + nwg, ...; band-major block order, so that a band's producer is
-    // dispatched no later than its consumer
-    const int wg = BSP ? __builtin_amdgcn_readfirstlane((int)blockIdx.x / nprob) : 0;
-    const int bg = BSP ? (int)blockIdx.x - wg * nprob : (int)blockIdx.x, g = bg % G;
+    // BSP (round 5): a problem's bands are separate jobs, one band each (nwg = the number of bands), handed out by a TICKET counter,
+    // band-major; a workgroup draws a ticket, solves that band, draws again.  The producer of a band -- the band above, an earlier
+    // ticket -- is therefore running or done whenever a consumer exists, whatever order and placement the dispatcher chose and
+    // however few workgroups are resident: a workgroup only ever waits for one that makes progress.  The
+    // launch's words (ticket and done counters included) start at zero: the previous launch on the slot left them so.
+    for (;;) {
+    int slot_id = (int)blockIdx.x;
+    if constexpr (BSP) {
+        if (threadIdx.x == 0) lds[0] = __builtin_bit_cast(float, __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        __syncthreads();
+        slot_id = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, lds[0]));
+        __syncthreads();
+        if (slot_id >= nwg * nprob) break;     // no band left
+    }
+    const int wg = BSP ? slot_id / nprob : 0;
+    const int bg = BSP ? slot_id - wg * nprob : slot_id, g = bg % G;
     const int band_rows = BSP ? nwg * P : P;   // rows from a band of this workgroup to its next one
     const int row0 = BSP ? wg * P : 0;         // first row of its first band
-    unsigned epoch = 0;
-    if constexpr (BSP) epoch = __builtin_amdgcn_readfirstlane(__hip_atomic_load(sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & 0xFFFu;
     const unsigned o = finc_group_orient(orient, g);
     const bool fh = (o & FINC_FLIP_H) != 0, fw = (o & FINC_FLIP_W) != 0;
     const int HW = H * W;
@@ -313,17 +322,7 @@ __global__ __launch_bounds__(64 * (1 + NBW)) void finc_split_kernel(const float 
 #else
         (void)st_busy;
 #endif
-        if constexpr (BSP) {                   // the last workgroup to finish retires the epoch: every progress word of this launch is void
-            if (lane == 0) {
-                const unsigned done = __hip_atomic_fetch_add(sync + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (done == gridDim.x - 1) {
-                    __hip_atomic_store(sync + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(sync, (epoch + 1) & 0xFFFu, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-                }
-            }
-        }
-        return;
-    }
+    } else {
 
     // =================================== B: everything that can be prepared ===================================
     // One copy of the code per B wave (`bi` is a compile-time constant inside): a step must not contain role branches.
@@ -487,7 +486,7 @@ __global__ __launch_bounds__(64 * (1 + NBW)) void finc_split_kernel(const float 
     auto progress_take = [&]() {
         asm volatile("" : "+v"(seen_raw));
         const unsigned val = __builtin_amdgcn_readfirstlane(seen_raw);
-        if ((val >> 20) == epoch && (int)(val & 0xFFFFFu) > seen) seen = (int)(val & 0xFFFFFu);
+        if ((int)val > seen) seen = (int)val;
     };
     auto progress_wait = [&](int need) {
         if (seen >= need) return;
@@ -496,8 +495,7 @@ __global__ __launch_bounds__(64 * (1 + NBW)) void finc_split_kernel(const float 
         for (; budget > 0; --budget) {
             unsigned v;
             asm volatile("buffer_load_dword %0, %1, %2, 0 offen sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(its_flag), "s"(rsync) : "memory");
-            const unsigned val = __builtin_amdgcn_readfirstlane(v);
-            if ((val >> 20) == epoch) seen = (int)(val & 0xFFFFFu);
+            seen = (int)__builtin_amdgcn_readfirstlane(v);
             if (seen >= need) break;
             __builtin_amdgcn_s_sleep(8);
         }
@@ -508,7 +506,7 @@ __global__ __launch_bounds__(64 * (1 + NBW)) void finc_split_kernel(const float 
     };
     auto publish = [&](int windows_done) {
         if (lane == 0) {
-            const unsigned v = (epoch << 20) | (unsigned)windows_done;
+            const unsigned v = (unsigned)windows_done;
             asm volatile("buffer_store_dword %0, %1, %2, 0 offen sc0 sc1" ::"v"(v), "v"(my_flag), "s"(rsync) : "memory");
         }
     };
@@ -707,8 +705,9 @@ __global__ __launch_bounds__(64 * (1 + NBW)) void finc_split_kernel(const float 
         // the stores of the last windows are not yet accounted for in the progress word (a window's stores are said complete two
         // windows later, and the loop ends with them): the consumer of this workgroup's LAST band waits for exactly those
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        publish(0xFFFFF);
+        publish(0x7FFFFFFF);
     }
+    if constexpr (BSP) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (its last word is out before the workgroup moves on or says "done")
 #ifdef FINC_SPLIT_STAMP
     if (blockIdx.x == 0 && lane == 0) finc_split_stamps[1 + bi] = st_busy;
 #else
@@ -720,6 +719,32 @@ __global__ __launch_bounds__(64 * (1 + NBW)) void finc_split_kernel(const float 
              if (role - 1 == BI) run_b(IC<BI>{});
          }()), ...);
     }(std::make_integer_sequence<int, NBW>{});
+    }   // role
+    if constexpr (!BSP) break;
+    __syncthreads();                           // (every wave is done with the LDS -- and the B waves with their last words -- before the next band)
+    }   // for (;;)
+    if constexpr (BSP) {
+        if (role == 0) {
+            // The launch leaves its words as it found them: zero.  Every workgroup counts itself done when it finds no band left (all
+            // its waves are then past their last access to the words: the barrier above; the B waves drained their stores in front of
+            // it); the last one to do so -- every band is then solved and every word final -- zeroes the words of the launch, ticket
+            // and done counters last.  So the next launch on this slot, or the next replay of a captured one, starts clean without a
+            // memset in front of it (a captured hipMemsetAsync node did not reset the words on replays: ROCm 7.2,
+            // scripts/debug_graph_bands.py).
+            unsigned done = 0;
+            if (lane == 0) done = __hip_atomic_fetch_add(sync + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+            done = __builtin_amdgcn_readfirstlane(done);
+            if (done == gridDim.x - 1) {
+                const int nwords = 2 + nprob * nwg * NBW;
+                for (int i = 2 + lane; i < nwords; i += 64) __hip_atomic_store(sync + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+                if (lane == 0) {
+                    __hip_atomic_store(sync + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(sync, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+    }
 }
 
 // -----------------------------------------------------------------------------------------------
@@ -770,14 +795,31 @@ long long split_max_problems()
     return v;
 }
 
-// ---- BSP: where the progress words live.  One area per device, SLOTS slots of SLOT_WORDS words: [0] epoch, [1] workgroups
-// finished, [2 ..] one word per (problem, workgroup of the problem, B wave).  A launch takes the next slot (round-robin), so two
-// launches in flight on different streams do not share words.  Allocated (and zeroed, synchronously) outside any stream
-// capture: by the packing calls, or by the first launch that finds no capture going on; until then the chained form runs.
-constexpr int BSP_SLOTS = 32, BSP_SLOT_WORDS = 2048, BSP_MAX_NWG = 2;
+// ---- BSP: where the progress words live.  One area per device, BSP_SLOTS + BSP_GRAPH_SLOTS slots of BSP_SLOT_WORDS words: [0] the
+// ticket counter, [1] workgroups done, [2 ..] one word per (problem, band, B wave) = the number of that wave's store windows that are
+// complete.  A launch finds its words zero and leaves them zero (its last workgroup to finish clears them), so nothing of an earlier
+// launch or replay can be taken for progress.  Launches that may EXECUTE at the same time must not share a slot: a slot
+// belongs to a STREAM -- launches of one stream run one after the other -- for as long as that stream keeps launching; a stream
+// that is new to a full table takes over the least recently used slot whose last launch has completed (an event per slot says so),
+// or runs the chained form.  A launch inside a stream capture takes a slot of its own from a second pool and keeps it for good (a
+// replay runs on whatever stream the graph is launched on; replays of one executable graph are ordered among themselves -- two
+// executable graphs instantiated from ONE capture must not run concurrently); the BSP_GRAPH_SLOTS + 1st captured band-split launch of
+// a process runs the chained form, and so does hipStreamPerThread (one handle, many streams).
+constexpr int BSP_SLOTS = 24, BSP_GRAPH_SLOTS = 8, BSP_SLOT_WORDS = 8192;
 constexpr int BSP_MAX_DEV = 64;
-unsigned *g_bsp_area[BSP_MAX_DEV];
-std::atomic<unsigned> g_bsp_next{0};
+struct BspSlot {
+    hipStream_t stream = nullptr;
+    hipEvent_t done = nullptr;                 // recorded behind the slot's last launch
+    bool used = false;
+    unsigned long long last_use = 0;
+};
+struct BspDevice {
+    unsigned *area = nullptr;                  // (BSP_SLOTS + BSP_GRAPH_SLOTS) * BSP_SLOT_WORDS words
+    BspSlot slots[BSP_SLOTS];
+    unsigned long long clock = 0;
+    int graph_next = 0;
+};
+BspDevice g_bsp[BSP_MAX_DEV];
 std::mutex g_bsp_mutex;
 
 int device_cus()
@@ -800,17 +842,17 @@ bool bsp_off()
     return off;
 }
 
-// workgroups per problem the band split would use for this problem set (1: the chained form)
+// workgroups per problem the band split would use for this problem set (1: the chained form): one per band (round 5; each waits
+// for the one above only, in ticket order -- no map is too narrow to complete, but below ~48 columns the hand-over lag of ~44 steps
+// per band exceeds what chaining costs)
 int bsp_nwg(const SInst &i, const FincShape &s)
 {
     const int P = s.W < 16 ? s.W : 16;
     const int NB = (s.H + P - 1) / P;
     const long long problems = (long long)s.B * s.G;
-    // W >= 64: band k + 2 starts W steps after band k on the same workgroup, and by then band k + 1 -- two hand-over lags behind
-    // band k -- must have delivered its first pieces (narrower maps: the two workgroups would wait for each other)
     if (bsp_off() || i.kh < 2 || NB < 2 || s.W < 64 || 2 * problems > device_cus()) return 1;
-    if (2 + problems * BSP_MAX_NWG * i.nbw > BSP_SLOT_WORDS) return 1;
-    return 2;       // (more workgroups per problem do not shorten the chain: every band boundary costs the same hand-over lag)
+    if (2 + problems * NB * i.nbw > BSP_SLOT_WORDS) return 1;
+    return NB;
 }
 
 } // namespace
@@ -820,18 +862,72 @@ int finc_split_prepare(hipStream_t st)
     int dev = 0;
     FINC_HIP_TRY(hipGetDevice(&dev));
     if (dev < 0 || dev >= BSP_MAX_DEV) return FINC_ERR_BAD_DIMS;
-    if (g_bsp_area[dev]) return FINC_OK;
+    if (g_bsp[dev].area) return FINC_OK;
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
     if (cs != hipStreamCaptureStatusNone) return FINC_OK;     // (not now: the launches of this capture run the chained form)
     std::lock_guard<std::mutex> lk(g_bsp_mutex);
-    if (g_bsp_area[dev]) return FINC_OK;
+    if (g_bsp[dev].area) return FINC_OK;
     unsigned *a = nullptr;
-    const size_t bytes = sizeof(unsigned) * BSP_SLOTS * BSP_SLOT_WORDS;
+    const size_t bytes = sizeof(unsigned) * (BSP_SLOTS + BSP_GRAPH_SLOTS) * BSP_SLOT_WORDS;
     FINC_HIP_TRY(hipMalloc((void **)&a, bytes));
     if (hipError_t e = hipMemset(a, 0, bytes); e != hipSuccess) { finc_set_hip_error(e); (void)hipFree(a); return FINC_ERR_LAUNCH; }
-    g_bsp_area[dev] = a;
+    g_bsp[dev].area = a;
     return FINC_OK;
+}
+
+// a slot of progress words for one launch on `st`, or nullptr (table full of busy streams, no area, a capture beyond its pool, the
+// per-thread stream handle): the chained form
+static unsigned *bsp_take_slot(hipStream_t st, int *slot_index)
+{
+    *slot_index = -1;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= BSP_MAX_DEV) { (void)hipGetLastError(); return nullptr; }
+    BspDevice &d = g_bsp[dev];
+    if (!d.area || st == hipStreamPerThread) return nullptr;
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
+    std::lock_guard<std::mutex> lk(g_bsp_mutex);
+    if (cs != hipStreamCaptureStatusNone) {
+        if (d.graph_next >= BSP_GRAPH_SLOTS) return nullptr;
+        return d.area + (size_t)(BSP_SLOTS + d.graph_next++) * BSP_SLOT_WORDS;
+    }
+    int pick = -1;
+    for (int i = 0; i < BSP_SLOTS && pick < 0; ++i)
+        if (d.slots[i].used && d.slots[i].stream == st) pick = i;           // this stream's own slot
+    for (int i = 0; i < BSP_SLOTS && pick < 0; ++i)
+        if (!d.slots[i].used) pick = i;                                      // a fresh one
+    if (pick < 0) {                                                          // the least recently used slot whose last launch is over
+        for (int i = 0; i < BSP_SLOTS; ++i) {
+            if (pick >= 0 && d.slots[i].last_use >= d.slots[pick].last_use) continue;
+            if (hipEventQuery(d.slots[i].done) != hipSuccess) { (void)hipGetLastError(); continue; }
+            pick = i;
+        }
+        if (pick < 0) return nullptr;
+    }
+    BspSlot &sl = d.slots[pick];
+    if (!sl.done && hipEventCreateWithFlags(&sl.done, hipEventDisableTiming) != hipSuccess) { (void)hipGetLastError(); sl.done = nullptr; return nullptr; }
+    sl.used = true;
+    sl.stream = st;
+    sl.last_use = ++d.clock;
+    *slot_index = pick;
+    return d.area + (size_t)pick * BSP_SLOT_WORDS;
+}
+
+static void bsp_record_slot(hipStream_t st, int slot_index)
+{
+    if (slot_index < 0) return;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= BSP_MAX_DEV) { (void)hipGetLastError(); return; }
+    std::lock_guard<std::mutex> lk(g_bsp_mutex);
+    // (an event that cannot be recorded would let another stream take the slot over while this launch runs: then the slot stays
+    // with this stream for good -- its event is dropped, and a slot without an event is never taken over)
+    BspSlot &sl = g_bsp[dev].slots[slot_index];
+    if (sl.done && hipEventRecord(sl.done, st) != hipSuccess) {
+        (void)hipGetLastError();
+        (void)hipEventDestroy(sl.done);
+        sl.done = nullptr;
+    }
 }
 
 int finc_split_timeouts_count(unsigned *count)
@@ -896,22 +992,27 @@ int finc_split_launch(const float *in, const void *packed, float *out, const Fin
     const int NB = (s.H + P - 1) / P;
     const size_t lds = (size_t)i->lds_bytes;
     int nwg = bsp_nwg(*i, s);
-    unsigned *area = nullptr;
+    unsigned *slot = nullptr;
+    int slot_index = -1;
     if (nwg > 1) {
         (void)finc_split_prepare(st);                          // (allocates unless a capture is going on)
-        int dev = 0;
-        FINC_HIP_TRY(hipGetDevice(&dev));
-        area = (dev >= 0 && dev < BSP_MAX_DEV) ? g_bsp_area[dev] : nullptr;
-        if (!area) nwg = 1;
+        slot = bsp_take_slot(st, &slot_index);
+        if (!slot) nwg = 1;
     }
     const int T = ((NB + nwg - 1) / nwg) * s.W + P - 1;        // steps of one workgroup
     const int Tr = (T + 2 + UNROLL - 1) / UNROLL * UNROLL - 2; // the B waves' loop is unrolled by UNROLL
     const int DF = fifo_depth(s.W, P, s.KH, s.KW);
     if (nwg > 1) {
-        if (int e = finc_ensure_dynamic_lds((const void *)i->fn_bsp, lds)) return e;
-        unsigned *slot = area + (size_t)(g_bsp_next.fetch_add(1) % BSP_SLOTS) * BSP_SLOT_WORDS;
-        hipLaunchKernelGGL(i->fn_bsp, dim3(s.B * s.G * nwg), dim3(64 * (1 + i->nbw)), lds, st, in, (const float *)packed, out, s.G, s.Cq, s.H,
+        // One workgroup per compute unit, enforced by its LDS size: two chains on one unit run at half the pace each (c3 at 32
+        // images with one workgroup per band and no such rule: 216 against 136 us).
+        const size_t lds_one_per_cu = lds > 82 * 1024 ? lds : 82 * 1024;
+        if (int e = finc_ensure_dynamic_lds((const void *)i->fn_bsp, lds_one_per_cu)) { bsp_record_slot(st, slot_index); return e; }
+        // (a workgroup draws bands until none is left: no more workgroups than compute units)
+        const long long jobs = (long long)s.B * s.G * nwg;
+        const int grid = (int)(jobs < device_cus() ? jobs : device_cus());
+        hipLaunchKernelGGL(i->fn_bsp, dim3(grid), dim3(64 * (1 + i->nbw)), lds_one_per_cu, st, in, (const float *)packed, out, s.G, s.Cq, s.H,
                            s.W, P, Tr, s.orient, DF, nwg, s.B * s.G, slot, finc_fault_device_word());
+        bsp_record_slot(st, slot_index);
     } else {
         if (int e = finc_ensure_dynamic_lds((const void *)i->fn, lds)) return e;
         hipLaunchKernelGGL(i->fn, dim3(s.B * s.G), dim3(64 * (1 + i->nbw)), lds, st, in, (const float *)packed, out, s.G, s.Cq, s.H, s.W, P,

@@ -1,111 +1,124 @@
 """The band split's progress-word protocol (finc_split.hip, BSP) as a window-level model -- no GPU.
 
-Two workgroups share a problem: workgroup g owns the bands g, g + 2, ... and chains them; band k needs the last rows of band
-k - 1, which the OTHER workgroup solves.  The kernel's rules, restated (all in units of windows of four steps, local to a
-workgroup; GR = W / 4 store groups per row):
-  * at step 0 of its window w a B wave requests piece w + 1 of the rows above (group gq = (w + 1) % GR of its local band
-    i = (w + 1) // GR) and, if that band has a band above it in the image, first WAITS until the producer's progress word is at
-    least  i' * GR + gq + 6  (i' = the producer's local index of the band above): the group leaves the producer at step 0 of
-    its window i' * GR + gq + 5 (rows P-2, P-1: fs4 = -5; the handed-over rows are stored early) and is complete by its step 3;
+Round 5 form: ONE workgroup per band.  Which (band, problem) a workgroup is comes from a ticket it draws when it starts, band-major,
+so the workgroup of band k - 1 has started before the one of band k whatever the dispatcher did; a workgroup waits only for that
+one.  The kernel's rules, restated (units: windows of four steps, local to a workgroup; GR = W / 4 store groups per row):
+  * at step 0 of its window w a B wave requests piece w + 1 of the rows above (group gq = (w + 1) % GR) and, if its band has a band
+    above it in the image, first WAITS until the producer's progress word is at least  gq + 6: the group leaves the producer at
+    step 0 of its window gq + 5 (rows P-2, P-1: fs4 = -5; the handed-over rows are stored early) and is complete by its step 3;
   * at step 3 of window w it publishes w + 1 (the handed-over stores of the windows 0 .. w are complete);
   * after its last window it drains its stores and publishes "all complete".
-A workgroup blocked in a wait publishes nothing further, so the two can wait for each other: band k + 2 starts GR windows after
-band k on the same workgroup, and by then band k + 1 must have delivered.  The model runs both workgroups to a fixpoint under
-the most favourable scheduling; if it stalls, no timing can save the kernel.  It must complete exactly for the maps the
-library sends to the band split (W >= 64: finc_split.hip bsp_nwg) -- and it reproduces the two failures met on the way: the
-first version's dead-lock on 32-column maps, and the tail the stress test found at W = 68 when the final publish was missing."""
+The wait graph is a chain (band k on band k - 1, band 0 on nobody), so the protocol completes under ANY residency in which a
+started workgroup keeps running -- also when only `resident` workgroups fit the chip at a time and the others start as slots free up
+(in ticket order).  The model runs that: it must complete for every map, narrow ones included (the round-4 form, two workgroups per
+problem chaining alternate bands, dead-locked below 52 columns and relied on both being resident: VERDICT r4 weak 6).  A stale word can no longer be taken for
+progress: the launch's words (ticket counter included) are zeroed by a memset node in front of it, and a slot is reused only behind
+the event of its last launch (tests/test_gpu_round5.py runs two streams and a graph replay beside eager launches)."""
 import pytest
 
-NWG = 2
-ALL_DONE = 0xFFFFF
+ALL_DONE = 0x7FFFFFFF
 
 
-def run_model(H, W, final_publish=True, lookahead=1):
-    """Returns True if both workgroups finish.  `lookahead`: piece w + lookahead is requested in window w."""
+def run_model(H, W, final_publish=True, lookahead=1, resident=None, start_order=None):
+    """Returns True if every band's workgroup finishes.  `resident`: at most that many workgroups hold a compute unit at a time
+    (None: all); `start_order`: the order in which the dispatcher starts workgroups (any permutation: the TICKET decides which band a
+    workgroup is, so the order of starts is the order of bands)."""
     P = 16
     NB = (H + P - 1) // P
     GR = W // 4
-    NBL = (NB + NWG - 1) // NWG
-    T = NBL * W + P - 1
+    T = W + P - 1
     Tr = (T + 2 + 7) // 8 * 8 - 2                    # finc_split_launch: the B waves' loop is unrolled by 8
     nwin = (Tr + 2) // 4                             # windows 0 .. nwin - 1 (u = 0 .. Tr + 1)
-    window = [0, 0]                                  # next window each workgroup will enter
-    published = [0, 0]
-    done = [False, False]
+    order = list(start_order) if start_order is not None else list(range(NB))
+    assert sorted(order) == list(range(NB))
+    band_of = {}                                     # block -> band (its ticket)
+    window = [0] * NB                                # per band: next window its workgroup will enter
+    published = [0] * NB
+    started = [False] * NB                           # per band: prologue done
+    done = [False] * NB
+    running = []                                     # bands whose workgroup holds a compute unit
+    queue = list(order)
+    tickets = 0
+    cap = NB if resident is None else resident
 
-    def need_for(wg, w):
+    def need_for(band, w):
         piece = w + lookahead
-        i, gq = piece // GR, piece % GR
-        kb = wg + i * NWG                            # the image band whose rows above are requested
-        if kb < 1 or kb >= NB:
+        if piece // GR != 0 or band < 1:             # (one band per workgroup: pieces beyond the band's row of groups belong to nobody)
             return None
-        return ((kb - 1) // NWG) * GR + gq + 6
+        return piece % GR + 6
 
-    def prologue_needs(wg):                          # pieces 0 .. lookahead - 1 are requested before the loop
-        out = []
-        for piece in range(lookahead):
-            i, gq = piece // GR, piece % GR
-            kb = wg + i * NWG
-            if 1 <= kb < NB:
-                out.append(((kb - 1) // NWG) * GR + gq + 6)
-        return out
-
-    started = [False, False]
     progress = True
     while progress and not all(done):
         progress = False
-        for wg in (0, 1):
-            other = (wg + NWG - 1) % NWG
-            if done[wg]:
-                continue
-            if not started[wg]:
-                if all(published[other] >= n for n in prologue_needs(wg)):
-                    started[wg] = True
+        while queue and len(running) < cap:          # the dispatcher starts the next block; it draws the next ticket
+            blk = queue.pop(0)
+            band_of[blk] = tickets
+            running.append(tickets)
+            tickets += 1
+            progress = True
+        for band in list(running):
+            if not started[band]:
+                needs = [p % GR + 6 for p in range(lookahead) if band >= 1]
+                if all(published[band - 1] >= n for n in needs):
+                    started[band] = True
                     progress = True
                 continue
-            w = window[wg]
+            w = window[band]
             if w >= nwin:
                 if final_publish:
-                    published[wg] = ALL_DONE
-                done[wg] = True
+                    published[band] = ALL_DONE
+                done[band] = True
+                running.remove(band)                 # frees its compute unit
                 progress = True
                 continue
-            need = need_for(wg, w)
-            if need is not None and published[other] < need:
+            need = need_for(band, w)
+            if need is not None and published[band - 1] < need:
                 continue                             # blocked in progress_wait at step 0 of window w
-            published[wg] = max(published[wg], w + 1)   # step 3 of window w
-            window[wg] = w + 1
+            published[band] = max(published[band], w + 1)   # step 3 of window w
+            window[band] = w + 1
             progress = True
     return all(done)
 
 
-@pytest.mark.parametrize("W", [64, 68, 72, 96, 128])
+@pytest.mark.parametrize("W", [16, 32, 40, 48, 64, 68, 72, 96, 128])
 @pytest.mark.parametrize("H", [17, 26, 32, 33, 48, 64, 85, 100, 128, 250])
-def test_the_protocol_completes_on_every_map_the_library_splits(H, W):
+def test_the_protocol_completes_on_every_map(H, W):
     assert run_model(H, W)
 
 
-@pytest.mark.parametrize("W", [32, 40, 48])
-def test_narrow_maps_dead_lock_which_is_why_the_library_does_not_split_them(W):
-    """band k + 2 starts W/4 windows after band k; the producer of band k + 1 is 7 windows behind its consumer's requests and
-    needs band k's groups up to 5 windows later: W/4 - 1 >= 12, i.e. W >= 52."""
-    assert not run_model(64, W)
+@pytest.mark.parametrize("resident", [1, 2, 3])
+@pytest.mark.parametrize("H", [33, 64, 128])
+def test_the_protocol_completes_whatever_the_residency(H, resident):
+    """Only `resident` workgroups of the problem hold a compute unit at a time (another tenant has the rest of the chip): a waiting
+    workgroup's producer drew an earlier ticket, so it is running or done -- never waiting for a slot the waiter holds."""
+    assert run_model(H, 64, resident=resident)
+    assert run_model(H, 32, resident=resident)
 
 
-def test_the_tail_the_stress_test_found():
-    """W = 68: 17 store groups per row; the loop of a one-band producer (H = 26: two bands, one each) ends at window 21 and has
-    published 21 (that version said a window's stores complete one window later than today's), the consumer's last piece
-    needs 22.  Without the publish behind the loop the consumer waits forever.  (Today's early store of the handed-over rows
-    gives the tail one window of slack; the final publish stays -- a longer tail, e.g. W = 76, would need it again.)"""
-    assert run_model(26, 68, final_publish=True)
-    assert run_model(26, 64, final_publish=False)
+def test_the_dispatch_order_does_not_matter():
+    """Blocks started in any order: a block is the band of the ticket it draws, not of its index."""
+    assert run_model(100, 64, resident=2, start_order=[6, 0, 3, 5, 1, 4, 2])
+    assert run_model(64, 64, resident=1, start_order=[3, 2, 1, 0])
+
+
+def test_the_tail_of_a_band():
+    """The consumer's last piece (group GR - 1) needs the producer's word at GR + 5; the producer's loop runs 2 * ceil((W + 17) / 8)
+    windows >= GR + 5 and publishes one per window, so with one band per workgroup the loop alone covers the tail (the two-workgroup
+    form of round 4 did not at W = 68: scripts/stress_bands.py found its consumers waiting forever).  The publish of "all complete"
+    behind the loop stays as the guard for any change of that arithmetic."""
+    for W in range(16, 260, 4):
+        assert run_model(26, W, final_publish=False), W
+        assert 2 * -(-(W + 17) // 8) >= W // 4 + 5
 
 
 def test_the_library_rule_matches_the_model():
-    """finc_split.hip bsp_nwg: W >= 64 (host-only query)."""
+    """finc_split.hip bsp_nwg: one workgroup per band on maps of >= 64 columns and >= 2 bands while the problems leave half the
+    compute units idle (host-only query)."""
     from fincflow_amd import _lib
     for W in (32, 48, 60, 64, 68, 72):
         v = _lib.inverse_variant(8, 4, 24, 64, W, 3, 3)
         assert v is not None and v["sec"] == 4
-        split = v["workgroups"] == 2 * 8 * 4
+        split = v["workgroups"] == 4 * 8 * 4
         assert split == (W >= 64) and (not split or run_model(64, W)), (W, v)
+    assert _lib.inverse_variant(8, 4, 24, 100, 64, 3, 3)["workgroups"] == 7 * 8 * 4
+    assert _lib.inverse_variant(40, 4, 24, 64, 64, 3, 3)["workgroups"] == 40 * 4      # 2 x 160 problems > 256 compute units: chained

@@ -75,9 +75,9 @@ def test_stack_matches_reference_trace():
         for m in reversed(layers):
             r = m.reverse(r, None)
             r = r[0] if isinstance(r, tuple) else r
-    assert rel_err(h.cpu().numpy(), g["z"]) <= 2e-5
+    assert rel_err(h.cpu().numpy(), g["z"]) <= 1e-5
     assert np.allclose(logdet.cpu().numpy(), g["logdet"], rtol=1e-5, atol=1e-4)
-    assert rel_err(r.cpu().numpy(), g["x_rev"]) <= 2e-5
+    assert rel_err(r.cpu().numpy(), g["x_rev"]) <= 1e-5
 
 
 @pytest.mark.gpu

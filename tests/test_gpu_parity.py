@@ -307,7 +307,7 @@ def test_backward_per_entry_against_cpu_autograd(case, dev):
         expect = (w.grad * m.mask.double()).numpy()
         got = m.conv.weight.grad.cpu().numpy()
         ew = rel_err(got, expect)
-        assert ew <= 2e-5, ("grad_w", m.order, ew)        # a B*H*W-term fp32 reduction against fp64
+        assert ew <= 1e-5, ("grad_w", m.order, ew)        # a B*H*W-term fp32 reduction against fp64 (worst on record 2.5e-6)
         assert np.all(got[m.mask.numpy() == 0] == 0)      # the corner-tap mask is applied in-kernel: exact zeros
 
 
@@ -642,7 +642,7 @@ def test_cincflowunit_at_96_channels(dev):
     F.conv2d(F.pad(xc, m.pad), w).backward(gz.cpu().double())
     assert rel_err(xt.grad.cpu().numpy(), xc.grad.numpy()) <= TOL
     got = m.conv.weight.grad.cpu().numpy()
-    assert rel_err(got, (w.grad * torch.as_tensor(m.mask).double()).numpy()) <= 2e-5
+    assert rel_err(got, (w.grad * torch.as_tensor(m.mask).double()).numpy()) <= 1e-5
     with torch.no_grad():
         xr = u.reverse(t(z_ref, dev))
     assert rel_err(xr.cpu().numpy(), oracle.inverse_via_f64(z_ref, wc, 1, 0)) <= TOL
@@ -898,7 +898,7 @@ def test_channel_counts_between_the_compiled_banks(case, dev):
     torch.cat(outs, 1).backward(gz.cpu().double())
     assert rel_err(xg.grad.cpu().numpy(), xc.grad.numpy()) <= TOL
     for m, w in zip((unit.conv_tl, unit.conv_tr, unit.conv_bl, unit.conv_br), wsc):
-        assert rel_err(m.conv.weight.grad.cpu().numpy(), (w.grad * m.mask.double()).numpy()) <= 2e-5
+        assert rel_err(m.conv.weight.grad.cpu().numpy(), (w.grad * m.mask.double()).numpy()) <= 1e-5
 
 
 def test_unaligned_activations_fall_back(dev):

@@ -220,7 +220,7 @@ def test_band_split_of_the_role_split_inverse(shape, dev):
     from fincflow_amd import FastFlowUnit, _lib, ops
     B, C, H, W, K = shape
     v = _lib.inverse_variant(B, 4, C // 4, H, W, K, K)
-    assert v is not None and v["sec"] == 4 and v["workgroups"] == 2 * B * 4, v
+    assert v is not None and v["sec"] == 4 and v["workgroups"] == ((H + 15) // 16) * B * 4, v   # (round 5: one workgroup per band)
     torch.manual_seed(sum(shape))
     unit = FastFlowUnit(C, C, K).to(dev)
     x = torch.randn(B, C, H, W, device=dev)
@@ -247,7 +247,7 @@ def test_band_split_in_a_captured_graph_and_with_a_folded_affine_map(dev):
     affine fold rides on the band split like on the chained form (same packed bank)."""
     from fincflow_amd import FastFlowUnit, _lib, glow
     B, C, H, W = 8, 96, 64, 64
-    assert _lib.inverse_variant(B, 4, C // 4, H, W, 3, 3)["workgroups"] == 2 * B * 4
+    assert _lib.inverse_variant(B, 4, C // 4, H, W, 3, 3)["workgroups"] == (H // 16) * B * 4
     torch.manual_seed(5)
     unit = FastFlowUnit(C, C, 3).to(dev)
     an = glow.ActNorm(C).to(dev)
@@ -381,7 +381,7 @@ def test_non_square_filters_run_on_mfma(case, dev):
     if len(pick) == B:                                                # (the weight gradient sums over the batch)
         for m, w in zip((unit.conv_tl, unit.conv_tr, unit.conv_bl, unit.conv_br), wds):
             want = (w.grad * m.get_mask().cpu().double()).numpy()
-            assert rel_err(m.conv.weight.grad.cpu().numpy(), want) <= 1e-4
+            assert rel_err(m.conv.weight.grad.cpu().numpy(), want) <= 2e-5
 
 
 # ------------------------------------------------------------------ Winograd weight gradients (finc_gradw.hip)
@@ -416,7 +416,7 @@ def test_winograd_weight_gradient_of_one_padded_conv(case, dev):
     got = m.conv.weight.grad.cpu().numpy()
     ew = rel_err(got, expect)
     report("grad_w_" + want, case="B%d_Cq%d_%dx%d_k%d_%s" % case[:6], max_normalised=ew)
-    assert ew <= 2e-5, ew
+    assert ew <= 1e-5, ew
     assert np.all(got[m.mask.numpy() == 0] == 0)
     assert rel_err(x.grad.cpu().numpy(), xc.grad.numpy()) <= TOL
 
@@ -490,7 +490,7 @@ def test_cinc_unit_forward_on_the_msplit_winograd_kernel(C, dev):
     zc.backward(gz.cpu().double())
     assert ld == 0.0 and rel_err(z.detach().cpu().numpy(), zc.detach().numpy()) <= TOL
     assert rel_err(x.grad.cpu().numpy(), xc.grad.numpy()) <= TOL
-    assert rel_err(m.conv.weight.grad.cpu().numpy(), (w.grad * m.mask.double()).numpy()) <= 2e-5
+    assert rel_err(m.conv.weight.grad.cpu().numpy(), (w.grad * m.mask.double()).numpy()) <= 1e-5
     if C <= 48:     # (64 channels at the init's N(0, 0.05^2) on a 64-wide map: the triangular system amplifies fp32 rounding past any
                     #  tolerance -- in the oracle's fp32 order as well; the forward / backward kernels are what this test is about)
         with torch.no_grad():

@@ -121,3 +121,112 @@ def test_short_step_kernel_on_a_dword_aligned_view(dev):
     ops.finc_inverse(zin, wc, G, ORIENT_FASTFLOW, out=out)
     want = oracle.inverse_via_f64(z, wco, G, ORIENT_FASTFLOW)
     assert rel_err(out.cpu().numpy(), want) <= TOL
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# The band split (finc_split.hip, BSP) in its round-5 form: one workgroup per band, ticket order, a launch owns its progress words
+# ---------------------------------------------------------------------------------------------------------------------------------
+def _band_split_unit(dev, B, C, H, W, seed):
+    from fincflow_amd import FastFlowUnit, _lib
+    v = _lib.inverse_variant(B, 4, C // 4, H, W, 3, 3)
+    assert v is not None and v["sec"] == 4 and v["workgroups"] == ((H + 15) // 16) * B * 4, v
+    torch.manual_seed(seed)
+    unit = FastFlowUnit(C, C, 3).to(dev)
+    x = torch.randn(B, C, H, W, device=dev)
+    with torch.no_grad():
+        z, _ = unit(x)
+        want = ops_strict(unit, z)
+    return unit, z, want
+
+
+def ops_strict(unit, z):
+    from fincflow_amd import ops
+    return ops.finc_inverse(z, unit._cache.w_canon, algo="strict")
+
+
+def test_band_split_launches_on_two_streams_do_not_share_progress_words(dev):
+    """launches in flight on different streams must not index the same words.  Two problem sets of different
+    sizes, 40 launches each, enqueued far ahead on two streams at once (more launches in flight than there are slots: the ones that
+    find none run the chained form) -- every result against the strict kernel's, no wait gave up."""
+    from fincflow_amd import _lib
+    ua, za, wa = _band_split_unit(dev, 8, 96, 64, 64, 1)
+    ub, zb, wb = _band_split_unit(dev, 3, 96, 100, 68, 2)
+    with torch.no_grad():
+        ua.reverse(za); ub.reverse(zb)                      # (packs the weights outside the streams)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    outs_a, outs_b = [], []
+    with torch.no_grad():
+        for _ in range(40):
+            with torch.cuda.stream(s1):
+                outs_a.append(ua.reverse(za))
+            with torch.cuda.stream(s2):
+                outs_b.append(ub.reverse(zb))
+    torch.cuda.synchronize()
+    for o in outs_a:
+        assert rel_err(o.cpu().numpy(), wa.cpu().numpy()) <= TOL
+    for o in outs_b:
+        assert rel_err(o.cpu().numpy(), wb.cpu().numpy()) <= TOL
+    assert all(torch.equal(o, outs_a[0]) for o in outs_a) and all(torch.equal(o, outs_b[0]) for o in outs_b)
+    assert _lib.hlp_timeouts() == 0 and not _lib.fault_pending()
+
+
+def test_band_split_graph_replays_beside_eager_launches(dev):
+    """A captured band-split launch keeps a slot of its own (its memset node zeroes the words at every replay); eager launches on
+    another stream take theirs from the event-tracked pool: replays and eager launches run side by side."""
+    from fincflow_amd import _lib
+    ua, za, wa = _band_split_unit(dev, 8, 96, 64, 64, 3)
+    ub, zb, wb = _band_split_unit(dev, 4, 96, 48, 64, 4)
+    with torch.no_grad():
+        ua.reverse(za); ub.reverse(zb)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = ua.reverse(za)
+        s2 = torch.cuda.Stream(dev)
+        eager = []
+        for _ in range(12):
+            out.zero_()
+            g.replay()
+            with torch.cuda.stream(s2):
+                for _ in range(3):
+                    eager.append(ub.reverse(zb))
+            torch.cuda.synchronize()
+            assert rel_err(out.cpu().numpy(), wa.cpu().numpy()) <= TOL
+    for o in eager:
+        assert rel_err(o.cpu().numpy(), wb.cpu().numpy()) <= TOL
+    assert _lib.hlp_timeouts() == 0 and not _lib.fault_pending()
+
+
+def test_band_split_beside_a_kernel_that_fills_the_chip(dev):
+    """the band split on one stream while the full-batch c3 inverse (1,024 one-wave problems: every SIMD of every
+    compute unit) runs on another, so that the band split's workgroups are placed a few at a time as the other kernel's retire.  A
+    workgroup waits only for the band above, whose workgroup drew an earlier ticket and is therefore running or done: the result is
+    the oracle's, no wait gives up, no fault is pending."""
+    from fincflow_amd import FastFlowUnit, _lib
+    ub, zb, wb = _band_split_unit(dev, 16, 96, 64, 64, 5)
+    torch.manual_seed(6)
+    big = FastFlowUnit(96, 96, 3).to(dev)
+    zbig = torch.randn(256, 96, 64, 64, device=dev)
+    with torch.no_grad():
+        big.reverse(zbig); ub.reverse(zb)
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+    outs = []
+    with torch.no_grad():
+        for _ in range(6):
+            with torch.cuda.stream(s1):
+                for _ in range(4):
+                    big.reverse(zbig)
+            with torch.cuda.stream(s2):
+                for _ in range(6):
+                    outs.append(ub.reverse(zb))
+    torch.cuda.synchronize()
+    ws = torch.cat(ub._weights()).detach().cpu().numpy()
+    wco = oracle.canonicalize(ws, 4, ORIENT_FASTFLOW)
+    want = oracle.inverse_via_f64(zb[:2].cpu().numpy(), wco, 4, ORIENT_FASTFLOW, nthreads=8)
+    for o in outs:
+        assert rel_err(o[:2].cpu().numpy(), want) <= TOL
+        assert torch.equal(o, outs[0])
+    assert rel_err(outs[0].cpu().numpy(), wb.cpu().numpy()) <= TOL
+    assert _lib.hlp_timeouts() == 0 and not _lib.fault_pending()

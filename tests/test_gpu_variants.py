@@ -66,6 +66,9 @@ def run_inverse_case(dev, B, G, orient, Cq, H, W, KH, KW, seed, tag, expect_row=
            reference_fp32_vs_fp64=gap, tol=tol, needed_more_than_1e5=bool(e_max > TOL))
     assert np.array_equal(strict, ref32), "strict kernel must be bit-exact with the fp32 reference order"
     assert e_max <= tol, (e_max, tol, v)
+    # element-wise (every entry of at least a thousandth of the largest judged against ITSELF): 1e-3 holds on every case on record
+    # (worst 5.4e-4, profiles/r04/parity_errors.json) -- scaled like `tol` for the banks whose own fp32-fp64 gap exceeds 1e-5
+    assert e_elem <= 1e-3 * (tol / TOL), (e_elem, tol, v)
     return e_max, e_elem
 
 
@@ -124,7 +127,7 @@ def test_role_split_kernel(case, dev):
     # (round 5: the banks of up to 16 channels run its short-step form, finc_chain.hip: form 6 -- the recurrence wave, one wave per
     # tap with a + b == 2, the I/O wave; one workgroup per problem)
     chain = Cq <= 16 and not (Cq > 12 and 2 * B * G <= 256 and H > 16 and W >= 64 and KH > 1)
-    per = 2 if (2 * B * G <= 256 and H > 16 and W >= 64 and KH > 1 and not chain) else 1
+    per = (H + 15) // 16 if (2 * B * G <= 256 and H > 16 and W >= 64 and KH > 1 and not chain) else 1   # (round 5: one workgroup per band)
     assert v is not None and v["sec"] == (6 if chain else 4) and v["nw"] == ((5 if KH == 3 else 3) if chain else 4), v
     assert v["workgroups"] == per * B * G, v
     e_max, _ = run_inverse_case(dev, B, G, orient, Cq, H, W, KH, KW, seed=31 * Cq + H + W, tag="role_split")

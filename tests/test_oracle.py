@@ -191,6 +191,33 @@ def test_config5_init_std_is_unstable_in_the_reference_arithmetic():
     assert err[0.05] > 1e-3 and err[0.02] < 1e-5, err
 
 
+def test_trained_like_weights_lose_their_digits_at_64x64_in_the_reference_arithmetic():
+    """Why tests/test_gpu_round4.py::test_f43_on_trained_like_weights... has no inverse half (VERDICT r4 weak 3: the claim was
+    on record, not pinned).  One group of the c3 bank -- 24 channels, 3x3, the reference's init (layers/conv.py:63-79) -- with its
+    free taps x 1.5 (tests/golden/make_golden.py's `heavy` rule): the round trip x -> forward (fp32) -> the reference-order fp64
+    solve loses its digits as the map grows -- 1e-5 is out of reach from 48x48 on (3.8e-5 measured), at 64x64 the error is 1.6e-3,
+    a hundred and fifty times the bar -- while the init weights themselves round-trip to 6e-8 at 64x64.  The 1e-7 rounding of z is amplified by the solve
+    itself (the fp32-order solve: no better), so no implementation can be held to 1e-5 there; the inverse meets trained-like
+    weights in the `heavy` golden fixtures, at sizes the reference can still solve."""
+    rng = np.random.default_rng(3)
+    ws = oracle.make_stored_weights(1, 24, 3, 3, orient=0, seed=1234, std=0.05)
+    mask = np.ones_like(ws)
+    for c in range(24):
+        mask[c, c:, 2, 2] = 0.0                     # the fixed corner entries (layers/conv.py:81-96) keep their values
+    heavy = (ws * (1.0 + 0.5 * mask)).astype(np.float32)
+    err = {}
+    for name, w in (("init", ws), ("x1.5", heavy)):
+        for n in (16, 32, 48, 64):
+            x = rng.standard_normal((1, 24, n, n)).astype(np.float32)
+            z = oracle.forward_f32(x, w, 1, 0)
+            xr = oracle.inverse_via_f64(z, w, 1, 0)
+            err[name, n] = float(np.abs(xr - x).max() / np.abs(x).max())
+    assert err["init", 64] < 1e-5, err
+    assert err["x1.5", 16] < 1e-5, err              # small maps are fine: the `heavy` fixtures live there
+    assert err["x1.5", 48] > 1e-5 and err["x1.5", 64] > 1e-4, err
+    assert err["x1.5", 16] < err["x1.5", 32] < err["x1.5", 48] < err["x1.5", 64], err
+
+
 def test_the_compiled_reference_never_travels_to_the_gpu_box():
     """BASELINE.md 2 / SURVEY 8c: the reference runs only in the build container.  oracle/_ref/ (the reference's .pyx, cythonised
     and compiled by oracle/build_ref.py) must stay excluded from the gpurun snapshot AND from history, and nothing that runs on
