@@ -137,10 +137,10 @@ struct SCfg {
 __device__ unsigned finc_split_timeouts = 0;     // BSP: progress waits that gave up (must stay 0)
 
 template <int CQP, int KH, int KW, int NBW, bool BSP>
-__global__ __launch_bounds__(64 * (1 + NBW)) void finc_split_kernel(const float *__restrict__ in, const float *__restrict__ packed,
-                                                                   float *__restrict__ out, int G, int CQ, int H, int W, int P,
-                                                                   int T, unsigned orient, int DF, int nwg, int nprob,
-                                                                   unsigned *__restrict__ sync, unsigned *fault_word)
+__global__ __launch_bounds__(64 * (1 + NBW)) void finc_split_kernel(const float *__restrict__ a_in, const float *__restrict__ a_packed,
+                                                                   float *__restrict__ a_out, int a_G, int a_CQ, int a_H, int a_W, int a_P,
+                                                                   int a_T, unsigned a_orient, int a_DF, int a_nwg, int a_nprob,
+                                                                   unsigned *__restrict__ a_sync, unsigned *a_fault_word)
 {
     using C = SCfg<CQP, KH, KW, NBW>;
     constexpr int MT = C::MT, MTB = C::MTB, NK = C::NK, NCH = C::NCH, JS = C::JS;
@@ -155,7 +155,21 @@ __global__ __launch_bounds__(64 * (1 + NBW)) void finc_split_kernel(const float 
     // ticket -- is therefore running or done whenever a consumer exists, whatever order and placement the dispatcher chose and
     // however few workgroups are resident: a workgroup only ever waits for one that makes progress.  The
     // launch's words (ticket and done counters included) start at zero: the previous launch on the slot left them so.
+    // (BSP: the arguments are read from the kernel-argument segment again for every band -- scalar loads, once per job -- instead of
+    // being kept in registers across the whole body: 16 more live scalars spilled 40-48 SGPRs in every instantiation)
+    typedef const volatile __attribute__((address_space(4))) unsigned *karg_ptr;
+    const karg_ptr ka = (karg_ptr)__builtin_amdgcn_kernarg_segment_ptr();
+    auto karg_p = [&](int dw) { return (unsigned long long)ka[dw] | ((unsigned long long)ka[dw + 1] << 32); };
     for (;;) {
+    unsigned *const sync = BSP ? (unsigned *)karg_p(16) : a_sync;
+    const int nwg = BSP ? (int)ka[14] : a_nwg, nprob = BSP ? (int)ka[15] : a_nprob;
+    const float *const in = BSP ? (const float *)karg_p(0) : a_in;
+    const float *const packed = BSP ? (const float *)karg_p(2) : a_packed;
+    float *const out = BSP ? (float *)karg_p(4) : a_out;
+    const int G = BSP ? (int)ka[6] : a_G, CQ = BSP ? (int)ka[7] : a_CQ, H = BSP ? (int)ka[8] : a_H, W = BSP ? (int)ka[9] : a_W;
+    const int P = BSP ? (int)ka[10] : a_P, T = BSP ? (int)ka[11] : a_T, DF = BSP ? (int)ka[13] : a_DF;
+    const unsigned orient = BSP ? ka[12] : a_orient;
+    unsigned *const fault_word = BSP ? (unsigned *)karg_p(18) : a_fault_word;
     int slot_id = (int)blockIdx.x;
     if constexpr (BSP) {
         if (threadIdx.x == 0) lds[0] = __builtin_bit_cast(float, __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
@@ -724,6 +738,8 @@ __global__ __launch_bounds__(64 * (1 + NBW)) void finc_split_kernel(const float 
     __syncthreads();                           // (every wave is done with the LDS -- and the B waves with their last words -- before the next band)
     }   // for (;;)
     if constexpr (BSP) {
+        unsigned *const sync = a_sync;
+        const int nwg = a_nwg, nprob = a_nprob;
         if (role == 0) {
             // The launch leaves its words as it found them: zero.  Every workgroup counts itself done when it finds no band left (all
             // its waves are then past their last access to the words: the barrier above; the B waves drained their stores in front of
