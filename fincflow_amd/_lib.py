@@ -24,6 +24,7 @@ SYMBOLS = [
     "finc_inverse_packed_f32", "finc_forward_packed_f32", "finc_backward_f32", "finc_backward_workspace_bytes",
     "finc_inverse_workspace_bytes", "finc_pack_inverse_weights_affine_f32",
     "finc_canonicalize_weights_f64", "finc_inverse_f64", "finc_forward_f64",
+    "finc_f64_workspace_bytes", "finc_inverse_f64_algo", "finc_forward_f64_algo",
     "finc_inverse_kernel_variant", "finc_debug_attr_table_insert", "finc_debug_inverse_table_row",
     "finc_mix_supported_f32", "finc_mix_f32", "finc_pack_forward_weights_affine_f32", "finc_debug_hlp_timeouts",
     "finc_build_flags", "finc_inverse_packed_premultiplied_f32", "finc_inverse_premultiplied_supported", "finc_clear_fault", "finc_debug_backward_variant", "finc_debug_set_forward_form",
@@ -86,6 +87,10 @@ def lib():
     run64 = [vp, vp, vp, i, i, i, i, i, i, i, u, vp]
     L.finc_inverse_f64.argtypes = run64
     L.finc_forward_f64.argtypes = run64
+    L.finc_f64_workspace_bytes.restype = sz
+    L.finc_f64_workspace_bytes.argtypes = [i, i, i, i]
+    L.finc_inverse_f64_algo.argtypes = run
+    L.finc_forward_f64_algo.argtypes = run
     L.finc_inverse_kernel_variant.argtypes = [i, i, i, i, i, i, i, ctypes.POINTER(ctypes.c_int)]
     L.finc_debug_attr_table_insert.argtypes = [i, sz]
     L.finc_debug_inverse_table_row.argtypes = [i, ctypes.POINTER(ctypes.c_int)]

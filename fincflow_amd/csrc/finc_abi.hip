@@ -178,7 +178,7 @@ int finc_version(void) { return 102; }
 
 unsigned finc_build_flags(void)
 {
-    return FINC_BUILD_FLAGS | finc_build_flags_mfma() | finc_build_flags_split() | finc_build_flags_chain() | finc_build_flags_conv() | finc_build_flags_gradw() | finc_build_flags_wino4m() |
+    return FINC_BUILD_FLAGS | finc_build_flags_mfma() | finc_build_flags_split() | finc_build_flags_chain() | finc_build_flags_f64() | finc_build_flags_conv() | finc_build_flags_gradw() | finc_build_flags_wino4m() |
            finc_build_flags_mix() | finc_build_flags_generic() | finc_build_flags_wino() | finc_build_flags_big() | finc_build_flags_probe() | finc_build_flags_wino5();
 }
 
@@ -498,6 +498,44 @@ int finc_forward_f64(const double *x, const double *w_canon, double *z, int B, i
                      int KW, unsigned orient, finc_stream_t stream)
 {
     return run_f64(x, w_canon, z, B, G, Cq, H, W, KH, KW, orient, stream, true);
+}
+
+size_t finc_f64_workspace_bytes(int G, int Cq, int KH, int KW)
+{
+    if (G <= 0 || Cq <= 0 || KH <= 0 || KW <= 0) return 0;
+    return finc_f64_packed_bytes(G, Cq, KH, KW);
+}
+
+static int run_f64_algo(const double *in, const double *w_canon, double *out, int B, int G, int Cq, int H, int W, int KH, int KW,
+                        unsigned orient, int algo, void *workspace, size_t workspace_bytes, finc_stream_t stream, bool forward)
+{
+    if (!in || !w_canon || !out) return FINC_ERR_NULL_POINTER;
+    if (int e = check_shape(B, G, Cq, H, W, KH, KW)) return e;
+    if (((uintptr_t)in | (uintptr_t)w_canon | (uintptr_t)out) & 7u) return FINC_ERR_ALIGNMENT;
+    if (in == out) return FINC_ERR_BAD_DIMS;
+    if (algo != FINC_ALGO_AUTO && algo != FINC_ALGO_STRICT && algo != FINC_ALGO_MFMA) return FINC_ERR_BAD_DIMS;
+    FincShape s{B, G, Cq, H, W, KH, KW, orient};
+    const bool can = algo != FINC_ALGO_STRICT && finc_f64_supported(s) && workspace && ((uintptr_t)workspace & 7u) == 0 &&
+                     workspace_bytes >= finc_f64_packed_bytes(G, Cq, KH, KW);
+    if (!can) {
+        if (algo == FINC_ALGO_MFMA) return finc_f64_supported(s) ? FINC_ERR_WORKSPACE : FINC_ERR_UNSUPPORTED;
+        return forward ? finc_launch_forward_generic_f64(in, w_canon, out, s, (hipStream_t)stream)
+                       : finc_launch_inverse_strict_f64(in, w_canon, out, s, (hipStream_t)stream);
+    }
+    if (int e = finc_fault_gate(false)) return e;
+    return finc_f64_launch(in, w_canon, out, workspace, s, forward, (hipStream_t)stream);
+}
+
+int finc_inverse_f64_algo(const double *z, const double *w_canon, double *x, int B, int G, int Cq, int H, int W, int KH, int KW,
+                          unsigned orient, int algo, void *workspace, size_t workspace_bytes, finc_stream_t stream)
+{
+    return run_f64_algo(z, w_canon, x, B, G, Cq, H, W, KH, KW, orient, algo, workspace, workspace_bytes, stream, false);
+}
+
+int finc_forward_f64_algo(const double *x, const double *w_canon, double *z, int B, int G, int Cq, int H, int W, int KH, int KW,
+                          unsigned orient, int algo, void *workspace, size_t workspace_bytes, finc_stream_t stream)
+{
+    return run_f64_algo(x, w_canon, z, B, G, Cq, H, W, KH, KW, orient, algo, workspace, workspace_bytes, stream, true);
 }
 
 int finc_inverse_kernel_variant(int B, int G, int Cq, int H, int W, int KH, int KW, int *info)

@@ -162,6 +162,13 @@ int finc_gradw_variant(const FincShape &s);   // 0 direct, 1 dword MFMA, 2 stage
 // info[0..2] = {waves per strip (K-split), staged form (1) or dword form (0), strips per slab}; FINC_ERR_UNSUPPORTED: direct kernel
 int finc_conv_variant(int B, int G, int Cq, int H, int W, int KH, int KW, int *info);
 
+// ---- double precision on the matrix cores: finc_f64.hip (the c2 / c3 class of banks: Cq <= 24 at 3x3, <= 32 at 2x2) ----
+bool finc_f64_supported(const FincShape &s);
+size_t finc_f64_packed_bytes(int G, int Cq, int KH, int KW);          // 0: no such kernel for this bank
+// packs the bank into `packed` (finc_f64_packed_bytes) and runs the inverse or the forward on it, all on `st`
+int finc_f64_launch(const double *in, const double *wc, double *out, void *packed, const FincShape &s, bool forward, hipStream_t st);
+unsigned finc_build_flags_f64();
+
 // ---- per-pixel channel mixing (1x1 conv + folded affine): finc_mix.hip ----
 bool finc_mix_supported(int C);
 int finc_mix_launch(const float *in, const float *mat, const float *bias, float *out, int B, int C, int HW, hipStream_t st);

@@ -964,13 +964,21 @@ bool finc_split_uses_chain(const FincShape &s)
     if (!finc_chain_takes(s)) return false;
     const SInst *i = find_sinst(s.Cq, s.KH, s.KW);
     const int P = s.W < 16 ? s.W : 16;
+    if ((long long)s.B * s.G > split_max_problems()) return true;          // (only it takes two problems per compute unit: finc_split_takes)
     if (i && i->cqp == 16 && fifo_fits(*i, s.W, P) && bsp_nwg(*i, s) > 1) return false;
     return true;
 }
 
 bool finc_split_takes(const FincShape &s)
 {
-    if ((long long)s.B * s.G > split_max_problems()) return false;
+    const long long problems = (long long)s.B * s.G;
+    if (problems > split_max_problems()) {
+        // two problems per compute unit: the short-step form still beats the wavefront kernel's table (its workgroup is 45 KB of LDS
+        // and five waves) once the chain is long enough to pay for its prologue -- C = 48, 32x32, B = 128: 42.6 against 57.3 us;
+        // the 16x16 maps of the CIFAR stack 14.2 against 15.1; 8x8 and 4x4 maps: 12.2 / 11.5 against 11.7 / 9.5, so not those
+        const int P = s.W < 16 ? s.W : 16;
+        return problems <= 2 * split_max_problems() && ((s.H + P - 1) / P) * s.W + P - 1 >= 31 && finc_chain_takes(s);
+    }
     if (finc_split_uses_chain(s)) return true;                             // (the small banks' short-step form: no FIFO-width limit)
     const SInst *i = find_sinst(s.Cq, s.KH, s.KW);
     if (!i || s.H < 1 || s.W < 1) return false;

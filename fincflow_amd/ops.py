@@ -107,13 +107,19 @@ def _run(fn_name, act, w_canon, G, orient, algo, out):
     if act.numel() == 0:
         return out
     L = _lib.lib()
-    if dt == torch.float64:                # reference-order fp64 kernels: no packed form, no workspace
-        if algo not in ("auto", "strict"):
-            raise _lib.FincError(f"{fn_name}: float64 runs on the reference-order kernel only (algo auto/strict)")
+    if dt == torch.float64:
+        # strict: the reference-order fp64 kernels (bit-exact with the reference's Cython solver; no packed form, no workspace);
+        # auto / mfma: the matrix-core form where the bank has one (finc_f64.hip: Cq <= 24 at 3x3, <= 32 at 2x2), else strict
         fn64 = fn_name.replace("_f32", "_f64")
         with torch.cuda.device(act.device):
-            st = getattr(L, fn64)(act.data_ptr(), w_canon.data_ptr(), out.data_ptr(), B, G, Cq, H, W, KH, KW, orient,
-                                  _stream_ptr(act))
+            if algo == "strict":
+                st = getattr(L, fn64)(act.data_ptr(), w_canon.data_ptr(), out.data_ptr(), B, G, Cq, H, W, KH, KW, orient,
+                                      _stream_ptr(act))
+            else:
+                ws = _workspace(act.device, L.finc_f64_workspace_bytes(G, Cq, KH, KW))
+                fn64 += "_algo"
+                st = getattr(L, fn64)(act.data_ptr(), w_canon.data_ptr(), out.data_ptr(), B, G, Cq, H, W, KH, KW, orient,
+                                      _lib.ALGO[algo], ws.data_ptr(), ws.numel(), _stream_ptr(act))
         _lib.check(st, fn64)
         return out
     if fn_name == "finc_inverse_f32":      # room for the zero-padded copy an odd width is solved on

@@ -206,6 +206,20 @@ int finc_inverse_f64(const double *z, const double *w_canon, double *x, int B, i
                      int KW, unsigned orient, finc_stream_t stream);
 int finc_forward_f64(const double *x, const double *w_canon, double *z, int B, int G, int Cq, int H, int W, int KH,
                      int KW, unsigned orient, finc_stream_t stream);
+/*
+ * The same two calls with an algorithm choice (round 5): FINC_ALGO_STRICT = the reference-order kernels above; FINC_ALGO_AUTO /
+ * FINC_ALGO_MFMA = the double-precision matrix-core form (finc_f64.hip: v_mfma_f64_16x16x4_f64, one wavefront per (image, group),
+ * the reference's anti-diagonal visitation band by band, the in-pixel substitution folded into the bank in fp64) for the banks that
+ * have one -- Cq <= 24 at 3x3 (configs[1], configs[2]), Cq <= 32 at 2x2; results within 1e-12 of the reference-order solve, not
+ * bit-equal to it (the order in which a pixel's terms are added differs).  AUTO falls back to the reference-order kernel for any
+ * other shape or when `workspace` is NULL / smaller than finc_f64_workspace_bytes(); MFMA reports FINC_ERR_UNSUPPORTED /
+ * FINC_ERR_WORKSPACE instead.  The workspace (8-byte aligned) holds the packed bank; the call packs and launches on `stream`.
+ */
+size_t finc_f64_workspace_bytes(int G, int Cq, int KH, int KW);
+int finc_inverse_f64_algo(const double *z, const double *w_canon, double *x, int B, int G, int Cq, int H, int W, int KH, int KW,
+                          unsigned orient, int algo, void *workspace, size_t workspace_bytes, finc_stream_t stream);
+int finc_forward_f64_algo(const double *x, const double *w_canon, double *z, int B, int G, int Cq, int H, int W, int KH, int KW,
+                          unsigned orient, int algo, void *workspace, size_t workspace_bytes, finc_stream_t stream);
 
 /*
  * SURVEY 8 f3, second half -- the 1x1 convolution next to the unit (layers/conv1x1.py:29-43: forward

@@ -112,9 +112,11 @@ SPLIT_BANKS = {(3, 3): (4, 8, 12, 16, 20, 24, 28, 32), (2, 2): (4, 8, 12, 16, 24
 def chain_takes(cqp, kh, kw, problems, H, W):
     """Mirror of finc_chain.hip finc_chain_takes (inside finc_split_takes): the short-step form of the role-split kernel takes the
     2x2 / 3x3 banks of up to 16 channels on any map whose width is a multiple of 4 (its hand-over FIFO is 128 bytes per step)."""
-    if problems > SPLIT_MAX_PROBLEMS or cqp > 16 or cqp not in SPLIT_BANKS.get((kh, kw), ()) or H < 1 or W < 4 or W % 4:
+    if problems > 2 * SPLIT_MAX_PROBLEMS or cqp > 16 or cqp not in SPLIT_BANKS.get((kh, kw), ()) or H < 1 or W < 4 or W % 4:
         return False
     P = min(16, W)
+    if problems > SPLIT_MAX_PROBLEMS and ((H + P - 1) // P) * W + P - 1 < 31:   # (two problems per compute unit: chains of >= 31 steps only)
+        return False
     nbw = sum(1 for a in range(kh) for b in range(kw) if a + b == 2)
     fixed = 8 * (64 + 8 + 1 + 8) * 16 + 2 * nbw * 1024 + (cqp // 4) * 8 * 1024
     if not (P >= kh - 1 and fixed + 2 * (W - P + 2) * 128 <= 160 * 1024):
@@ -159,7 +161,7 @@ def problem_counts_for_row(rows, r):
     i = rows[r]
     shape = (i["cqp"], i["kh"], i["kw"])
     edges = sorted({x["max_problems"] for x in rows if (x["cqp"], x["kh"], x["kw"]) == shape and x["max_problems"] > 0})
-    cands = [1, 2, 3, 4, 6, 8, 257, 258, 259, 260, 262, 264]
+    cands = [1, 2, 3, 4, 6, 8, 257, 258, 259, 260, 262, 264, 513, 514, 515, 516, 518, 520]   # (beyond the role-split kernel's 256 and its short-step form's 512)
     for e in edges:
         cands += [e - 2, e - 1, e, e + 1, e + 2, e + 4]
     hits = [n for n in sorted(set(cands)) if n > 0 and pick_row(rows, *shape, n) == r]

@@ -762,8 +762,9 @@ def test_affine_fold_into_the_inverse(shape, dev):
 # (B, C, H, W, K): problem sets the helper-wave form takes (B*4 > 256 -- > 512 on the 24-channel 3x3 bank, whose small-batch
 # variant comes first --, % 4 == 0, W % 16 == 0); C = 88 runs on the padded 24-channel bank (Cq = 22: the last group of four
 # carries two masked channels)
-PREMULTIPLIED_CASES = [(132, 96, 64, 64, 3), (72, 48, 32, 32, 3), (65, 64, 48, 48, 3), (130, 88, 20, 48, 3), (80, 32, 35, 16, 3),
-                       (70, 48, 33, 32, 2)]
+# (round 5: the banks of up to 16 channels stay on the short-step kernel up to 512 problems: their cases moved beyond that)
+PREMULTIPLIED_CASES = [(132, 96, 64, 64, 3), (132, 48, 32, 32, 3), (129, 64, 48, 48, 3), (130, 88, 20, 48, 3), (136, 32, 35, 16, 3),
+                       (130, 48, 33, 32, 2)]
 
 
 @pytest.mark.parametrize("shape", PREMULTIPLIED_CASES, ids=lambda c: "B%d_C%d_%dx%d_k%d" % c)
@@ -787,7 +788,7 @@ def test_inverse_of_a_premultiplied_input(shape, dev):
         x_ref = unit.reverse(z)
     assert x_pre is not None
     assert rel_err(x_pre.cpu().numpy(), x_ref.cpu().numpy()) <= TOL
-    if B * C * H * W <= 72 * 48 * 32 * 32:           # (the oracle on the big cases takes minutes: they are pinned through x_ref)
+    if B * C * H * W <= 136 * 48 * 32 * 32:          # (the oracle on the big cases takes minutes: they are pinned through x_ref)
         wco = oracle.canonicalize(torch.cat(ws).detach().cpu().numpy(), 4, ORIENT_FASTFLOW)
         assert rel_err(x_pre.cpu().numpy(), oracle.inverse_via_f64(z.cpu().numpy(), wco)) <= TOL
     assert _lib.hlp_timeouts() == 0
