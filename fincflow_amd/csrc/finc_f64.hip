@@ -22,11 +22,13 @@ namespace {
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 typedef unsigned v2u __attribute__((ext_vector_type(2)));
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
 
 constexpr unsigned OFF_INVALID = 0x80000000u;     // voffset beyond any slab: buffer loads return 0, stores are dropped
 constexpr unsigned OFF_BAD_CHANNEL = 0x40000000u;
 
 constexpr int XS = 6;             // x ring slots: taps reach back KH + KW - 2 <= 4 steps
+constexpr int WPW = 4;            // inverse: problems (= waves) per workgroup
 
 template <int CQP, int KH, int KW>
 struct DCfg {
@@ -86,16 +88,22 @@ __global__ void pack_f64_kernel(const double *__restrict__ wc, double *__restric
 // inverse: grid = B*G one-wave workgroups
 // -----------------------------------------------------------------------------------------------
 template <int CQP, int KH, int KW>
-__global__ __launch_bounds__(64) void finc_f64_inverse_kernel(const double *__restrict__ in, const double *__restrict__ packed,
-                                                              double *__restrict__ out, int G, int CQ, int H, int W, int P, int T,
-                                                              unsigned orient, int DF)
+__global__ __launch_bounds__(64 * WPW, 1) void finc_f64_inverse_kernel(const double *__restrict__ in, const double *__restrict__ packed,
+                                                                      double *__restrict__ out, int G, int CQ, int H, int W, int P, int T,
+                                                                      unsigned orient, int DF, int nprob, int wpw)
 {
     using C = DCfg<CQP, KH, KW>;
     constexpr int MT = C::MT, NK = C::NK, CELL = C::CELL, HROWS = C::HROWS;
-    extern __shared__ __attribute__((aligned(16))) double ldsd[];
+    extern __shared__ __attribute__((aligned(16))) double lds_all[];
+    // wpw (<= WPW, as many as the LDS holds) independent problems per workgroup, one wave each: the waves of ONE workgroup go to the four SIMDs in turn, one-wave
+    // workgroups do not (two of them on one SIMD halve each other: 2.9 against 2.1 ms at c3)
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int bg = (int)blockIdx.x * wpw + wave;
+    if (bg >= nprob) return;
+    double *const ldsd = lds_all + (size_t)wave * (C::lds_bytes(DF) / 8);
     char *const ldsb = reinterpret_cast<char *>(ldsd);
-    const int lane = threadIdx.x, q = lane >> 4, p = lane & 15;
-    const int bg = (int)blockIdx.x, g = bg % G;
+    const int lane = threadIdx.x & 63, q = lane >> 4, p = lane & 15;
+    const int g = bg % G;
     const unsigned o = finc_group_orient(orient, g);
     const bool fh = (o & FINC_FLIP_H) != 0, fw = (o & FINC_FLIP_W) != 0;
     const int HW = H * W;
@@ -103,7 +111,7 @@ __global__ __launch_bounds__(64) void finc_f64_inverse_kernel(const double *__re
     const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc((void *)(in + (size_t)bg * CQ * HW), 0, (int)slab_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rout = __builtin_amdgcn_make_buffer_rsrc((void *)(out + (size_t)bg * CQ * HW), 0, (int)slab_bytes, 0x00020000);
 
-    for (int i = lane; i < C::lds_bytes(DF) / 8; i += 64) ldsd[i] = 0.0;
+    for (int i = lane; i < C::lds_bytes(DF) / 8; i += 64) ldsd[i] = 0.0;      // (the wave's own part: no barrier anywhere)
 
     // the bank: registers for the whole kernel
     double fr[C::NTAP][NK][MT];
@@ -143,6 +151,7 @@ __global__ __launch_bounds__(64) void finc_f64_inverse_kernel(const double *__re
         }
     };
     request(c, row);
+    const bool W4 = (W & 3) == 0;                // rows of whole 32-byte groups
     int slot = 0;                                // t mod XS
     int fpush = 0;                               // t mod DF
     for (int t = 0; t < T; ++t) {
@@ -199,7 +208,24 @@ __global__ __launch_bounds__(64) void finc_f64_inverse_kernel(const double *__re
 #pragma unroll
             for (int j = 0; j < NK; ++j) st(push_cell + fpush * C::FSLOT + j * 8, xs[j]);
         }
-        {
+        if (W4) {
+            // 32-byte pieces: a lane stores a group of four canonical columns when it has solved the last one -- the three before sit
+            // in the ring's last slots at its own lane.  (8-byte stores, 100 M of them at c3, bound the kernel at 2.9 ms: every wave
+            // keeps 384 partially written lines open, more than the L2s hold.)
+            const bool ok = started && row < H && (c & 3) == 3;
+            const unsigned base = ok ? pix_off(row, fw ? c : c - 3) : OFF_INVALID;
+            int s1 = slot - 1, s2 = slot - 2, s3 = slot - 3;
+            s1 = s1 < 0 ? s1 + XS : s1; s2 = s2 < 0 ? s2 + XS : s2; s3 = s3 < 0 ? s3 + XS : s3;
+            const int own = C::RING_B + lane * CELL;
+#pragma unroll
+            for (int j = 0; j < NK; ++j) {
+                const double x3 = ld(own + s3 * (64 * CELL) + j * 8), x2 = ld(own + s2 * (64 * CELL) + j * 8), x1 = ld(own + s1 * (64 * CELL) + j * 8);
+                const double lo0 = fw ? xs[j] : x3, lo1 = fw ? x1 : x2, hi0 = fw ? x2 : x1, hi1 = fw ? x3 : xs[j];
+                const v2u a0 = __builtin_bit_cast(v2u, lo0), a1 = __builtin_bit_cast(v2u, lo1), b0 = __builtin_bit_cast(v2u, hi0), b1 = __builtin_bit_cast(v2u, hi1);
+                __builtin_amdgcn_raw_buffer_store_b128((v4u){a0.x, a0.y, a1.x, a1.y}, rout, base + chan_off[j], 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128((v4u){b0.x, b0.y, b1.x, b1.y}, rout, base + chan_off[j] + 16, 0, 0);
+            }
+        } else {
             const bool ok = started && row < H;
             const unsigned base = ok ? pix_off(row, c) : OFF_INVALID;
 #pragma unroll
@@ -272,7 +298,7 @@ __global__ __launch_bounds__(64) void finc_f64_forward_kernel(const double *__re
     }
 }
 
-typedef void (*f64inv_fn)(const double *, const double *, double *, int, int, int, int, int, int, unsigned, int);
+typedef void (*f64inv_fn)(const double *, const double *, double *, int, int, int, int, int, int, unsigned, int, int, int);
 typedef void (*f64fwd_fn)(const double *, const double *, double *, int, int, int, int, unsigned);
 struct DInst {
     int cqp, kh, kw, nfrag, lds_fixed, fslot;
@@ -330,10 +356,13 @@ int finc_f64_launch(const double *in, const double *wc, double *out, void *packe
         const int P = s.W < 16 ? s.W : 16;
         const int NB = (s.H + P - 1) / P;
         const int DF = f64_fifo_depth(s.W, P, s.KH, s.KW);
-        const size_t lds = (size_t)i->lds_fixed + (size_t)DF * i->fslot;
+        const size_t per_wave = (size_t)i->lds_fixed + (size_t)DF * i->fslot;
+        int wpw = WPW;
+        while (wpw > 1 && per_wave * wpw > 160 * 1024) wpw >>= 1;
+        const size_t lds = per_wave * wpw;
         if (int e = finc_ensure_dynamic_lds((const void *)i->inv, lds)) return e;
-        hipLaunchKernelGGL(i->inv, dim3(s.B * s.G), dim3(64), lds, st, in, (const double *)packed, out, s.G, s.Cq, s.H, s.W, P, NB * s.W + P - 1,
-                           s.orient, DF);
+        hipLaunchKernelGGL(i->inv, dim3((s.B * s.G + wpw - 1) / wpw), dim3(64 * wpw), lds, st, in, (const double *)packed, out, s.G, s.Cq, s.H, s.W, P,
+                           NB * s.W + P - 1, s.orient, DF, s.B * s.G, wpw);
     }
     FINC_CHECK_LAUNCH();
     return FINC_OK;

@@ -230,3 +230,78 @@ def test_band_split_beside_a_kernel_that_fills_the_chip(dev):
         assert torch.equal(o, outs[0])
     assert rel_err(outs[0].cpu().numpy(), wb.cpu().numpy()) <= TOL
     assert _lib.hlp_timeouts() == 0 and not _lib.fault_pending()
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Double precision on the matrix cores (finc_f64.hip): FINC_ALGO_AUTO for float64 tensors
+# ---------------------------------------------------------------------------------------------------------------------------------
+def _oracle_f64_unit(z, wco, G, orient, Cq):
+    """The reference-order fp64 solve per group in its own orientation (flip in, flip out: layers/conv.py:113-163)."""
+    ref = np.empty_like(z)
+    for g in range(G):
+        og = (orient >> (2 * g)) & 3
+        sl = slice(g * Cq, (g + 1) * Cq)
+        zc = z[:, sl]
+        if og & 1:
+            zc = zc[:, :, :, ::-1]
+        if og & 2:
+            zc = zc[:, :, ::-1, :]
+        xc = oracle.inverse_f64(np.ascontiguousarray(zc), wco[sl], 1)
+        if og & 1:
+            xc = xc[:, :, :, ::-1]
+        if og & 2:
+            xc = xc[:, :, ::-1, :]
+        ref[:, sl] = xc
+    return ref
+
+
+# (B, G, Cq, H, W, K, orient or None = FastFlow's): every bank of finc_f64.hip, padded channel counts, one band / several / a partial
+# last one, W < 16 (fewer rows than lanes), W == 16, wide maps, every orientation, the c2 and c3 banks at their map sizes
+F64_CASES = [(2, 4, 12, 32, 32, 3, None), (1, 4, 24, 64, 64, 3, None), (2, 1, 5, 9, 11, 3, 0), (1, 1, 3, 7, 7, 3, 1), (2, 4, 6, 8, 12, 3, None),
+             (1, 1, 4, 6, 5, 2, 3), (3, 2, 16, 33, 16, 3, 6), (1, 4, 20, 17, 40, 3, None), (2, 4, 23, 40, 24, 3, None), (1, 3, 8, 50, 100, 3, 0x1B),
+             (2, 4, 32, 20, 36, 2, None), (1, 4, 9, 21, 4, 2, None), (4, 4, 1, 5, 8, 3, None)]
+
+
+@pytest.mark.parametrize("shape", F64_CASES, ids=lambda c: "B%d_G%d_Cq%d_%dx%d_k%d_o%s" % c)
+def test_fp64_inverse_and_forward_on_the_matrix_cores(shape, dev):
+    """finc_inverse_f64_algo / finc_forward_f64_algo under FINC_ALGO_AUTO (v_mfma_f64_16x16x4_f64, the bank folded in fp64): within
+    1e-12 of the reference-order fp64 solve (the oracle's inverse_f64 = solve_parallel_mc.pyx:77-126, bit-equal to the rebuilt
+    .pyx; the strict kernel bit-exact beside it) and of the fp64 forward; `mfma` insists on the matrix-core form."""
+    from fincflow_amd import ops
+    B, G, Cq, H, W, K, o = shape
+    orient = ORIENT_FASTFLOW if o is None else o
+    rng = np.random.default_rng(sum(shape[:6]))
+    ws = oracle.make_stored_weights(G, Cq, K, K, orient=orient, seed=3).astype(np.float64)
+    ws += 1e-9 * rng.standard_normal(ws.shape) * (ws != 0) * (ws != 1)      # (bits below fp32: a kernel that narrows anything shows)
+    wco64 = oracle.canonicalize(ws.astype(np.float32), G, orient).astype(np.float64)
+    wc = ops.canonicalize(t(ws, dev), G, orient)
+    wco = wc.cpu().numpy()
+    assert wc.dtype == torch.float64 and wco.shape == wco64.shape
+    z = rng.standard_normal((B, G * Cq, H, W))
+    ref = _oracle_f64_unit(z, wco, G, orient, Cq)
+    strict = ops.finc_inverse(t(z, dev), wc, G, orient, algo="strict").cpu().numpy()
+    assert np.array_equal(strict, ref)
+    fast = ops.finc_inverse(t(z, dev), wc, G, orient, algo="mfma").cpu().numpy()
+    auto = ops.finc_inverse(t(z, dev), wc, G, orient).cpu().numpy()
+    assert np.array_equal(fast, auto)
+    assert rel_err(fast, ref) <= 1e-12, rel_err(fast, ref)
+    zf_strict = ops.finc_forward(t(ref, dev), wc, G, orient, algo="strict").cpu().numpy()
+    zf = ops.finc_forward(t(ref, dev), wc, G, orient, algo="mfma").cpu().numpy()
+    assert rel_err(zf, zf_strict) <= 1e-13 and rel_err(zf, z) <= 1e-12, (rel_err(zf, zf_strict), rel_err(zf, z))
+
+
+@pytest.mark.parametrize("name", ["unit_c1_B2_C4_8x8_k3", "unit_B2_C8_6x9_k3", "unit_B1_C12_16x16_k3", "unit_B1_C24_8x8_k3", "unit_B2_C48_32x32_k3",
+                                  "unit_B1_C96_16x16_k3", "unit_B1_C16_12x12_k2"])
+def test_fp64_matrix_core_inverse_on_the_reference_fixtures(name, dev):
+    """The reference's own CPU path (reverse_cython: fp32 -> fp64 solve -> fp32, layers/conv.py:113-163) recorded in tests/golden:
+    the fp64 matrix-core inverse of the fixture's z, rounded to fp32 as the reference rounds, against x_rev_cython."""
+    from fincflow_amd import ops
+    from helpers import golden, unit_stored_weights
+    g = golden(name)
+    ws = unit_stored_weights(g).astype(np.float64)
+    wc = ops.canonicalize(t(ws, dev), 4, ORIENT_FASTFLOW)
+    x64 = ops.finc_inverse(t(g["z"].astype(np.float64), dev), wc, 4, ORIENT_FASTFLOW, algo="mfma").cpu().numpy()
+    x32 = x64.astype(np.float32)
+    want = g["x_rev_cython"]
+    assert rel_err(x32, want) <= 1e-7, rel_err(x32, want)
+    assert np.mean(x32 == want) >= 0.999             # (the same fp32 value wherever the fp64 results do not straddle a rounding boundary)
