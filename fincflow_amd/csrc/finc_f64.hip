@@ -222,8 +222,12 @@ __global__ __launch_bounds__(64 * WPW, 1) void finc_f64_inverse_kernel(const dou
                 const double x3 = ld(own + s3 * (64 * CELL) + j * 8), x2 = ld(own + s2 * (64 * CELL) + j * 8), x1 = ld(own + s1 * (64 * CELL) + j * 8);
                 const double lo0 = fw ? xs[j] : x3, lo1 = fw ? x1 : x2, hi0 = fw ? x2 : x1, hi1 = fw ? x3 : xs[j];
                 const v2u a0 = __builtin_bit_cast(v2u, lo0), a1 = __builtin_bit_cast(v2u, lo1), b0 = __builtin_bit_cast(v2u, hi0), b1 = __builtin_bit_cast(v2u, hi1);
+                // (s_nop 1: a store of more than 8 bytes reads its data registers a few cycles after issue; scripts/check_store_hazard.py
+                // wants two wait states before anything is written to them -- here the allocator reuses them for the next LDS read)
                 __builtin_amdgcn_raw_buffer_store_b128((v4u){a0.x, a0.y, a1.x, a1.y}, rout, base + chan_off[j], 0, 0);
+                asm volatile("s_nop 1");
                 __builtin_amdgcn_raw_buffer_store_b128((v4u){b0.x, b0.y, b1.x, b1.y}, rout, base + chan_off[j] + 16, 0, 0);
+                asm volatile("s_nop 1");
             }
         } else {
             const bool ok = started && row < H;
