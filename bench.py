@@ -833,7 +833,7 @@ def bench_unit(args):
         # multiplies the forward kernel executes: Winograd F(2,3) = 4 frequencies x 3 row taps per 2 outputs (2/3 of the direct
         # sum's), F(4,3) = 6 x 3 per 4 outputs (1/2)
         # (5x5: F(2,5) = 6 frequencies x 5 row taps per 2 outputs: 3/5)
-        fwd_flops = (alg_flops * 2 // 3 if conv_form == "winograd" else alg_flops // 2 if conv_form == "winograd4"
+        fwd_flops = (alg_flops * 2 // 3 if conv_form == "winograd" else alg_flops // 2 if conv_form in ("winograd4", "winograd4m")
                      else alg_flops * 3 // 5 if conv_form == "winograd25" else alg_flops)
         inv, fwd, smp = launch_stats(inv_per), launch_stats(fwd_per), launch_stats(smp_per)
         inv_launch_ms, fwd_launch_ms = inv["mean_ms"], fwd["mean_ms"]

@@ -59,11 +59,26 @@ extern "C" int finc_debug_clock_probe_begin(int period_us, int max_ms)
     Probe &p = g_probe[dev];
     if (p.running) return FINC_ERR_BAD_DIMS;
     if (!p.stream) {
-        FINC_HIP_TRY(hipStreamCreateWithFlags(&p.stream, hipStreamNonBlocking));
-        FINC_HIP_TRY(hipMalloc((void **)&p.d_out, sizeof(unsigned long long) * 2 * MAX_SAMPLES));
-        FINC_HIP_TRY(hipMalloc((void **)&p.d_count, sizeof(unsigned)));
-        FINC_HIP_TRY(hipHostMalloc((void **)&p.h_stop, sizeof(unsigned), hipHostMallocMapped));
-        FINC_HIP_TRY(hipHostGetDevicePointer((void **)&p.d_stop, p.h_stop, 0));
+        // (everything is allocated into locals and committed only when every step has succeeded: a half-built probe would be launched
+        // with null pointers by the next call -- ADVICE r4)
+        hipStream_t st = nullptr;
+        unsigned long long *d_out = nullptr;
+        unsigned *d_count = nullptr, *h_stop = nullptr, *d_stop = nullptr;
+        hipError_t e = hipStreamCreateWithFlags(&st, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipMalloc((void **)&d_out, sizeof(unsigned long long) * 2 * MAX_SAMPLES);
+        if (e == hipSuccess) e = hipMalloc((void **)&d_count, sizeof(unsigned));
+        if (e == hipSuccess) e = hipHostMalloc((void **)&h_stop, sizeof(unsigned), hipHostMallocMapped);
+        if (e == hipSuccess) e = hipHostGetDevicePointer((void **)&d_stop, h_stop, 0);
+        if (e != hipSuccess) {
+            finc_set_hip_error(e);
+            if (h_stop) (void)hipHostFree(h_stop);
+            if (d_count) (void)hipFree(d_count);
+            if (d_out) (void)hipFree(d_out);
+            if (st) (void)hipStreamDestroy(st);
+            return FINC_ERR_LAUNCH;
+        }
+        p.d_out = d_out; p.d_count = d_count; p.h_stop = h_stop; p.d_stop = d_stop;
+        p.stream = st;
     }
     *(volatile unsigned *)p.h_stop = 0;
     FINC_HIP_TRY(hipMemsetAsync(p.d_count, 0, sizeof(unsigned), p.stream));
@@ -88,8 +103,8 @@ extern "C" int finc_debug_clock_probe_end(double *h_stats)
     Probe &p = g_probe[dev];
     if (!p.running) return FINC_ERR_BAD_DIMS;
     *(volatile unsigned *)p.h_stop = 1;
-    p.running = false;
     FINC_HIP_TRY(hipStreamSynchronize(p.stream));
+    p.running = false;                                  // (only once the probe kernel is known to have ended)
     unsigned n = 0;
     FINC_HIP_TRY(hipMemcpy(&n, p.d_count, sizeof(unsigned), hipMemcpyDeviceToHost));
     for (int i = 0; i < 6; ++i) h_stats[i] = 0.0;

@@ -42,7 +42,9 @@ for r in _lib.inverse_table():
             res.append(a.elapsed_time(b) / 30 * 1e-3)
     flops = 2.0 * B * C * H * W * K * K * Cq
     v = _lib.inverse_variant(B, 4, Cq, H, W, K, K)
+    # (the forward's figure is DIRECT-EQUIVALENT flops over time: the Winograd forms execute 1/2 .. 2/3 of those multiplies, so it can
+    # exceed 100 % -- it is a speed relative to the direct sum's roof, not a utilisation)
     print(f"Cq={Cq:3d} K={K} B={B:3d}: inverse {res[0]*1e6:8.1f} us = {flops/res[0]/PEAK:5.1%} of fp32 peak (nw {v['nw']} form {v['sec']}) | "
-          f"forward {res[1]*1e6:8.1f} us = {flops/res[1]/PEAK:5.1%} | round trip {err:.1e}", flush=True)
+          f"forward {res[1]*1e6:8.1f} us = {flops/res[1]/PEAK:5.1%} direct-equivalent | round trip {err:.1e}", flush=True)
     del unit, x, z, o, xr
     torch.cuda.empty_cache()
