@@ -11,11 +11,14 @@ workload, path = sys.argv[1], sys.argv[2]
 from bench import WORKLOADS
 B, C, H, W, K, std = WORKLOADS[workload]
 s = json.load(open(path))
-inv = s.get("inverse") or s[[k for k in s if "inverse" in k or "split" in k or "chain" in k or "wave" in k][0]]
+# the workload's inverse kernel: the wavefront kernel ("inverse"), else the role-split / short-step one
+inv = s.get("inverse") or s.get("inverse_chain") or s.get("inverse_split")
+kernel_class = "inverse" if "inverse" in s else "inverse_chain" if "inverse_chain" in s else "inverse_split"
 fetch, write = inv["FETCH_SIZE"] * 1024.0, inv["WRITE_SIZE"] * 1024.0
 alg = 8 * B * C * H * W + 4 * C * (C // 4) * K * K
 out = {
     "workload": workload,
+    "kernel_class": kernel_class,
     "inverse_hbm_bytes_per_launch": int(round(fetch + write)),
     "inverse_fetch_bytes": int(round(fetch)),
     "inverse_write_bytes": int(round(write)),

@@ -9,6 +9,8 @@ for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursiv
             k = "inverse"
         elif "finc_split_kernel" in k:
             k = "inverse_split"
+        elif "finc_chain_kernel" in k:
+            k = "inverse_chain"
         elif "finc_conv_kernel" in k:
             k = "forward"
         elif "finc_wino4m_kernel" in k:

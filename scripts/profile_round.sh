@@ -26,16 +26,19 @@ if [ "$WHAT" = "benches" ]; then
   python3 scripts/f3_measure.py > gpurun_out/${TAG}/f3.json 2>> gpurun_out/${TAG}/bench.err
   python3 scripts/debug_big.py time > gpurun_out/${TAG}/big_banks.txt 2>> gpurun_out/${TAG}/bench.err
   python3 scripts/time_small.py > gpurun_out/${TAG}/small_batch.txt 2>> gpurun_out/${TAG}/bench.err
+  python3 scripts/time_f64.py > gpurun_out/${TAG}/fp64_mfma.txt 2>> gpurun_out/${TAG}/bench.err
+  scripts/chain_vs_split.sh > gpurun_out/${TAG}/chain_vs_split.txt 2>> gpurun_out/${TAG}/bench.err
+  scripts/tiny_prof2.sh > gpurun_out/${TAG}/tiny_maps_kernel_time.txt 2>> gpurun_out/${TAG}/bench.err
   echo "other timings done"
   cd /tmp && export TMPDIR=/tmp
-  for w in c3 c3_share8 c5; do
+  for w in c3 c2 c3_share8 c5; do
     rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/${TAG}_prof_$w -- python3 $ROOT/bench.py --workload $w --no-cpu --no-share --no-clock > $ROOT/gpurun_out/${TAG}/bench_${w}_under_rocprof.json 2> $ROOT/gpurun_out/${TAG}/prof_$w.err
     cp $(find $ROOT/gpurun_out/${TAG}_prof_$w -name "*kernel_stats.csv" | head -1) $ROOT/gpurun_out/${TAG}/${w}_kernel_stats.csv
     rm -rf $ROOT/gpurun_out/${TAG}_prof_$w
     echo "rocprof $w done"
   done
 else
-  for w in c3 c3_share8 c5; do
+  for w in c3 c2 c3_share8 c5; do
     scripts/pmc_run.sh ${TAG}_$w --workload $w --no-clock > gpurun_out/${TAG}/pmc_$w.log 2>&1
     cp gpurun_out/pmc_${TAG}_$w/summary.json gpurun_out/${TAG}/${w}_pmc_summary.json
     rm -rf gpurun_out/pmc_${TAG}_$w
