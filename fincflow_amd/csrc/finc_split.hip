@@ -171,16 +171,29 @@ __global__ __launch_bounds__(64 * (1 + NBW)) void finc_split_kernel(const float 
     const unsigned orient = BSP ? ka[12] : a_orient;
     unsigned *const fault_word = BSP ? (unsigned *)karg_p(18) : a_fault_word;
     int slot_id = (int)blockIdx.x;
+    float *const ctrl = lds + C::LDS_BYTES / 4;   // BSP: two words behind the kernel's own LDS (the launch allocates 82 KB): ticket, bands of this job
     if constexpr (BSP) {
-        if (threadIdx.x == 0) lds[0] = __builtin_bit_cast(float, __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        // a job's CLAIM word ([2 + job]) says a running workgroup owns it: set by the workgroup that drew its ticket, or by the one
+        // that extended its own job to it (below).  A drawn ticket whose job is already claimed is skipped.
+        if (threadIdx.x == 0) {
+            int tk;
+            for (;;) {
+                tk = (int)__hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (tk >= nwg * nprob) break;
+                unsigned expect = 0u;
+                if (__hip_atomic_compare_exchange_strong(sync + 2 + tk, &expect, 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+            }
+            ctrl[0] = __builtin_bit_cast(float, tk);
+        }
         __syncthreads();
-        slot_id = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, lds[0]));
+        slot_id = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ctrl[0]));
         __syncthreads();
         if (slot_id >= nwg * nprob) break;     // no band left
     }
-    const int wg = BSP ? slot_id / nprob : 0;
+    const int wg = BSP ? slot_id / nprob : 0;  // BSP: the image band of this job (its first one)
     const int bg = BSP ? slot_id - wg * nprob : slot_id, g = bg % G;
-    const int band_rows = BSP ? nwg * P : P;   // rows from a band of this workgroup to its next one
+    constexpr int BSTRIDE = 2;                 // BSP: a job that is extended continues with band wg + BSTRIDE
+    const int band_rows = BSP ? BSTRIDE * P : P;   // rows from a band of this workgroup to its next one
     const int row0 = BSP ? wg * P : 0;         // first row of its first band
     const unsigned o = finc_group_orient(orient, g);
     const bool fh = (o & FINC_FLIP_H) != 0, fw = (o & FINC_FLIP_W) != 0;
@@ -231,10 +244,40 @@ __global__ __launch_bounds__(64 * (1 + NBW)) void finc_split_kernel(const float 
         int fpush = 0;
         int fpop = ((-(W - P)) % DF + DF) % DF;
         int tm = 0;                            // t % W
+        int Tj = T;                            // steps of this job
         if constexpr (BSP && KH > 1) {
+            // EXTENSION.  A job is one band; a workgroup that went from band k to band k + 2 without a restart would save the restart
+            // (ticket, LDS clear, fragment and first-z loads, the rounding of the step count: ~17 us) -- the round-4 form did, by
+            // dealing the bands cyclically, and paid with a wait on a workgroup that might not be running.  Here the workgroup takes
+            // band k + 2 as well only if band k + 1 is CLAIMED: then whoever owns it runs, and every wait of this job is on a running
+            // workgroup (band k + 1's owner needs band k, which this workgroup solves first).  At a launch on an idle chip every
+            // ticket is drawn within microseconds, so the pairs {k, k + 2} form; beside another tenant the jobs stay single bands.
+            if (lane == 0) {
+                int nbl = 1;
+                const int NBi = (H + P - 1) / P;
+                // (only when the bands outnumber the workgroups: with every band resident at once four single bands trail each other by
+                // 32 steps, a pair's second band trails the other pair's first by 44 -- c3 at 16 images: 130 against 137 us)
+                if (wg + BSTRIDE < NBi && nwg * nprob > (int)gridDim.x) {
+                    bool claimed = false;
+                    for (int tries = 0; tries < 6 && !claimed; ++tries) {
+                        claimed = __hip_atomic_load(sync + 2 + (wg + 1) * nprob + bg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
+                        if (!claimed) __builtin_amdgcn_s_sleep(8);
+                    }
+                    unsigned expect = 0u;
+                    if (claimed && __hip_atomic_compare_exchange_strong(sync + 2 + (wg + BSTRIDE) * nprob + bg, &expect, 1u, __ATOMIC_RELAXED,
+                                                                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))
+                        nbl = 2;
+                }
+                ctrl[1] = __builtin_bit_cast(float, nbl);
+            }
             // the first band of this workgroup may have real rows above it (image band wg >= 1): the B waves have just landed their
             // first pieces in the FIFO -- S_1(-1) of lane 0 is the pixel above column 0, the push of virtual step -1
             __syncthreads();
+            {
+                const int nbl = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ctrl[1]));
+                const int Traw = nbl * W + P - 1;
+                Tj = (Traw + 2 + UNROLL - 1) / UNROLL * UNROLL - 2;
+            }
             float fv0[NK];
             const int fp0 = fpop == 0 ? DF - 1 : fpop - 1;
 #pragma unroll
@@ -244,7 +287,7 @@ __global__ __launch_bounds__(64 * (1 + NBW)) void finc_split_kernel(const float 
         }
         __syncthreads();                       // (iteration t = -1: the B waves prepare step 0)
         unsigned long long st_busy = 0;
-        for (int t = 0; t <= T; ++t) {
+        for (int t = 0; t <= Tj; ++t) {
             FINC_ST_BEGIN();
             const int par = t & 1, slot = t & (XSLOTS - 1);
             float fv[NK];
@@ -400,11 +443,12 @@ __global__ __launch_bounds__(64 * (1 + NBW)) void finc_split_kernel(const float 
     const int drow = (fh ? -band_rows : band_rows) * W * 4 - (dgrp / 4) * W;   // ... and from the end of a row to the start of the same lane's next row
     auto piece_off = [&](int row, int col0) { return ((fh ? H - 1 - row : row) * W + (fw ? W - 4 - col0 : col0)) * 4; };
     // load walk: next group to request (starts at group f); store walk: next group to store (starts at group fs)
+    int nbl = 1, row_lim = H;                  // BSP: bands of this job; rows beyond its last band belong to another workgroup
     int lcol = 4 * f4, lrow = row0 + p, loff = piece_off(row0 + p, 0) + f4 * dgrp;
     int scol = 4 * fs4, srow = row0 + p, soff = piece_off(row0 + p, 0) + fs4 * dgrp;
     v4f zin[2][NJ > 0 ? NJ : 1];               // in flight: the set of window parity wp is requested in the windows of parity wp
     auto zreq = [&](v4f (&dst)[NJ > 0 ? NJ : 1]) {
-        const bool ok = lcol >= 0 && lrow < H && p < P;
+        const bool ok = lcol >= 0 && lrow < row_lim && p < P;
         const unsigned base = ok ? (unsigned)loff : OFF_INVALID;
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
@@ -436,7 +480,7 @@ __global__ __launch_bounds__(64 * (1 + NBW)) void finc_split_kernel(const float 
     const int xs2 = C::RING_B + (((p + e2) & 7) * 64 + lane) * 4, xs3 = C::RING_B + (((p + e3) & 7) * 64 + lane) * 4;
     int stog = (fs4 & 1) * 1024;               // toggles with the group
     auto xstore = [&]() {
-        const bool ok = scol >= 0 && srow < H && p < P;
+        const bool ok = scol >= 0 && srow < row_lim && p < P;
         const unsigned base = ok ? (unsigned)soff : OFF_INVALID;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
@@ -462,7 +506,7 @@ __global__ __launch_bounds__(64 * (1 + NBW)) void finc_split_kernel(const float 
     // already (the others do nothing; step 2 stores the whole instruction again, which is harmless): its completion is then
     // covered by the window's one counted wait at step 3, and the progress word says so four steps sooner.
     auto xstore_early = [&]() {
-        const bool ok = scol >= 0 && srow < H && p >= P - (KH - 1) && p < P;
+        const bool ok = scol >= 0 && srow < row_lim && p >= P - (KH - 1) && p < P;
         const unsigned base = ok ? (unsigned)soff : OFF_INVALID;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
@@ -489,10 +533,13 @@ __global__ __launch_bounds__(64 * (1 + NBW)) void finc_split_kernel(const float 
     int hslot = BSP ? (((-W + P - 1 - p) % DF) + DF) % DF : 0;            // slot of the first element of the next piece to LAND
     v4f hin[NJ > 0 ? NJ : 1];
     int seen = 0;                                                          // producer progress read so far
-    const int wgp = BSP ? (wg + nwg - 1) % nwg : 0;
     const int NBimg = (H + P - 1) / P;
-    const __amdgpu_buffer_rsrc_t rsync = __builtin_amdgcn_make_buffer_rsrc((void *)sync, 0, BSP ? (2 + nprob * nwg * NBW) * 4 : 0, 0x00020000);
-    const unsigned my_flag = (unsigned)(2 + (bg * nwg + wg) * NBW + bi) * 4u, its_flag = (unsigned)(2 + (bg * nwg + wgp) * NBW + bi) * 4u;
+    // progress words: one per (problem, image band, B wave) behind the claim words = that wave's store windows complete, counted from
+    // the start of THAT band
+    const int nwords = BSP ? 2 + nprob * nwg + nprob * nwg * NBW : 0;
+    const __amdgpu_buffer_rsrc_t rsync = __builtin_amdgcn_make_buffer_rsrc((void *)sync, 0, nwords * 4, 0x00020000);
+    auto band_word = [&](int band) { return (unsigned)(2 + nprob * nwg + (bg * nwg + band) * NBW + bi) * 4u; };
+    unsigned its_flag = BSP && wg >= 1 ? band_word(wg - 1) : 0u;
     unsigned seen_raw = 0;                     // the progress word as last fetched (asynchronously, once per window)
     auto progress_fetch = [&]() {              // (no wait: the value is read by progress_take, behind the window's one vmcnt wait)
         asm volatile("buffer_load_dword %0, %1, %2, 0 offen sc0 sc1" : "=v"(seen_raw) : "v"(its_flag), "s"(rsync) : "memory");
@@ -518,22 +565,32 @@ __global__ __launch_bounds__(64 * (1 + NBW)) void finc_split_kernel(const float 
             if (fault_word) __hip_atomic_store(fault_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
     };
-    auto publish = [&](int windows_done) {
-        if (lane == 0) {
-            const unsigned v = (unsigned)windows_done;
-            asm volatile("buffer_store_dword %0, %1, %2, 0 offen sc0 sc1" ::"v"(v), "v"(my_flag), "s"(rsync) : "memory");
-        }
+    // windows_done counts this job's windows; local band i began at window i * W / 4: lane 0 says it for the band that has begun last,
+    // lane 1 for the one before (whose last rows are still leaving); `all`: every band of the job is complete
+    auto publish = [&](int windows_done, bool all) {
+        const int GR = W >> 2;
+        int i1 = windows_done / GR;
+        i1 = i1 > nbl - 1 ? nbl - 1 : i1;
+        const int bi_l = i1 - lane;                                        // lane 0: band i1, lane 1: band i1 - 1
+        const bool act = lane < 2 && bi_l >= 0;
+        const unsigned v = all ? 0x7FFFFFFFu : (unsigned)(windows_done - bi_l * GR);
+        const unsigned off = act ? band_word(wg + bi_l * BSTRIDE) : OFF_INVALID;
+        asm volatile("buffer_store_dword %0, %1, %2, 0 offen sc0 sc1" ::"v"(v), "v"(off), "s"(rsync) : "memory");
     };
     auto hreq = [&]() {
-        const int kb = wg + hband * nwg;                                   // the image band these rows sit above
-        const bool live = kb >= 1 && kb < NBimg;                           // (band 0: the zero rows above the image; beyond: nothing)
-        if (live) progress_wait(((kb - 1) / nwg) * (W >> 2) + (hcol >> 2) + 6);
+        const int kb = wg + hband * BSTRIDE;                               // the image band these rows sit above
+        const bool live = kb >= 1 && kb < NBimg && hband < nbl;            // (band 0: the zero rows above the image; beyond: nothing)
+        if (live) progress_wait((hcol >> 2) + 6);
         const unsigned base = (live && hl) ? (unsigned)hoff : OFF_INVALID;
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
             asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen sc0 sc1" : "=v"(hin[j]) : "v"(base + xmask[j]), "s"(rout) : "memory");
         hcol += 4; hoff += dgrp;
-        if (hcol == W) { hcol = 0; ++hband; hoff += drow; }
+        if (hcol == W) {                       // on to the rows above this job's next band: another producer, another word
+            hcol = 0; ++hband; hoff += drow;
+            seen = 0;
+            its_flag = band_word(wg + hband * BSTRIDE - 1);
+        }
     };
     auto hland = [&]() {                       // (the caller has waited for the loads)
 #pragma unroll
@@ -566,7 +623,14 @@ __global__ __launch_bounds__(64 * (1 + NBW)) void finc_split_kernel(const float 
             hland();
         }
     }
-    if constexpr (BSP) __syncthreads();        // every B wave's first piece of the rows above is in the FIFO (the taps read all k-steps)
+    int Tj = T;                                // steps of this job
+    if constexpr (BSP) {
+        __syncthreads();                       // every B wave's first piece of the rows above is in the FIFO (the taps read all k-steps)
+        nbl = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ctrl[1]));   // (A's decision: see there)
+        const int last_row = (wg + (nbl - 1) * BSTRIDE + 1) * P;
+        row_lim = last_row < H ? last_row : H;
+        Tj = (nbl * W + P - 1 + 2 + UNROLL - 1) / UNROLL * UNROLL - 2;
+    }
     // z read address: slot (n mod 12) of this lane
     int zn = ((-p) % 12 + 12) % 12;
 
@@ -633,7 +697,7 @@ __global__ __launch_bounds__(64 * (1 + NBW)) void finc_split_kernel(const float 
             asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NJ) : "memory");
             progress_take();
             hland();
-            publish(((t + 1) >> 2) + 1);       // the handed-over stores of the windows 0 .. w are complete: w + 1 windows
+            publish(((t + 1) >> 2) + 1, false); // the handed-over stores of the windows 0 .. w are complete: w + 1 windows
         }
         if constexpr (NJ > 0 && PH == 0 && !BSP) {
             // younger than the set that lands: the other set's requests (NJ) and the stores of the two windows in between
@@ -711,7 +775,7 @@ __global__ __launch_bounds__(64 * (1 + NBW)) void finc_split_kernel(const float 
     };
     // iterations t = -1 .. T (u = t + 1 = 0 .. T + 1), unrolled by UNROLL: the host rounds T up so that T + 2 is a multiple of
     // it (the extra steps solve rows below the image: nothing is stored)
-    for (int t0 = -1; t0 < T; t0 += UNROLL) {
+    for (int t0 = -1; t0 < Tj; t0 += UNROLL) {
         [&]<int... K>(std::integer_sequence<int, K...>) { ((bstep(IC<K>{}, t0 + K)), ...); }(std::make_integer_sequence<int, UNROLL>{});
     }
     // (the last window's store covers the last group of every lane: T + 1 >= NB*W + P and P/4 + fs >= -1)
@@ -719,7 +783,7 @@ __global__ __launch_bounds__(64 * (1 + NBW)) void finc_split_kernel(const float 
         // the stores of the last windows are not yet accounted for in the progress word (a window's stores are said complete two
         // windows later, and the loop ends with them): the consumer of this workgroup's LAST band waits for exactly those
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        publish(0x7FFFFFFF);
+        publish((nbl - 1) * (W >> 2), true);
     }
     if constexpr (BSP) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (its last word is out before the workgroup moves on or says "done")
 #ifdef FINC_SPLIT_STAMP
@@ -751,7 +815,7 @@ __global__ __launch_bounds__(64 * (1 + NBW)) void finc_split_kernel(const float 
             if (lane == 0) done = __hip_atomic_fetch_add(sync + 1, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
             done = __builtin_amdgcn_readfirstlane(done);
             if (done == gridDim.x - 1) {
-                const int nwords = 2 + nprob * nwg * NBW;
+                const int nwords = 2 + nprob * nwg + nprob * nwg * NBW;
                 for (int i = 2 + lane; i < nwords; i += 64) __hip_atomic_store(sync + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
                 if (lane == 0) {
@@ -867,7 +931,7 @@ int bsp_nwg(const SInst &i, const FincShape &s)
     const int NB = (s.H + P - 1) / P;
     const long long problems = (long long)s.B * s.G;
     if (bsp_off() || i.kh < 2 || NB < 2 || s.W < 64 || 2 * problems > device_cus()) return 1;
-    if (2 + problems * NB * i.nbw > BSP_SLOT_WORDS) return 1;
+    if (2 + problems * NB * (1 + i.nbw) > BSP_SLOT_WORDS) return 1;          // ticket, done, one claim word and NBW progress words per band
     return NB;
 }
 
