@@ -26,19 +26,22 @@
 // lane p-1 by one step), same arithmetic (exact fp32 MFMA; only the order in which the partial sums of a pixel are added
 // differs).  Any Cq <= CQP (padded channels are masked per k-step) and any W (dword I/O: no alignment rule).
 //
-// BSP ("bands split over workgroups", round 4): with problems to spare CUs for -- B*G <= half the compute units: c3 at the 32
-// images an 8-way strong split leaves a GPU -- ONE problem still is a chain of NB*W + P - 1 steps on one CU while the other
-// half of the chip idles.  The bands of 16 rows are therefore dealt out to NWG workgroups on different CUs (band k to
-// workgroup k % NWG; each workgroup chains ITS bands as before), and the one thing a band needs from the band above -- its
-// last KH-1 rows -- comes through memory: the workgroup above stores those rows like every other row (write-through), says how
-// far it got in a progress word, and the consumer's B waves fetch the pieces (past the caches) into the very FIFO slots the
-// chained form pushes them to, two windows before the first lane needs them.  Nothing else changes: same lanes, same
-// visitation inside a band (cinc_cuda_kernel_level2.cu:49-56), same arithmetic.  The dependent chain of c3 shrinks from 271
-// steps to 64 + 15 + 3 x (the hand-over lag); the lag is what the memory round trip makes it, ~34 steps.
-// Progress words live in a per-device area that the library owns (slots handed out round-robin per launch); a word is valid
-// only with the area's current EPOCH, which the last workgroup of a launch to finish advances -- so nothing is cleared
-// between launches, and a captured launch can be replayed.  Every wait is bounded; one that gives up sets the device's fault
-// word (include/finc.h) exactly like the helper-wave protocol of the wavefront kernel.
+// BSP ("bands split over workgroups", round 4; jobs since round 5): with problems to spare CUs for -- B*G <= half the compute
+// units: c3 at the 32 images an 8-way strong split leaves a GPU -- ONE problem still is a chain of NB*W + P - 1 steps on one CU
+// while the other half of the chip idles.  The bands of 16 rows are therefore JOBS: a workgroup (one per compute unit, the grid
+// is min(jobs, CUs)) draws a ticket, band-major, claims that band of that problem, solves it and draws again; the one thing a
+// band needs from the band above -- its last KH-1 rows -- comes through memory: the workgroup above stores those rows like every
+// other row (write-through), says how far it got in the BAND's progress word, and the consumer's B waves fetch the pieces (past
+// the caches) into the very FIFO slots the chained form pushes them to, two windows before the first lane needs them.  A ticket
+// is band-major, so the owner of band k-1 drew its ticket before the owner of band k: a waiter's producer runs or is done,
+// whatever the residency.  When bands outnumber the workgroups, a workgroup that holds band k goes on into band k+2 without a
+// restart if band k+1 is claimed already.  Nothing else changes: same lanes, same visitation inside a band
+// (cinc_cuda_kernel_level2.cu:49-56), same arithmetic.  The dependent chain of c3 shrinks from 271 steps to
+// 64 + 15 + 3 x (the hand-over lag); the lag is what the memory round trip makes it, ~34 steps.
+// The words (ticket, claims, progress) live in a per-device area the library owns, in slots: a STREAM owns its slot (another
+// stream takes it over only behind the event of the slot's last launch), and the last workgroup of a launch to finish zeroes
+// the launch's words -- so nothing is cleared between launches and a captured launch can be replayed.  Every wait is bounded;
+// one that gives up sets the device's fault word (include/finc.h) exactly like the helper-wave protocol of the wavefront kernel.
 #include "finc_common.h"
 #include "finc_tile.h"
 

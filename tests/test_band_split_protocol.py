@@ -12,8 +12,9 @@ The wait graph is a chain (band k on band k - 1, band 0 on nobody), so the proto
 started workgroup keeps running -- also when only `resident` workgroups fit the chip at a time and the others start as slots free up
 (in ticket order).  The model runs that: it must complete for every map, narrow ones included (the round-4 form, two workgroups per
 problem chaining alternate bands, dead-locked below 52 columns and relied on both being resident: VERDICT r4 weak 6).  A stale word can no longer be taken for
-progress: the launch's words (ticket counter included) are zeroed by a memset node in front of it, and a slot is reused only behind
-the event of its last launch (tests/test_gpu_round5.py runs two streams and a graph replay beside eager launches).
+progress: the last workgroup of a launch zeroes the launch's words (ticket counter included) before it leaves, and a STREAM owns its
+slot of words -- another stream takes a slot over only behind the event of its last launch (tests/test_gpu_round5.py runs two streams
+and a graph replay beside eager launches).
 
 Extension (when the bands outnumber the workgroups): a workgroup that holds band k takes band k + 2 as well -- no restart between them
 -- but only if band k + 1 is already CLAIMED, i.e. owned by a running workgroup.  The wait graph stays acyclic in time: the owner of
