@@ -190,19 +190,21 @@ __global__ __launch_bounds__(64 * (2 + NBW)) void finc_chain_kernel(const float 
     const unsigned long long st_entry = __builtin_amdgcn_s_memtime();
 #endif
 
-    {
-        const int n16 = C::lds_bytes(DF) / 16;
-        for (int i = threadIdx.x; i < n16; i += 64 * (2 + NBW)) {
-            reinterpret_cast<v4f *>(ldsb)[i] = (v4f){0.f, 0.f, 0.f, 0.f};
+    // Everything but the z ring starts as zeros (a slab of the z ring is written by its request before anything reads it -- lanes
+    // whose piece lies outside the image get zeros from the buffer unit), so the I/O wave takes no part in the clear: its first
+    // requests are under way while the other waves clear and gather their fragments; barrier (2) closes both.
+    auto clear_lds = [&]() {                    // (called by the A and B waves once their fragment loads are in flight)
+        constexpr int Z0 = C::ZR_B / 16, Z1 = C::FIFO_B / 16;
+        const int n16 = C::lds_bytes(DF) / 16 - (Z1 - Z0);
+        for (int i = threadIdx.x - 64; i < n16; i += 64 * (1 + NBW)) {
+            reinterpret_cast<v4f *>(ldsb)[i < Z0 ? i : i + (Z1 - Z0)] = (v4f){0.f, 0.f, 0.f, 0.f};
         }
-    }
+    };
     const float *pk = packed + (size_t)g * C::NPACK * 64;
     auto tap_f0 = [&](int a, int b) { return NK * MT + (a * KW + b - 1) * NK * MT; };
     auto ld4 = [&](int byte_off) { return *reinterpret_cast<const v4f *>(ldsb + byte_off); };
     auto st4 = [&](int byte_off, v4f v) { *reinterpret_cast<v4f *>(ldsb + byte_off) = v; };
     auto ld1 = [&](int byte_off) { return *reinterpret_cast<const float *>(ldsb + byte_off); };
-
-    __syncthreads();                            // (1) LDS is zero: the DMA prologue may start
 
     if (role == 0) {
         // =================================== A: the recurrence ===================================
@@ -215,6 +217,7 @@ __global__ __launch_bounds__(64 * (2 + NBW)) void finc_chain_kernel(const float 
             f01[j] = (KW > 1 && arow_ok) ? bank_elem<MTB, MT>(pk, tap_f0(0, 1), j, q, arow) : 0.f;
             f10[j] = (KH > 1 && arow_ok) ? bank_elem<MTB, MT>(pk, tap_f0(1, 0), j, q, arow) : 0.f;
         }
+        clear_lds();
 #pragma unroll
         for (int j = 0; j < NK; ++j) {          // (the empty asm makes the compiler wait for the loads HERE, not in the loop)
             asm volatile("" : "+v"(f01[j]));
@@ -228,7 +231,7 @@ __global__ __launch_bounds__(64 * (2 + NBW)) void finc_chain_kernel(const float 
         // the push is branch-free: every lane writes, the lanes that hand nothing over into a trash copy of the FIFO behind it
         const int push_w = pusher ? C::FIFO_B + hcell : C::FIFO_B + DF * FSLOT_B + (lane & 7) * 16;
         const int push_d = pusher ? C::RING_B + 64 * 16 + hcell : C::RING_B + TRASH_CELL + (lane & 7) * 16;   // (W == P: straight into the slot's halo)
-        __syncthreads();                        // (2) the I/O wave has the first slabs
+        __syncthreads();                        // (2) LDS is zero, the I/O wave has the first slabs
         __syncthreads();                        // (3) iteration t = -1: the B waves prepare step 0
         unsigned long long st_busy = 0;
 #ifdef FINC_SPLIT_STAMP
@@ -384,6 +387,7 @@ __global__ __launch_bounds__(64 * (2 + NBW)) void finc_chain_kernel(const float 
         zreq();
         if (v & 1) xstore(IC<1>{}); else xstore(IC<0>{});
     }
+    // (the stores above were dropped: what they read from the ring, cleared or not yet, did not matter)
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NK * (2 * DPF - 3)) : "memory");
     __syncthreads();                            // (2)
     // the copy of the rows above: FIFO slot of push step (u + 1) - (W - P) -> halo of ring slot (u + 1) & 7, in iteration u - 1
@@ -409,8 +413,12 @@ __global__ __launch_bounds__(64 * (2 + NBW)) void finc_chain_kernel(const float 
         FINC_ST_END();
         __syncthreads();
     };
+    // (iterations u = 0 .. T + 1; finc_chain_launch: T + 1 = 2 mod 4, the last one is a store phase -- the unrolled body is left after its 3rd or 7th step)
     for (int t0 = -1; t0 < T; t0 += UNROLL) {
-        [&]<int... K>(std::integer_sequence<int, K...>) { ((iostep(IC<K>{})), ...); }(std::make_integer_sequence<int, UNROLL>{});
+        const bool last = [&]<int... K>(std::integer_sequence<int, K...>) {
+            return ((iostep(IC<K>{}), (K & 3) == 2 && t0 + K == T) || ...);
+        }(std::make_integer_sequence<int, UNROLL>{});
+        if (last) break;
     }
 #ifdef FINC_SPLIT_STAMP
     if (blockIdx.x == 0 && lane == 0) finc_chain_stamps[1 + NBW] = st_busy;
@@ -447,6 +455,7 @@ __global__ __launch_bounds__(64 * (2 + NBW)) void finc_chain_kernel(const float 
         for (int r = 0; r < NK; ++r) bv[r] = MTB ? pb[r * 64 + lane] : pb[(4 * r + q) * 64 + p];
         bias = (v4f){bv[0], bv[1], bv[2], bv[3]};
     }
+    clear_lds();
     asm volatile("" : "+v"(bias));              // every fragment load must have LANDED before the loop
 #pragma unroll
     for (int n = 0; n < NZ; ++n) asm volatile("" : "+v"(fz[n]));
@@ -454,7 +463,7 @@ __global__ __launch_bounds__(64 * (2 + NBW)) void finc_chain_kernel(const float 
     for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int j = 0; j < NK; ++j) asm volatile("" : "+v"(ft[i][j]));
-    __syncthreads();                            // (2) the I/O wave has the first slabs
+    __syncthreads();                            // (2) LDS is zero, the I/O wave has the first slabs
 
     // ---- operands.  S_a(tau) of tap (a, b): ring slot tau & 7 at lane p - a, or the slot's halo cell (row a - p above the band)
     // for the lanes p < a: a per-lane constant per a; the slot is the read's immediate.  A tap's column mask (b > 0: column c - b
@@ -560,10 +569,12 @@ __global__ __launch_bounds__(64 * (2 + NBW)) void finc_chain_kernel(const float 
         FINC_ST_END();
         __syncthreads();
     };
-    // iterations t = -1 .. T (u = t + 1 = 0 .. T + 1), unrolled by UNROLL: the host rounds T up so that T + 2 is a multiple of
-    // it (the extra steps solve rows below the image: nothing is stored)
+    // iterations t = -1 .. T (u = t + 1 = 0 .. T + 1), unrolled by UNROLL and left at the exact step (see the I/O wave)
     for (int t0 = -1; t0 < T; t0 += UNROLL) {
-        [&]<int... K>(std::integer_sequence<int, K...>) { ((bstep(IC<K>{})), ...); }(std::make_integer_sequence<int, UNROLL>{});
+        const bool last = [&]<int... K>(std::integer_sequence<int, K...>) {
+            return ((bstep(IC<K>{}), (K & 3) == 2 && t0 + K == T) || ...);
+        }(std::make_integer_sequence<int, UNROLL>{});
+        if (last) break;
     }
 #ifdef FINC_SPLIT_STAMP
     if (blockIdx.x == 0 && lane == 0) finc_chain_stamps[1 + bi] = st_busy;
@@ -666,7 +677,9 @@ int finc_chain_launch(const float *in, const void *packed, float *out, const Fin
     const int DF = fifo_depth(s.W, P);
     const size_t lds = (size_t)i->lds_fixed + 2 * (size_t)DF * FSLOT_B;
     const int T = NB * s.W + P - 1;
-    const int Tr = (T + 2 + UNROLL - 1) / UNROLL * UNROLL - 2;   // the B waves' loop is unrolled by UNROLL
+    // the kernel runs the iterations u = 0 .. Tr + 1; the last store -- lane P - 1's last group, solved by step T - 1 -- leaves in the
+    // store phase of window NB * W / 4 + P / 4, i.e. in iteration u = T + 3 (W, P multiples of 4: T = 3 mod 4, u = 2 mod 4)
+    const int Tr = T + 2;
     if (int e = finc_ensure_dynamic_lds((const void *)i->fn, lds)) return e;
     hipLaunchKernelGGL(i->fn, dim3(s.B * s.G), dim3(64 * (2 + i->nbw)), lds, st, in, (const float *)packed, out, s.G, s.Cq, s.H, s.W, P, Tr,
                        s.orient, DF);

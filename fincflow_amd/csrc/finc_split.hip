@@ -1041,10 +1041,9 @@ bool finc_split_takes(const FincShape &s)
     const long long problems = (long long)s.B * s.G;
     if (problems > split_max_problems()) {
         // two problems per compute unit: the short-step form still beats the wavefront kernel's table (its workgroup is 45 KB of LDS
-        // and five waves) once the chain is long enough to pay for its prologue -- C = 48, 32x32, B = 128: 42.6 against 57.3 us;
-        // the 16x16 maps of the CIFAR stack 14.2 against 15.1; 8x8 and 4x4 maps: 12.2 / 11.5 against 11.7 / 9.5, so not those
-        const int P = s.W < 16 ? s.W : 16;
-        return problems <= 2 * split_max_problems() && ((s.H + P - 1) / P) * s.W + P - 1 >= 31 && finc_chain_takes(s);
+        // and five waves) -- C = 48, 32x32, B = 128: 40.3 against 57.3 us; the maps of the CIFAR stack at its sampling batch: 16x16
+        // 12.6 against 15.1, 8x8 10.3 against 11.7, 4x4 9.0 against 9.6 (profiles/r05/tiny_maps_kernel_time.txt)
+        return problems <= 2 * split_max_problems() && finc_chain_takes(s);
     }
     if (finc_split_uses_chain(s)) return true;                             // (the small banks' short-step form: no FIFO-width limit)
     const SInst *i = find_sinst(s.Cq, s.KH, s.KW);

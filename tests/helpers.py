@@ -115,8 +115,6 @@ def chain_takes(cqp, kh, kw, problems, H, W):
     if problems > 2 * SPLIT_MAX_PROBLEMS or cqp > 16 or cqp not in SPLIT_BANKS.get((kh, kw), ()) or H < 1 or W < 4 or W % 4:
         return False
     P = min(16, W)
-    if problems > SPLIT_MAX_PROBLEMS and ((H + P - 1) // P) * W + P - 1 < 31:   # (two problems per compute unit: chains of >= 31 steps only)
-        return False
     nbw = sum(1 for a in range(kh) for b in range(kw) if a + b == 2)
     fixed = 8 * (64 + 8 + 1 + 8) * 16 + 2 * nbw * 1024 + (cqp // 4) * 8 * 1024
     if not (P >= kh - 1 and fixed + 2 * (W - P + 2) * 128 <= 160 * 1024):

@@ -134,7 +134,7 @@ def test_role_split_kernel_takes_the_under_filled_chip():
     wave); everything else stays with the wavefront kernel's table (host-only calls)."""
     from helpers import split_takes, chain_takes
     for (B, G, Cq, H, W, K), want in (((64, 4, 12, 32, 32, 3), True), ((32, 4, 24, 64, 64, 3), True), ((64, 4, 24, 64, 64, 3), True),
-                                      ((65, 4, 24, 64, 64, 3), False), ((128, 4, 3, 16, 16, 3), True), ((128, 4, 6, 8, 8, 3), False), ((129, 4, 3, 16, 16, 3), False),
+                                      ((65, 4, 24, 64, 64, 3), False), ((128, 4, 3, 16, 16, 3), True), ((128, 4, 6, 8, 8, 3), True), ((129, 4, 3, 16, 16, 3), False),
                                       ((64, 4, 3, 16, 16, 3), True),
                                       ((16, 4, 12, 4, 4, 3), True), ((1, 1, 23, 40, 36, 3), True), ((8, 4, 24, 8, 80, 3), False),
                                       ((8, 4, 16, 30, 44, 2), True), ((8, 4, 16, 32, 32, 5), False), ((8, 4, 40, 32, 32, 3), False),

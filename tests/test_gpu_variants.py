@@ -370,7 +370,7 @@ def test_unaligned_view_through_fastflowunit_reverse(dev):
     starts 4 bytes into an allocation goes through FastFlowUnit.reverse / reverse_affine / PaddedConv2d.reverse."""
     from fincflow_amd import FastFlowUnit, glow, ops
     torch.manual_seed(6)
-    B, C, H, W = 80, 16, 8, 8              # (more problems than the role-split kernel takes: that one has no alignment rule)
+    B, C, H, W = 160, 16, 8, 8             # (more problems than the role-split kernel takes: that one has no alignment rule)
     unit = FastFlowUnit(C, C, 3).to(dev)
     x = torch.randn(B, C, H, W, device=dev)
     with torch.no_grad():
