@@ -117,6 +117,9 @@ __device__ unsigned long long finc_split_stamps[16];
 constexpr int XSLOTS = 8;        // x ring: the pixels of the last 8 steps (taps reach back KH + KW - 2 <= 8 steps)
 constexpr int JSTRIDE = 2048;    // bytes between the k-steps of the x ring (8 slots x 64 lanes) AND of the FIFO: one immediate
 constexpr int ZJSTRIDE = 3072;   // bytes between the k-steps of the z ring (12 slots x 64 lanes)
+#ifndef FINC_BSP_TRIES
+#define FINC_BSP_TRIES 6
+#endif
 constexpr int UNROLL = 8;        // steps per iteration of the B waves' loop: two I/O windows (the in-flight sets alternate)
 
 template <int CQP, int KH, int KW, int NBW>
@@ -262,7 +265,7 @@ __global__ __launch_bounds__(64 * (1 + NBW)) void finc_split_kernel(const float 
                 // 32 steps, a pair's second band trails the other pair's first by 44 -- c3 at 16 images: 130 against 137 us)
                 if (wg + BSTRIDE < NBi && nwg * nprob > (int)gridDim.x) {
                     bool claimed = false;
-                    for (int tries = 0; tries < 6 && !claimed; ++tries) {
+                    for (int tries = 0; tries < FINC_BSP_TRIES && !claimed; ++tries) {
                         claimed = __hip_atomic_load(sync + 2 + (wg + 1) * nprob + bg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u;
                         if (!claimed) __builtin_amdgcn_s_sleep(8);
                     }
@@ -278,8 +281,7 @@ __global__ __launch_bounds__(64 * (1 + NBW)) void finc_split_kernel(const float 
             __syncthreads();
             {
                 const int nbl = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ctrl[1]));
-                const int Traw = nbl * W + P - 1;
-                Tj = (Traw + 2 + UNROLL - 1) / UNROLL * UNROLL - 2;
+                Tj = nbl * W + P - 1 + 2;     // (finc_split_launch: the iterations u = 0 .. chain + 3)
             }
             float fv0[NK];
             const int fp0 = fpop == 0 ? DF - 1 : fpop - 1;
@@ -632,7 +634,7 @@ __global__ __launch_bounds__(64 * (1 + NBW)) void finc_split_kernel(const float 
         nbl = __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, ctrl[1]));   // (A's decision: see there)
         const int last_row = (wg + (nbl - 1) * BSTRIDE + 1) * P;
         row_lim = last_row < H ? last_row : H;
-        Tj = (nbl * W + P - 1 + 2 + UNROLL - 1) / UNROLL * UNROLL - 2;
+        Tj = nbl * W + P - 1 + 2;
     }
     // z read address: slot (n mod 12) of this lane
     int zn = ((-p) % 12 + 12) % 12;
@@ -776,12 +778,15 @@ __global__ __launch_bounds__(64 * (1 + NBW)) void finc_split_kernel(const float 
         FINC_ST_END();
         __syncthreads();
     };
-    // iterations t = -1 .. T (u = t + 1 = 0 .. T + 1), unrolled by UNROLL: the host rounds T up so that T + 2 is a multiple of
-    // it (the extra steps solve rows below the image: nothing is stored)
+    // iterations t = -1 .. Tj (u = t + 1 = 0 .. Tj + 1), unrolled by UNROLL and left at the exact step: the last store -- lane P - 1's
+    // last group, solved by step chain - 1 -- leaves in the store phase (u = 2 mod 4) of window chain / 4 + 1, i.e. in iteration
+    // chain + 3 = Tj + 1; the body is left after its 3rd or 7th step (the extra steps solve rows below the band: nothing is stored)
     for (int t0 = -1; t0 < Tj; t0 += UNROLL) {
-        [&]<int... K>(std::integer_sequence<int, K...>) { ((bstep(IC<K>{}, t0 + K)), ...); }(std::make_integer_sequence<int, UNROLL>{});
+        const bool last = [&]<int... K>(std::integer_sequence<int, K...>) {
+            return ((bstep(IC<K>{}, t0 + K), (K & 3) == 2 && t0 + K == Tj) || ...);
+        }(std::make_integer_sequence<int, UNROLL>{});
+        if (last) break;
     }
-    // (the last window's store covers the last group of every lane: T + 1 >= NB*W + P and P/4 + fs >= -1)
     if constexpr (BSP && NJ > 0) {
         // the stores of the last windows are not yet accounted for in the progress word (a window's stores are said complete two
         // windows later, and the loop ends with them): the consumer of this workgroup's LAST band waits for exactly those
@@ -1090,7 +1095,7 @@ int finc_split_launch(const float *in, const void *packed, float *out, const Fin
         if (!slot) nwg = 1;
     }
     const int T = ((NB + nwg - 1) / nwg) * s.W + P - 1;        // steps of one workgroup
-    const int Tr = (T + 2 + UNROLL - 1) / UNROLL * UNROLL - 2; // the B waves' loop is unrolled by UNROLL
+    const int Tr = T + 2;                                      // iterations u = 0 .. T + 3: the last store leaves in u = T + 3 (see the B waves' loop)
     const int DF = fifo_depth(s.W, P, s.KH, s.KW);
     if (nwg > 1) {
         // One workgroup per compute unit, enforced by its LDS size: two chains on one unit run at half the pace each (c3 at 32

@@ -32,8 +32,8 @@ def run_model(H, W, final_publish=True, lookahead=1, resident=None, start_order=
     NB = (H + P - 1) // P
     GR = W // 4
     T = W + P - 1
-    Tr = (T + 2 + 7) // 8 * 8 - 2                    # finc_split_launch: the B waves' loop is unrolled by 8
-    nwin = (Tr + 2) // 4                             # windows 0 .. nwin - 1 (u = 0 .. Tr + 1)
+    Tr = T + 2                                       # finc_split_launch: the loops are left at the exact step, u = 0 .. T + 3
+    nwin = (Tr + 2) // 4                             # windows whose step 3 is reached (the last window is left after its step 2)
     order = list(start_order) if start_order is not None else list(range(NB))
     assert sorted(order) == list(range(NB))
     band_of = {}                                     # block -> band (its ticket)
@@ -107,13 +107,15 @@ def test_the_dispatch_order_does_not_matter():
 
 
 def test_the_tail_of_a_band():
-    """The consumer's last piece (group GR - 1) needs the producer's word at GR + 5; the producer's loop runs 2 * ceil((W + 17) / 8)
-    windows >= GR + 5 and publishes one per window, so with one band per workgroup the loop alone covers the tail (the two-workgroup
-    form of round 4 did not at W = 68: scripts/stress_bands.py found its consumers waiting forever).  The publish of "all complete"
-    behind the loop stays as the guard for any change of that arithmetic."""
+    """The consumer's last piece (group GR - 1) needs the producer's word at GR + 5.  The producer's loop ends with the store of its
+    last group -- iteration W + 18, step 2 of window GR + 4 -- so the loop itself publishes GR + 4 windows and the tail rests on the
+    publish of "all complete" behind the drain of the stores (finc_split.hip, behind the B waves' loop): without it every consumer
+    would wait forever, with it none does (scripts/stress_bands.py found the round-4 form, two workgroups per problem, waiting at
+    W = 68 for want of exactly that publish)."""
     for W in range(16, 260, 4):
-        assert run_model(26, W, final_publish=False), W
-        assert 2 * -(-(W + 17) // 8) >= W // 4 + 5
+        assert run_model(26, W), W
+        assert not run_model(26, W, final_publish=False), W
+        assert (W + 15 + 4) // 4 == W // 4 + 4
 
 
 def test_the_library_rule_matches_the_model():
