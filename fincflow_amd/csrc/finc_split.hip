@@ -100,6 +100,9 @@ struct BTaps {
     static constexpr int b_of(int i) { return find(i, false); }
 };
 
+#ifdef FINC_BSP_TRACE     // diagnostic build: one record per band-split job (scripts/bsp_trace.py)
+__device__ unsigned long long finc_bsp_trace[1 + 4 * 4096];   // [0] = records; then {job, blockIdx | xcc << 16 | bands << 24, start, end (s_memrealtime)}
+#endif
 #ifdef FINC_SPLIT_STAMP   // diagnostic build: busy cycles (barrier exit -> next barrier arrival) per wave of workgroup 0, summed over the steps
 __device__ unsigned long long finc_split_stamps[16];
 #define FINC_ST_BEGIN() unsigned long long st_b_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(st_b_)::"memory")
@@ -117,6 +120,12 @@ __device__ unsigned long long finc_split_stamps[16];
 constexpr int XSLOTS = 8;        // x ring: the pixels of the last 8 steps (taps reach back KH + KW - 2 <= 8 steps)
 constexpr int JSTRIDE = 2048;    // bytes between the k-steps of the x ring (8 slots x 64 lanes) AND of the FIFO: one immediate
 constexpr int ZJSTRIDE = 3072;   // bytes between the k-steps of the z ring (12 slots x 64 lanes)
+#ifndef FINC_BSP_HSC      // cache-policy bits of the loads that fetch the rows above a band (timing experiments only: anything weaker is stale)
+#define FINC_BSP_HSC "sc0 sc1"
+#endif
+#ifndef FINC_BSP_ABL      // timing-only builds (bit mask; results are garbage): 1 no wait for the producer, 2 no early stores of the handed-over rows,
+#define FINC_BSP_ABL 0    // 4 no fetch of the rows above, 8 no publish, 16 the fetched pieces are not written to the FIFO
+#endif
 #ifndef FINC_BSP_TRIES
 #define FINC_BSP_TRIES 6
 #endif
@@ -292,6 +301,9 @@ __global__ __launch_bounds__(64 * (1 + NBW)) void finc_split_kernel(const float 
         }
         __syncthreads();                       // (iteration t = -1: the B waves prepare step 0)
         unsigned long long st_busy = 0;
+#ifdef FINC_BSP_TRACE
+        const unsigned long long tr_start = __builtin_amdgcn_s_memrealtime();
+#endif
         for (int t = 0; t <= Tj; ++t) {
             FINC_ST_BEGIN();
             const int par = t & 1, slot = t & (XSLOTS - 1);
@@ -379,6 +391,22 @@ __global__ __launch_bounds__(64 * (1 + NBW)) void finc_split_kernel(const float 
             FINC_ST_END();
             __syncthreads();
         }
+#ifdef FINC_BSP_TRACE
+        if constexpr (BSP) {
+            if (lane == 0) {
+                const unsigned long long n = __hip_atomic_fetch_add(finc_bsp_trace, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (n < 4096) {
+                    unsigned xcc;
+                    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+                    const int nb = (Tj - 2 - (P - 1)) / W;
+                    finc_bsp_trace[1 + 4 * n] = (unsigned long long)slot_id;
+                    finc_bsp_trace[2 + 4 * n] = (unsigned long long)blockIdx.x | ((unsigned long long)(xcc & 15) << 16) | ((unsigned long long)nb << 24);
+                    finc_bsp_trace[3 + 4 * n] = tr_start;
+                    finc_bsp_trace[4 + 4 * n] = __builtin_amdgcn_s_memrealtime();
+                }
+            }
+        }
+#endif
 #ifdef FINC_SPLIT_STAMP
         if (blockIdx.x == 0 && lane == 0) { finc_split_stamps[0] = st_busy; finc_split_stamps[9] = T + 1; }
 #else
@@ -511,6 +539,7 @@ __global__ __launch_bounds__(64 * (1 + NBW)) void finc_split_kernel(const float 
     // already (the others do nothing; step 2 stores the whole instruction again, which is harmless): its completion is then
     // covered by the window's one counted wait at step 3, and the progress word says so four steps sooner.
     auto xstore_early = [&]() {
+        if constexpr (FINC_BSP_ABL & 2) return;
         const bool ok = scol >= 0 && srow < row_lim && p >= P - (KH - 1) && p < P;
         const unsigned base = ok ? (unsigned)soff : OFF_INVALID;
 #pragma unroll
@@ -555,6 +584,7 @@ __global__ __launch_bounds__(64 * (1 + NBW)) void finc_split_kernel(const float 
         if ((int)val > seen) seen = (int)val;
     };
     auto progress_wait = [&](int need) {
+        if constexpr (FINC_BSP_ABL & 1) return;
         if (seen >= need) return;
         int budget = 1 << 21;                  // bounded (seconds): a protocol bug must not hang the GPU, and must not pass unnoticed;
                                                // long enough for a producer workgroup that another tenant of the chip keeps waiting
@@ -579,17 +609,17 @@ __global__ __launch_bounds__(64 * (1 + NBW)) void finc_split_kernel(const float 
         const int bi_l = i1 - lane;                                        // lane 0: band i1, lane 1: band i1 - 1
         const bool act = lane < 2 && bi_l >= 0;
         const unsigned v = all ? 0x7FFFFFFFu : (unsigned)(windows_done - bi_l * GR);
-        const unsigned off = act ? band_word(wg + bi_l * BSTRIDE) : OFF_INVALID;
+        const unsigned off = act && !(FINC_BSP_ABL & 8) ? band_word(wg + bi_l * BSTRIDE) : OFF_INVALID;
         asm volatile("buffer_store_dword %0, %1, %2, 0 offen sc0 sc1" ::"v"(v), "v"(off), "s"(rsync) : "memory");
     };
     auto hreq = [&]() {
         const int kb = wg + hband * BSTRIDE;                               // the image band these rows sit above
         const bool live = kb >= 1 && kb < NBimg && hband < nbl;            // (band 0: the zero rows above the image; beyond: nothing)
         if (live) progress_wait((hcol >> 2) + 6);
-        const unsigned base = (live && hl) ? (unsigned)hoff : OFF_INVALID;
+        const unsigned base = (live && hl && !(FINC_BSP_ABL & 4)) ? (unsigned)hoff : OFF_INVALID;
 #pragma unroll
         for (int j = 0; j < NJ; ++j)
-            asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen sc0 sc1" : "=v"(hin[j]) : "v"(base + xmask[j]), "s"(rout) : "memory");
+            asm volatile("buffer_load_dwordx4 %0, %1, %2, 0 offen " FINC_BSP_HSC : "=v"(hin[j]) : "v"(base + xmask[j]), "s"(rout) : "memory");
         hcol += 4; hoff += dgrp;
         if (hcol == W) {                       // on to the rows above this job's next band: another producer, another word
             hcol = 0; ++hband; hoff += drow;
@@ -600,7 +630,7 @@ __global__ __launch_bounds__(64 * (1 + NBW)) void finc_split_kernel(const float 
     auto hland = [&]() {                       // (the caller has waited for the loads)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) asm volatile("" : "+v"(hin[j]));
-        if (hl) {
+        if (hl && !(FINC_BSP_ABL & 16)) {
             int s0 = hslot, s1 = hslot + 1, s2 = hslot + 2, s3 = hslot + 3;
             s1 = s1 >= DF ? s1 - DF : s1; s2 = s2 >= DF ? s2 - DF : s2; s3 = s3 >= DF ? s3 - DF : s3;
             const int cell = C::FIFO_B + (q * (KH - 1) + (KH - 2 - p)) * 4;
@@ -1024,6 +1054,14 @@ int finc_split_timeouts_count(unsigned *count)
     return FINC_OK;
 }
 
+#ifdef FINC_BSP_TRACE
+extern "C" int finc_debug_bsp_trace(unsigned long long *h, int reset)
+{
+    int e = (int)hipMemcpyFromSymbol(h, HIP_SYMBOL(finc_bsp_trace), sizeof(finc_bsp_trace));
+    if (!e && reset) { const unsigned long long z = 0; e = (int)hipMemcpyToSymbol(HIP_SYMBOL(finc_bsp_trace), &z, sizeof(z)); }
+    return e;
+}
+#endif
 #ifdef FINC_SPLIT_STAMP
 extern "C" int finc_debug_split_stamps(unsigned long long *h) { return (int)hipMemcpyFromSymbol(h, HIP_SYMBOL(finc_split_stamps), sizeof(finc_split_stamps)); }
 #endif
