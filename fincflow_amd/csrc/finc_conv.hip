@@ -651,7 +651,7 @@ int finc_conv_pack(const float *wc, void *packed, int G, int Cq, int KH, int KW,
         return finc_bigfwd_pack(wc, (char *)packed + conv_bank_bytes(i, G), G, Cq, KH, KW, transpose, st, scale, shift);
     if (finc_wino5_packed_bytes(G, Cq, KH, KW))    // (5x5: Winograd F(2,5) along W, finc_wino5.hip)
         return finc_wino5_pack(wc, (char *)packed + conv_bank_bytes(i, G), G, Cq, transpose, st, scale, shift);
-    if (finc_wino4m_packed_bytes(G, Cq, KH, KW))   // (3x3 banks of 28 .. 64 channels: F(4,3), M-split, finc_wino4m.hip)
+    if (finc_wino4m_packed_bytes(G, Cq, KH, KW))   // (3x3 banks of 25 .. 64 channels: F(4,3), M-split, finc_wino4m.hip)
         return finc_wino4m_pack(wc, (char *)packed + conv_bank_bytes(i, G), G, Cq, transpose, st, scale, shift);
     return FINC_OK;
 }
@@ -668,7 +668,7 @@ int finc_conv_launch(const float *in, const void *packed, float *out, const Finc
     // 5x5 with 0.6 x the multiplies (Winograd F(2,5) along W: finc_wino5.hip) where the call allows it
     if (finc_wino5_packed_bytes(s.G, s.Cq, s.KH, s.KW) && finc_wino5_takes(in, out, s))
         return finc_wino5_launch(in, (const char *)packed + conv_bank_bytes(i, s.G), out, s, st);
-    // 3x3 banks of 28 .. 64 channels with half the multiplies (F(4,3), M-split over a workgroup's waves: finc_wino4m.hip)
+    // 3x3 banks of 25 .. 64 channels with half the multiplies (F(4,3), M-split over a workgroup's waves: finc_wino4m.hip)
     if (finc_wino4m_packed_bytes(s.G, s.Cq, s.KH, s.KW) && finc_wino4m_takes(in, out, s))
         return finc_wino4m_launch(in, (const char *)packed + conv_bank_bytes(i, s.G), out, s, st);
     const int NS = (s.W + 15) / 16;

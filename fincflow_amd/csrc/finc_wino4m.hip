@@ -2,7 +2,7 @@
 // Winograd F(4,3) along W, M-split over the waves of a workgroup (gfx950 only; round 4).
 //
 // finc_wino.hip's F(4,3) keeps the whole bank -- 18 x NK x MT fragments -- in ONE wave's registers: that ends at 24 channels per
-// group, and the banks above it (FastFlowUnit at C = 112 .. 256, CINCFlowUnit at C = 28 .. 64) ran the direct K-split strip
+// group, and the banks above it (FastFlowUnit at C = 100 .. 256, CINCFlowUnit at C = 25 .. 64) ran the direct K-split strip
 // kernel.  Here a workgroup of NW = Cq/16 waves owns a strip of 16 column QUADS (64 columns) of one (image, group) slab:
 //   * wave w holds the fragments of OUTPUT tile w only (18 x NK registers: 144 / 216 / 288 at Cq = 32 / 48 / 64) and computes
 //     those 16 channels completely -- no partial sums, no exchange of results;

@@ -258,7 +258,7 @@ int finc_inverse_kernel_variant(int B, int G, int Cq, int H, int W, int KH, int 
  * workgroup) / 4 Winograd (3x3 banks of 13..32 channels: F(4,3) transposed, half the multiplies) / 5 Winograd on one tile pair
  * per wave (3x3 above 32 channels: F(4,3) transposed; 5x5 above 12: F(2,5) transposed), grad-input: waves per strip of the MFMA strip kernel (0 = direct kernel; > 1 = K-split), grad-input: staged form
  * (1) or dword form (0); 2 = Winograd F(2,3) along W, 3 = the big banks' M-split, 4 = Winograd F(4,3) along W, 5 = Winograd
- * F(2,5) along W (5x5 banks), 6 = Winograd F(4,3) M-split over a workgroup's waves (3x3 banks of 28 .. 64 channels)}.  Lets a parity
+ * F(2,5) along W (5x5 banks), 6 = Winograd F(4,3) M-split over a workgroup's waves (3x3 banks of 25 .. 64 channels)}.  Lets a parity
  * test assert WHICH kernel its numbers came from. */
 int finc_debug_backward_variant(int B, int G, int Cq, int H, int W, int KH, int KW, int *info);
 /* Pins the kernel family of the 3x3 forward / grad-input for this process (tests and A/B timing of each form on one shape):
