@@ -191,10 +191,17 @@ __global__ __launch_bounds__(64 * (1 + NBW)) void finc_split_kernel(const float 
         // a job's CLAIM word ([2 + job]) says a running workgroup owns it: set by the workgroup that drew its ticket, or by the one
         // that extended its own job to it (below).  A drawn ticket whose job is already claimed is skipped.
         if (threadIdx.x == 0) {
+            // Ticket t is band t / nprob of problem (t % nprob + band) % nprob: band-major as the order of claims requires, and rotated by
+            // one problem per band.  Workgroups tend to draw their tickets in the order of their indices, and the dispatcher deals
+            // indices round-robin over the XCDs: unrotated, ticket j (band 0 of problem j) and ticket nprob + j (its band 1) would go to
+            // the same XCD whenever nprob % 8 == 0 -- and an XCD whose 32 workgroups all hand over to a neighbour on the same L2 runs
+            // 10-15 % slower (profiles/r05/notes/band_split_jobs.txt: job traces).  Rotated, neighbours in a problem sit on neighbouring XCDs.
             int tk;
             for (;;) {
                 tk = (int)__hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (tk >= nwg * nprob) break;
+                const int band = tk / nprob, pr = (tk - band * nprob + band) % nprob;
+                tk = band * nprob + pr;                                    // (from here on: the job's index = band * nprob + problem)
                 unsigned expect = 0u;
                 if (__hip_atomic_compare_exchange_strong(sync + 2 + tk, &expect, 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
             }

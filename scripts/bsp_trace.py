@@ -45,6 +45,15 @@ with torch.no_grad():
             ln = e - s
             print(f"   jobs whose partner (the other bands of the problem) runs on the SAME XCD: {int(flag.sum())}, length {ln[flag].mean():6.1f} (max {ln[flag].max():6.1f}); "
                   f"on another XCD: {int((~flag).sum())}, length {ln[~flag].mean():6.1f} (max {ln[~flag].max():6.1f})")
+        ln = e - s
+        if ln.max() > np.median(ln) + 6 or os.environ.get("BSP_TRACE_XCC"):
+            print("      per XCD (jobs, of them with the partner on the same XCD, mean / max length): " + "  ".join(
+                f"{x}: {int((xcc == x).sum())} {int((flag & (xcc == x)).sum())} {ln[xcc == x].mean():.1f}/{ln[xcc == x].max():.1f}" for x in range(8) if (xcc == x).any()))
+        if ln.max() > np.median(ln) + 6:
+            for i in np.argsort(-ln)[:6]:
+                j = owner.get((int(band[i]) ^ 1, int(prob[i])))
+                print(f"      slow job: band {band[i]} problem {prob[i]:3d} block {blk[i]:3d} xcc {xcc[i]} start {s[i]:6.1f} end {e[i]:6.1f} length {ln[i]:6.1f}"
+                      + (f" | partner band {band[j]} block {blk[j]:3d} xcc {xcc[j]} start {s[j]:6.1f} end {e[j]:6.1f} length {ln[j]:6.1f}" if j is not None else ""))
         for bd in sorted(set(band.tolist())):
             m = band == bd
             print(f"   first band {bd}: {int(m.sum()):4d} jobs  start {s[m].min():6.1f} .. {s[m].max():6.1f}  end {e[m].min():6.1f} .. {e[m].max():6.1f}  "
