@@ -571,7 +571,16 @@ __global__ __launch_bounds__(64 * (1 + NBW)) void finc_split_kernel(const float 
     const bool hl = BSP && p < KH - 1;
     int hcol = 0, hband = 0;
     int hoff = BSP ? piece_off(row0 - 1 - p, 0) : 0;
-    int hslot = BSP ? (((-W + P - 1 - p) % DF) + DF) % DF : 0;            // slot of the first element of the next piece to LAND
+    // FIFO cell (byte address, k-step 0) of each of the four elements of the next piece to LAND: element e of the piece in memory order
+    // is canonical column e (3 - e on a W-flipped group) and goes to slot (first + column) % DF; a window moves all four on by 4 slots
+    int ha[4] = {0, 0, 0, 0};
+    const int hcell = C::FIFO_B + (q * (KH - 1) + (KH - 2 - p)) * 4;
+    const int ha_wrap = hcell + DF * (JS * 4);                             // (this lane's cell in slot DF: back to slot 0)
+    if constexpr (BSP) {
+        const int first = (((-W + P - 1 - p) % DF) + DF) % DF;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ha[e] = hcell + ((first + (fw ? 3 - e : e)) % DF) * (JS * 4);
+    }
     v4f hin[NJ > 0 ? NJ : 1];
     int seen = 0;                                                          // producer progress read so far
     const int NBimg = (H + P - 1) / P;
@@ -638,21 +647,20 @@ __global__ __launch_bounds__(64 * (1 + NBW)) void finc_split_kernel(const float 
 #pragma unroll
         for (int j = 0; j < NJ; ++j) asm volatile("" : "+v"(hin[j]));
         if (hl && !(FINC_BSP_ABL & 16)) {
-            int s0 = hslot, s1 = hslot + 1, s2 = hslot + 2, s3 = hslot + 3;
-            s1 = s1 >= DF ? s1 - DF : s1; s2 = s2 >= DF ? s2 - DF : s2; s3 = s3 >= DF ? s3 - DF : s3;
-            const int cell = C::FIFO_B + (q * (KH - 1) + (KH - 2 - p)) * 4;
-            const int se[4] = {s0, s1, s2, s3};                            // canonical column k of the piece -> its slot
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 const float v0 = hin[j].x, v1 = hin[j].y, v2 = hin[j].z, v3 = hin[j].w;
-                st(cell + se[fw ? 3 : 0] * (JS * 4) + (JLO + j) * JSTRIDE, v0);
-                st(cell + se[fw ? 2 : 1] * (JS * 4) + (JLO + j) * JSTRIDE, v1);
-                st(cell + se[fw ? 1 : 2] * (JS * 4) + (JLO + j) * JSTRIDE, v2);
-                st(cell + se[fw ? 0 : 3] * (JS * 4) + (JLO + j) * JSTRIDE, v3);
+                st(ha[0] + (JLO + j) * JSTRIDE, v0);
+                st(ha[1] + (JLO + j) * JSTRIDE, v1);
+                st(ha[2] + (JLO + j) * JSTRIDE, v2);
+                st(ha[3] + (JLO + j) * JSTRIDE, v3);
             }
         }
-        hslot += 4;
-        hslot = hslot >= DF ? hslot - DF : hslot;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            ha[e] += 4 * (JS * 4);
+            ha[e] = ha[e] >= ha_wrap ? ha[e] - DF * (JS * 4) : ha[e];
+        }
     };
     // prologue: groups f, f+1 land now (window 0 reads them), f+2 and f+3 wait in the two sets
     if constexpr (NJ > 0) {
