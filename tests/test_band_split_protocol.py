@@ -175,3 +175,22 @@ def run_pairs(NB, resident, claim_delay):
 def test_extended_jobs_never_wait_for_an_unowned_band(NB, resident):
     assert run_pairs(NB, resident, claim_delay=True)
     assert run_pairs(NB, resident, claim_delay=False)
+
+
+def ticket_to_job(t, nprob):
+    """finc_split.hip, the ticket draw: ticket t is band t // nprob of problem (t % nprob + band) % nprob."""
+    band = t // nprob
+    return band, (t % nprob + band) % nprob
+
+
+@pytest.mark.parametrize("nprob,bands", [(128, 4), (120, 4), (4, 8), (1, 5), (7, 3), (64, 2)])
+def test_the_ticket_map_is_a_band_major_bijection(nprob, bands):
+    """The rotation by one problem per band (neighbouring bands of a problem on different XCDs when tickets are drawn in workgroup
+    order) must not disturb what the protocol rests on: every job has exactly one ticket, and every ticket of band k - 1 is smaller
+    than every ticket of band k."""
+    jobs = [ticket_to_job(t, nprob) for t in range(nprob * bands)]
+    assert sorted(jobs) == [(b, p) for b in range(bands) for p in range(nprob)]
+    assert all(jobs[t][0] <= jobs[t + 1][0] for t in range(len(jobs) - 1))
+    if nprob % 8 == 0:                       # drawn in workgroup order, workgroup w on XCD w % 8: a problem's neighbouring bands differ in XCD
+        xcd = {job: t % 8 for t, job in enumerate(jobs)}
+        assert all(xcd[(b, p)] != xcd[(b + 1, p)] for b in range(bands - 1) for p in range(nprob))
