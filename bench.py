@@ -170,9 +170,13 @@ class Sensors:
             return
         self._p, self._f = [], []
         self._stop = threading.Event()
+        self._quiet = threading.Event()
 
         def run():
             while not self._stop.is_set():
+                if self._quiet.is_set():                    # (a timed region: no driver file is touched while it runs)
+                    self._stop.wait(0.001)
+                    continue
                 ts = time.perf_counter()
                 if self.power_path:
                     v = self._read(self.power_path)
@@ -187,9 +191,20 @@ class Sensors:
         self._thread = threading.Thread(target=run, daemon=True)
         self._thread.start()
 
+    def quiet(self, on):
+        """No sampling inside a timed region: a read of the hwmon files goes through the driver to the SMU, and the one launch on record
+        that took 38 ms (profiles/r05/notes/bench_c3_share8_outlier_run.json) fell together with a sampler stalled for as long.  The
+        samples that describe a leg are taken in the 12 ms behind it, while the same launches keep the card busy."""
+        if self._thread is None:
+            return
+        if on:
+            self._quiet.set()
+        else:
+            self._quiet.clear()
+
     def stop(self, t0=None, t1=None):
-        """Stops the sampler; the statistics cover the samples taken in [t0, t1] (the timed region -- the sampler itself is started
-        before the leg's untimed spin-up, so that the first, slow, read of the driver's files does not fall into the timed steps)."""
+        """Stops the sampler; the statistics cover the samples taken in [t0, t1] (the window right behind the timed region -- the
+        sampler itself is started before the leg's untimed spin-up, so that the first, slow, read of the driver's files is long past)."""
         if self._thread is None:
             return {"power_w": None, "smi_sclk_mhz": None, "samples": 0, "source": self.note}
         self._stop.set()
@@ -298,6 +313,8 @@ class Harness:
             per = sorted(stamps)
         else:
             evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+            if self.sensors is not None:
+                self.sensors.quiet(True)
             self.barrier()
             t0 = time.perf_counter()
             for a, b in evs:
@@ -306,7 +323,14 @@ class Harness:
                 b.record()
             self.barrier()
             dt = time.perf_counter() - t0
-            self.last_sensors = self.sensors.stop(t0, t0 + dt) if self.sensors is not None else None
+            if self.sensors is not None:
+                # (keep the card busy while the sensors are read: the readings then describe the leg, not the idle card behind it)
+                t1 = time.perf_counter()
+                self.sensors.quiet(False)
+                while time.perf_counter() - t1 < 0.012:
+                    fn()
+                    self.sync()
+            self.last_sensors = self.sensors.stop(t0 + dt, None) if self.sensors is not None else None
             per = sorted(a.elapsed_time(b) for a, b in evs)
         ranks = [dt]
         if self.world > 1:
