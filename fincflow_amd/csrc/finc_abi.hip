@@ -179,7 +179,7 @@ int finc_version(void) { return 102; }
 unsigned finc_build_flags(void)
 {
     return FINC_BUILD_FLAGS | finc_build_flags_mfma() | finc_build_flags_split() | finc_build_flags_chain() | finc_build_flags_f64() | finc_build_flags_conv() | finc_build_flags_gradw() | finc_build_flags_wino4m() |
-           finc_build_flags_mix() | finc_build_flags_generic() | finc_build_flags_wino() | finc_build_flags_big() | finc_build_flags_probe() | finc_build_flags_wino5();
+           finc_build_flags_mix() | finc_build_flags_generic() | finc_build_flags_wino() | finc_build_flags_big() | finc_build_flags_probe() | finc_build_flags_wino5() | finc_build_flags_stream();
 }
 
 int finc_fault_pending(void)

@@ -125,6 +125,16 @@ int finc_chain_info(const FincShape &s, int *waves, int *lds_bytes, int *steps);
 int finc_chain_launch(const float *in, const void *packed, float *out, const FincShape &s, hipStream_t st);
 unsigned finc_build_flags_chain();
 
+// ---- banks no register-resident kernel holds: the streaming-bank kernel, inverse and forward forms: finc_stream.hip ----
+bool finc_stream_bank_ok(int Cq, int KH, int KW);                      // within its limits (Cq <= 256, KH, KW <= 7)
+bool finc_stream_supported(int Cq, int H, int W, int KH, int KW, bool inverse);
+size_t finc_stream_packed_bytes(int G, int Cq, int KH, int KW, bool inverse);
+int finc_stream_pack(const float *wc, const float *scale, const float *shift, void *packed, int G, int Cq, int KH, int KW, bool inverse,
+                     bool transpose, hipStream_t st);
+int finc_stream_info(const FincShape &s, bool inverse, int *cqp, int *lds, int *steps);
+int finc_stream_launch(const float *in, const void *packed, float *out, const FincShape &s, bool inverse, hipStream_t st);
+unsigned finc_build_flags_stream();
+
 // ---- forward / grad-input, MFMA strip kernel: finc_conv.hip ----
 bool finc_conv_supported(int Cq, int H, int W, int KH, int KW);
 size_t finc_conv_packed_bytes(int G, int Cq, int KH, int KW);

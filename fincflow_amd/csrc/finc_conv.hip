@@ -617,8 +617,12 @@ const ConvInst *find_conv(int Cq, int KH, int KW)
 
 } // namespace
 
+// banks beyond this table: the streaming-bank kernel in its forward form (finc_stream.hip)
+static bool stream_bank(int Cq, int KH, int KW) { return !find_conv(Cq, KH, KW) && finc_stream_bank_ok(Cq, KH, KW); }
+
 bool finc_conv_supported(int Cq, int H, int W, int KH, int KW)
 {
+    if (stream_bank(Cq, KH, KW)) return finc_stream_supported(Cq, H, W, KH, KW, false);
     if (!find_conv(Cq, KH, KW)) return false;
     if ((size_t)Cq * H * W * 4 >= ((size_t)1 << 30)) return false;
     return true;
@@ -629,6 +633,7 @@ bool finc_conv_supported(int Cq, int H, int W, int KH, int KW)
 static size_t conv_bank_bytes(const ConvInst *i, int G) { return (size_t)(i->nfrag + 4 * i->mt) * 64 * sizeof(float) * (size_t)G; }
 size_t finc_conv_packed_bytes(int G, int Cq, int KH, int KW)
 {
+    if (stream_bank(Cq, KH, KW)) return finc_stream_packed_bytes(G, Cq, KH, KW, false);
     const ConvInst *i = find_conv(Cq, KH, KW);
     return i ? conv_bank_bytes(i, G) + finc_wino_packed_bytes(G, Cq, KH, KW) + finc_bigfwd_packed_bytes(G, Cq, KH, KW) +
                    finc_wino5_packed_bytes(G, Cq, KH, KW) + finc_wino4m_packed_bytes(G, Cq, KH, KW) : 0;   // (at most one of the four exists for a bank)
@@ -637,6 +642,7 @@ size_t finc_conv_packed_bytes(int G, int Cq, int KH, int KW)
 int finc_conv_pack(const float *wc, void *packed, int G, int Cq, int KH, int KW, bool transpose, hipStream_t st,
                    const float *scale, const float *shift)
 {
+    if (stream_bank(Cq, KH, KW)) return finc_stream_pack(wc, scale, shift, packed, G, Cq, KH, KW, false, transpose, st);
     const ConvInst *i = find_conv(Cq, KH, KW);
     if (!i) return FINC_ERR_UNSUPPORTED;
     const int total = i->nfrag * 64;
@@ -658,6 +664,7 @@ int finc_conv_pack(const float *wc, void *packed, int G, int Cq, int KH, int KW,
 
 int finc_conv_launch(const float *in, const void *packed, float *out, const FincShape &s, hipStream_t st)
 {
+    if (stream_bank(s.Cq, s.KH, s.KW)) return finc_stream_launch(in, packed, out, s, false, st);
     const ConvInst *i = find_conv(s.Cq, s.KH, s.KW);
     if (!i || !finc_conv_supported(s.Cq, s.H, s.W, s.KH, s.KW)) return FINC_ERR_UNSUPPORTED;
     // 3x3 with fewer multiplies (Winograd F(2,3) along W: finc_wino.hip) where the call allows it
@@ -694,6 +701,11 @@ int finc_conv_launch(const float *in, const void *packed, float *out, const Finc
 
 int finc_conv_variant(int B, int G, int Cq, int H, int W, int KH, int KW, int *info)
 {
+    if (stream_bank(Cq, KH, KW)) {              // (7: the streaming-bank kernel, four waves per problem)
+        if (!finc_conv_supported(Cq, H, W, KH, KW)) return FINC_ERR_UNSUPPORTED;
+        info[0] = 4; info[1] = 7; info[2] = 1;
+        return FINC_OK;
+    }
     const ConvInst *i = find_conv(Cq, KH, KW);
     if (!i || !finc_conv_supported(Cq, H, W, KH, KW)) return FINC_ERR_UNSUPPORTED;
     static const bool no_wide = finc_env("FINC_CONV_NO_WIDE") != nullptr;

@@ -1618,9 +1618,16 @@ int finc_mfma_hlp_timeouts(unsigned *count)
     return FINC_OK;
 }
 
+// banks that neither this table nor finc_big.hip holds in registers: the streaming-bank kernel (finc_stream.hip)
+static bool stream_bank(int Cq, int KH, int KW)
+{
+    return !finc_big_bank(Cq, KH, KW) && padded_cq(Cq, KH, KW) == 0 && finc_stream_bank_ok(Cq, KH, KW);
+}
+
 bool finc_mfma_supported(int Cq, int H, int W, int KH, int KW)
 {
     if (finc_big_bank(Cq, KH, KW)) return finc_big_supported(Cq, H, W, KH, KW);   // beyond this table: finc_big.hip
+    if (stream_bank(Cq, KH, KW)) return finc_stream_supported(Cq, H, W, KH, KW, true);
     if (W % 4 != 0 || W < 4 || H < 1) return false;
     const int P = W < 16 ? W : 16;
     if (P < KH - 1) return false;
@@ -1634,6 +1641,7 @@ bool finc_mfma_supported(int Cq, int H, int W, int KH, int KW)
 int finc_mfma_packed_cqp(int Cq, int KH, int KW)
 {
     if (finc_big_bank(Cq, KH, KW)) { int w, l, c; return finc_big_info(FincShape{1, 1, Cq, 16, 16, KH, KW, 0}, &w, &l, &c) ? 0 : c; }
+    if (stream_bank(Cq, KH, KW)) { int c = 0; return finc_stream_info(FincShape{1, 1, Cq, 16, 16, KH, KW, 0}, true, &c, nullptr, nullptr) ? 0 : c; }
     const Inst *a = find_inst(Cq, KH, KW);
     return a ? a->cqp : 0;
 }
@@ -1682,12 +1690,14 @@ static bool dead_wide_has(const void *packed)
 bool finc_mfma_affine_takes(const FincShape &s)
 {
     if (!finc_mfma_supported(s.Cq, s.H, s.W, s.KH, s.KW)) return false;
+    if (stream_bank(s.Cq, s.KH, s.KW)) return true;       // (scale into the z-term's columns, Linv * shift as the accumulators' start)
     return !finc_big_bank(s.Cq, s.KH, s.KW) && !wide_takeover(s);
 }
 
 size_t finc_mfma_packed_bytes(int G, int Cq, int KH, int KW)
 {
     if (finc_big_bank(Cq, KH, KW)) return finc_big_packed_bytes(G, Cq, KH, KW);
+    if (stream_bank(Cq, KH, KW)) return finc_stream_packed_bytes(G, Cq, KH, KW, true);
     const size_t own = wave_bank_bytes(G, Cq, KH, KW);
     return own && finc_big_wide_bank(Cq, KH, KW) ? own + finc_big_packed_bytes(G, Cq, KH, KW) : own;
 }
@@ -1698,6 +1708,7 @@ int finc_mfma_pack(const float *wc, const float *scale, const float *shift, void
     (void)finc_fault_gate(true, st);           // arm the device's fault word here, outside any capture of the launches
     (void)finc_split_prepare(st);              // ... and the band split's progress words (finc_split.hip)
     if (finc_big_bank(Cq, KH, KW)) return finc_big_pack(wc, scale, shift, packed, G, Cq, KH, KW, st);
+    if (stream_bank(Cq, KH, KW)) return finc_stream_pack(wc, scale, shift, packed, G, Cq, KH, KW, true, false, st);
     const Inst *i = find_inst(Cq, KH, KW);
     if (!i) return FINC_ERR_UNSUPPORTED;
     hipLaunchKernelGGL(pack_kernel, dim3(G), dim3(256), sizeof(double) * Cq * Cq, st, wc, scale, shift, (float *)packed, Cq,
@@ -1717,6 +1728,13 @@ int finc_mfma_pack(const float *wc, const float *scale, const float *shift, void
 int finc_mfma_variant(int B, int G, int Cq, int H, int W, int KH, int KW, int *info)
 {
     if (!finc_mfma_supported(Cq, H, W, KH, KW)) return FINC_ERR_UNSUPPORTED;
+    if (stream_bank(Cq, KH, KW)) {             // form 7: the streaming-bank kernel, one workgroup of four waves per problem
+        int cqp = 0, lds = 0;
+        if (int e = finc_stream_info(FincShape{B, G, Cq, H, W, KH, KW, 0}, true, &cqp, &lds, nullptr)) return e;
+        info[0] = cqp; info[1] = 4; info[2] = 1; info[3] = 7; info[4] = lds; info[5] = B * G;
+        info[6] = -3; info[7] = (int)(sizeof(g_insts) / sizeof(g_insts[0]));
+        return FINC_OK;
+    }
     if (finc_big_bank(Cq, KH, KW) || wide_takeover(FincShape{B, G, Cq, H, W, KH, KW, 0})) {   // form 5: the big-bank kernel, one workgroup of info[1] waves per problem
         int waves = 0, lds = 0, cqp = 0;
         if (int e = finc_big_info(FincShape{B, G, Cq, H, W, KH, KW, 0}, &waves, &lds, &cqp)) return e;
@@ -1761,7 +1779,7 @@ int finc_mfma_table_row(int row, int *info)
 // small problem sets and the forms without helper waves keep their z-term)
 bool finc_mfma_zpre_takes(const FincShape &s)
 {
-    if (!finc_mfma_supported(s.Cq, s.H, s.W, s.KH, s.KW) || finc_split_takes(s)) return false;
+    if (!finc_mfma_supported(s.Cq, s.H, s.W, s.KH, s.KW) || stream_bank(s.Cq, s.KH, s.KW) || finc_split_takes(s)) return false;
     const Inst *i = find_inst(s.Cq, s.KH, s.KW, (long long)s.B * s.G, s.W);
     if (!i || !i->fn_zpre || s.W % 16 != 0 || finc_no_s64() || finc_no_hlp()) return false;
     const int P = 16;
@@ -1774,6 +1792,7 @@ int finc_mfma_launch(const float *in, const void *packed, float *out, const Finc
     if (zpre && !finc_mfma_zpre_takes(s)) return FINC_ERR_UNSUPPORTED;
     if (int e = finc_fault_gate(false)) return e;          // an earlier launch on this device gave up a protocol wait
     if (finc_big_bank(s.Cq, s.KH, s.KW)) return finc_big_launch(in, packed, out, s, st);   // beyond this table (finc_big.hip)
+    if (stream_bank(s.Cq, s.KH, s.KW)) return finc_stream_launch(in, packed, out, s, true, st);   // beyond both (finc_stream.hip)
     if (wide_takeover(s) && dead_wide_has(packed)) return FINC_ERR_UNSUPPORTED;            // packed with a folded shift: no wide-map form
     if (wide_takeover(s))                                                                  // too wide for this table's forms
         return finc_big_launch(in, (const char *)packed + wave_bank_bytes(s.G, s.Cq, s.KH, s.KW), out, s, st);
