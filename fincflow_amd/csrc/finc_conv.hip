@@ -701,9 +701,11 @@ int finc_conv_launch(const float *in, const void *packed, float *out, const Finc
 
 int finc_conv_variant(int B, int G, int Cq, int H, int W, int KH, int KW, int *info)
 {
-    if (stream_bank(Cq, KH, KW)) {              // (7: the streaming-bank kernel, four waves per problem)
+    if (stream_bank(Cq, KH, KW)) {              // (7: the streaming-bank kernel, one or four waves per problem)
         if (!finc_conv_supported(Cq, H, W, KH, KW)) return FINC_ERR_UNSUPPORTED;
-        info[0] = 4; info[1] = 7; info[2] = 1;
+        int waves = 0;
+        (void)finc_stream_info(FincShape{B, G, Cq, H, W, KH, KW, 0}, false, nullptr, nullptr, nullptr, &waves);
+        info[0] = waves; info[1] = 7; info[2] = 1;
         return FINC_OK;
     }
     const ConvInst *i = find_conv(Cq, KH, KW);

@@ -10,11 +10,11 @@
 //   3. the knobs keep their own #ifndef defaults next to the code they act on, so the product's value is in the source.
 #pragma once
 
-#define FINC_KNOB_LIST(X) X(FINC_ABLATE, 0) X(FINC_ABLATE_IO, 1) X(FINC_STAMP, 2) X(FINC_HLP_COUNT, 3) X(FINC_HLP_NOWAIT, 4) X(FINC_S64_ABLATE, 5) X(FINC_HLP_MODE, 6) X(FINC_ONLY_C3, 7) X(FINC_CONV_ABLATE, 8) X(FINC_CONV_2W_MAX, 9) X(FINC_SPLIT_STAMP, 10) X(FINC_HLP_INJECT_TIMEOUT, 11) X(FINC_HLP_BUDGET_LOG2, 12) X(FINC_WINO_ABLATE, 13) X(FINC_BIG_ABLATE, 14) X(FINC_CHAIN_ABLATE, 15)
+#define FINC_KNOB_LIST(X) X(FINC_ABLATE, 0) X(FINC_ABLATE_IO, 1) X(FINC_STAMP, 2) X(FINC_HLP_COUNT, 3) X(FINC_HLP_NOWAIT, 4) X(FINC_S64_ABLATE, 5) X(FINC_HLP_MODE, 6) X(FINC_ONLY_C3, 7) X(FINC_CONV_ABLATE, 8) X(FINC_CONV_2W_MAX, 9) X(FINC_SPLIT_STAMP, 10) X(FINC_HLP_INJECT_TIMEOUT, 11) X(FINC_HLP_BUDGET_LOG2, 12) X(FINC_WINO_ABLATE, 13) X(FINC_BIG_ABLATE, 14) X(FINC_CHAIN_ABLATE, 15) X(FINC_STREAM_ABLATE, 16)
 
 // (knobs of experiments that DESIGN.md marks closed were removed in round 4 -- FINC_SAMEBUF, FINC_FIFO_EXEC, FINC_HLP_PRIO,
 // FINC_S64_MODE, FINC_LD_AUX, FINC_ST_AUX, FINC_ZREP; their code is kept as a patch: profiles/r04/notes/removed_knobs.patch)
-#if defined(FINC_ABLATE) || defined(FINC_ABLATE_IO) || defined(FINC_STAMP) || defined(FINC_HLP_COUNT) || defined(FINC_HLP_NOWAIT) || defined(FINC_S64_ABLATE) || defined(FINC_HLP_MODE) || defined(FINC_ONLY_C3) || defined(FINC_CONV_ABLATE) || defined(FINC_CONV_2W_MAX) || defined(FINC_SPLIT_STAMP) || defined(FINC_HLP_INJECT_TIMEOUT) || defined(FINC_HLP_BUDGET_LOG2) || defined(FINC_WINO_ABLATE) || defined(FINC_BIG_ABLATE) || defined(FINC_CHAIN_ABLATE)
+#if defined(FINC_ABLATE) || defined(FINC_ABLATE_IO) || defined(FINC_STAMP) || defined(FINC_HLP_COUNT) || defined(FINC_HLP_NOWAIT) || defined(FINC_S64_ABLATE) || defined(FINC_HLP_MODE) || defined(FINC_ONLY_C3) || defined(FINC_CONV_ABLATE) || defined(FINC_CONV_2W_MAX) || defined(FINC_SPLIT_STAMP) || defined(FINC_HLP_INJECT_TIMEOUT) || defined(FINC_HLP_BUDGET_LOG2) || defined(FINC_WINO_ABLATE) || defined(FINC_BIG_ABLATE) || defined(FINC_CHAIN_ABLATE) || defined(FINC_STREAM_ABLATE)
 #ifndef FINC_EXPERIMENT
 #error "a measurement knob (finc_experiment.h) is set without -DFINC_EXPERIMENT: this would build a library that computes wrong results"
 #endif
@@ -104,9 +104,14 @@
 #else
 #define FINC_BF_15 0u
 #endif
+#ifdef FINC_STREAM_ABLATE
+#define FINC_BF_16 1u
+#else
+#define FINC_BF_16 0u
+#endif
 #ifdef FINC_EXPERIMENT
 #define FINC_BF_31 1u
 #else
 #define FINC_BF_31 0u
 #endif
-#define FINC_BUILD_FLAGS ((FINC_BF_0 << 0) | (FINC_BF_1 << 1) | (FINC_BF_2 << 2) | (FINC_BF_3 << 3) | (FINC_BF_4 << 4) | (FINC_BF_5 << 5) | (FINC_BF_6 << 6) | (FINC_BF_7 << 7) | (FINC_BF_8 << 8) | (FINC_BF_9 << 9) | (FINC_BF_10 << 10) | (FINC_BF_11 << 11) | (FINC_BF_12 << 12) | (FINC_BF_13 << 13) | (FINC_BF_14 << 14) | (FINC_BF_15 << 15) | (FINC_BF_31 << 31))
+#define FINC_BUILD_FLAGS ((FINC_BF_0 << 0) | (FINC_BF_1 << 1) | (FINC_BF_2 << 2) | (FINC_BF_3 << 3) | (FINC_BF_4 << 4) | (FINC_BF_5 << 5) | (FINC_BF_6 << 6) | (FINC_BF_7 << 7) | (FINC_BF_8 << 8) | (FINC_BF_9 << 9) | (FINC_BF_10 << 10) | (FINC_BF_11 << 11) | (FINC_BF_12 << 12) | (FINC_BF_13 << 13) | (FINC_BF_14 << 14) | (FINC_BF_15 << 15) | (FINC_BF_16 << 16) | (FINC_BF_31 << 31))

@@ -1728,10 +1728,10 @@ int finc_mfma_pack(const float *wc, const float *scale, const float *shift, void
 int finc_mfma_variant(int B, int G, int Cq, int H, int W, int KH, int KW, int *info)
 {
     if (!finc_mfma_supported(Cq, H, W, KH, KW)) return FINC_ERR_UNSUPPORTED;
-    if (stream_bank(Cq, KH, KW)) {             // form 7: the streaming-bank kernel, one workgroup of four waves per problem
-        int cqp = 0, lds = 0;
-        if (int e = finc_stream_info(FincShape{B, G, Cq, H, W, KH, KW, 0}, true, &cqp, &lds, nullptr)) return e;
-        info[0] = cqp; info[1] = 4; info[2] = 1; info[3] = 7; info[4] = lds; info[5] = B * G;
+    if (stream_bank(Cq, KH, KW)) {             // form 7: the streaming-bank kernel, one workgroup of info[1] waves per problem
+        int cqp = 0, lds = 0, waves = 0;
+        if (int e = finc_stream_info(FincShape{B, G, Cq, H, W, KH, KW, 0}, true, &cqp, &lds, nullptr, &waves)) return e;
+        info[0] = cqp; info[1] = waves; info[2] = 1; info[3] = 7; info[4] = lds; info[5] = B * G;
         info[6] = -3; info[7] = (int)(sizeof(g_insts) / sizeof(g_insts[0]));
         return FINC_OK;
     }

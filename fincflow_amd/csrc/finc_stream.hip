@@ -18,30 +18,43 @@
 //   forward:  z_t = sum_{(a,b)} W_ab x_{t-a-b, rows - a}                                   (and grad-input: transposed bank
 //             on the flipped image, finc_abi.hip)
 //
-// Four waves per problem, wave w owns the output channels [16 MT w, 16 MT (w+1)); one barrier per step.
+// NW waves per problem, wave w owns the output channels [16 MT w, 16 MT (w+1)); one barrier per step.  Banks of up to 48
+// channels are one-wave problems (NW = 1, MT = 1..3: four problems per compute unit, one per SIMD), wider ones take a
+// workgroup of four waves (MT = 1..4 tiles each: 64, 128, 192, 256 padded channels).
 #include "finc_common.h"
 
 namespace {
 
 typedef float v4f __attribute__((ext_vector_type(4)));
 
-constexpr int SNW = 4;       // waves per workgroup
-constexpr int SPD = 8;       // units (one B quad x MT fragment quads) of bank a wave keeps in flight
+// FINC_STREAM_ABLATE (timing-only builds, wrong results): 1 = the bank is not re-read (the fragments of the first units stay),
+// 2 = no MFMAs, 4 = no operand loads (z / halo rows), 8 = every wave starts the bank stream at block 0;
+// FINC_STREAM_SPD overrides the prefetch depth
+#ifndef FINC_STREAM_ABLATE
+#define FINC_STREAM_ABLATE 0
+#endif
+#ifndef FINC_STREAM_SPD
+#define FINC_STREAM_SPD 0
+#endif
+// units (one B quad x MT fragment quads) of bank a wave keeps in flight.  Two tiles per wave: 6, so that the kernel stays
+// within 256 registers and two workgroups share a compute unit (and its L1: the second one's bank reads hit)
+constexpr int spd_of(int MT) { return FINC_STREAM_SPD ? FINC_STREAM_SPD : MT == 2 ? 6 : 8; }
 constexpr int SMAXK = 7;     // KH, KW <= 7
 constexpr int SMINWP = 20;   // period of a band in steps: >= 16 + 4 (the halo rows' distance to their producer)
-constexpr int SMAXMT = 4;    // Cq <= 256
+constexpr int SMAXCQ = 256;
 
 struct Geo {
-    int Cqp, MT, NKQ, NT, HALO, RS, SLOTF, NRING, NSLOT, U, Wp;
+    int Cqp, MT, NW, NKQ, NT, HALO, RS, SLOTF, NRING, NSLOT, U, Wp, SPD;
     size_t lds;
 };
 
 Geo make_geo(int Cq, int W, int KH, int KW, bool inv)
 {
     Geo q;
-    q.MT = (Cq + 63) / 64;
-    q.Cqp = 64 * q.MT;
-    q.NKQ = 4 * q.MT;
+    q.NW = Cq <= 48 ? 1 : 4;
+    q.MT = (Cq + 16 * q.NW - 1) / (16 * q.NW);
+    q.Cqp = 16 * q.NW * q.MT;
+    q.NKQ = q.Cqp / 16;
     q.NT = KH * KW;
     q.HALO = KH - 1;
     q.RS = q.Cqp + 4;
@@ -49,7 +62,8 @@ Geo make_geo(int Cq, int W, int KH, int KW, bool inv)
     const int smax = KH + KW - 2;
     q.NRING = inv ? smax + 1 : smax + 2;
     q.NSLOT = q.NRING + (inv ? 2 : 0);
-    q.U = (q.NT * q.NKQ + SPD - 1) / SPD * SPD;
+    q.SPD = spd_of(q.MT);
+    q.U = (q.NT * q.NKQ + q.SPD - 1) / q.SPD * q.SPD;
     q.Wp = W + KW - 1 > SMINWP ? W + KW - 1 : SMINWP;
     q.lds = (size_t)q.NSLOT * q.SLOTF * sizeof(float);
     return q;
@@ -75,22 +89,34 @@ __device__ inline int pos_pix(const Pos &p, int rho, int H, int W, int NB, unsig
     return finc_pix(H, W, o, h, p.col);
 }
 
+// Every wave starts the bank stream at its own block: the 32 compute units of an XCD (workgroups are dealt round-robin to
+// the XCDs) times NW waves, spread evenly over the stream, so that they do not walk the same L2 lines at the same time
+// (measured: -7 % at 192 channels, -11 % at 128).  The order of a pixel's sum therefore depends on the workgroup: results
+// are reproducible launch to launch, and equal across batch positions only to rounding.
+__device__ inline int rot_of(int nblk, int wave, int nw)
+{
+    if ((FINC_STREAM_ABLATE & 8) || nw == 1) return 0;          // (one-wave problems: the bank is a few KB, it sits in the L1)
+    const unsigned idx = ((blockIdx.x >> 3) & 31u) * (unsigned)nw + (unsigned)wave;
+    return (int)(idx * (unsigned)nblk / (32u * (unsigned)nw));
+}
+
 __device__ inline void lds_barrier()
 {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <int MT, bool INV>
-__global__ __attribute__((amdgpu_flat_work_group_size(256, 256), amdgpu_waves_per_eu(1, 1))) void
+template <int MT, int NW, bool INV, bool VEC>
+__global__ __attribute__((amdgpu_flat_work_group_size(64 * NW, 64 * NW), amdgpu_waves_per_eu(1, 1))) void
 finc_stream_kernel(const float *__restrict__ in, const float *__restrict__ bank, const float *__restrict__ biasv, float *out,
                    int G, int Cq, int H, int W, int KH, int KW, unsigned orient, int U, int Wp, int xcdmap)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int Cqp = 64 * MT, NKQ = 4 * MT, RS = Cqp + 4;
+    constexpr int NTHR = 64 * NW, Cqp = 16 * NW * MT, NKQ = NW * MT, RS = Cqp + 4;
     constexpr int AS = MT == 1 ? 2 : 1;     // accumulators per tile: no MFMA waits on the one before it
+    constexpr int SPD = spd_of(MT);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = NW == 1 ? 0 : __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane >> 4, n = lane & 15;
     const int NT = KH * KW, HALO = KH - 1, SLOTF = (16 + HALO) * RS;
     const int smax = KH + KW - 2;
@@ -117,11 +143,11 @@ finc_stream_kernel(const float *__restrict__ in, const float *__restrict__ bank,
     const int NB = (H + 15) >> 4;
     const int Tend = (NB - 1) * Wp + W + 15;
 
-    for (int e = tid; e < (NRING + (INV ? 2 : 0)) * SLOTF; e += 256) lds[e] = 0.f;
+    for (int e = tid; e < (NRING + (INV ? 2 : 0)) * SLOTF; e += NTHR) lds[e] = 0.f;
 
     // ---- loaders: the 16 rows of a slot (thread -> row, 4 MT channels), its halo rows (thread -> halo row, channels) ----
-    const int mrow = tid & 15, mch = tid >> 4;
-    const int CHT = HALO > 0 ? 256 / HALO : 256;
+    const int mrow = tid & 15, mch = tid >> 4;          // channels mch + 4 NW i
+    const int CHT = HALO > 0 ? NTHR / HALO : NTHR;
     const int hidx = tid / CHT, hch = tid - hidx * CHT;
     const bool hact = HALO > 0 && hidx < HALO;
     Pos pm, ph, pc;
@@ -134,13 +160,60 @@ finc_stream_kernel(const float *__restrict__ in, const float *__restrict__ bank,
         const int pix = pos_pix(pm, mrow, H, W, NB, o);
 #pragma unroll
         for (int i = 0; i < 4 * MT; ++i) {
-            const int ch = mch + 16 * i;
-            mv[i] = (pix >= 0 && ch < Cq) ? src[(size_t)ch * HW + pix] : 0.f;
+            const int ch = mch + 4 * NW * i;
+            mv[i] = (pix >= 0 && ch < Cq && !(FINC_STREAM_ABLATE & 4)) ? src[(size_t)ch * HW + pix] : 0.f;
         }
     };
     auto store_main = [&](int slot_off) {
 #pragma unroll
-        for (int i = 0; i < 4 * MT; ++i) lds[slot_off + (mrow + HALO) * RS + mch + 16 * i] = mv[i];
+        for (int i = 0; i < 4 * MT; ++i) lds[slot_off + (mrow + HALO) * RS + mch + 4 * NW * i] = mv[i];
+    };
+    // the same 16 rows in 16-byte pieces (W % 4 == 0, aligned activations): lanes are channels, wave w owns the rows
+    // RPW w .. RPW w + RPW - 1, and a row requests its next four columns on the step its column count passes a multiple of
+    // four (uniform per wave: a scalar branch) -- a quarter of the requests of the dword form and every line fetched
+    // 8 times instead of 32 (the activations of 32 compute units do not stay in an XCD's L2 beside the bank)
+    constexpr int RPW = 16 / NW, CG = (Cqp + 63) / 64;
+    Pos pv[RPW];
+    v4f zp[RPW][CG];
+    if constexpr (VEC) {
+#pragma unroll
+        for (int k = 0; k < RPW; ++k) {
+            pos_init(pv[k], -(RPW * wave + k) - 1, Wp);                        // "slot -1": the first request steps to slot 0
+#pragma unroll
+            for (int cg = 0; cg < CG; ++cg) zp[k][cg] = v4f{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+    auto fetch_main_vec = [&]() {
+#pragma unroll
+        for (int k = 0; k < RPW; ++k) {
+            pos_step(pv[k], Wp);
+            if ((pv[k].col & 3) == 0) {
+                const int h = pv[k].band * 16 + RPW * wave + k;
+                const bool ok = pv[k].col >= 0 && pv[k].col < W && pv[k].band < NB && h < H;
+                const int hh = (o & FINC_FLIP_H) ? H - 1 - h : h;
+                const int wc = (o & FINC_FLIP_W) ? W - 4 - pv[k].col : pv[k].col;
+#pragma unroll
+                for (int cg = 0; cg < CG; ++cg) {
+                    const int ch = lane + 64 * cg;
+                    zp[k][cg] = (ok && ch < Cq && !(FINC_STREAM_ABLATE & 4)) ? *(const v4f *)(src + (size_t)ch * HW + hh * W + wc)
+                                                                            : v4f{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+        }
+    };
+    auto store_main_vec = [&](int slot_off) {
+#pragma unroll
+        for (int k = 0; k < RPW; ++k) {
+            int comp = pv[k].col & 3;                                          // (before a row's first column the pieces are zeros)
+            if (o & FINC_FLIP_W) comp = 3 - comp;
+#pragma unroll
+            for (int cg = 0; cg < CG; ++cg) {
+                const int ch = lane + 64 * cg;
+                const v4f pcs = zp[k][cg];
+                const float v = comp == 0 ? pcs.x : comp == 1 ? pcs.y : comp == 2 ? pcs.z : pcs.w;
+                if (ch < Cqp) lds[slot_off + (RPW * wave + k + HALO) * RS + ch] = v;
+            }
+        }
     };
     auto load_halo = [&]() {
         const int pix = hact ? pos_pix(ph, -1 - hidx, H, W, NB, o) : -1;
@@ -149,7 +222,7 @@ finc_stream_kernel(const float *__restrict__ in, const float *__restrict__ bank,
             hv[i] = 0.f;
             if (i * CHT < Cqp) {
                 const int ch = hch + CHT * i;
-                if (pix >= 0 && ch < Cq) {
+                if (pix >= 0 && ch < Cq && !(FINC_STREAM_ABLATE & 4)) {
                     if constexpr (INV)      // rows this workgroup stored a few steps ago: read at the L2, never a stale L1 line
                         hv[i] = __hip_atomic_load(dst + (size_t)ch * HW + pix, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     else
@@ -168,22 +241,29 @@ finc_stream_kernel(const float *__restrict__ in, const float *__restrict__ bank,
     };
 
     __syncthreads();
-    load_main();
-    store_main(INV ? ZOFF : 0);
+    if constexpr (VEC) {
+        fetch_main_vec();
+        store_main_vec(INV ? ZOFF : 0);
+    } else {
+        load_main();
+        store_main(INV ? ZOFF : 0);
+    }
     if constexpr (!INV) {
         load_halo();
         store_halo(0);
     }
 
     // ---- the bank stream of this wave: [U units][MT tiles][64 lanes][4 floats], SPD units in flight ----
-    const char *astream = (const char *)(bank + ((size_t)g * SNW + wave) * (size_t)U * MT * 256);
+    const char *astream = (const char *)(bank + ((size_t)g * NW + wave) * (size_t)U * MT * 256);
     const unsigned aoff = (unsigned)lane * 16u;
     v4f ar[SPD][MT];
 #pragma unroll
     for (int d = 0; d < SPD; ++d)
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) ar[d][mt] = *(const v4f *)(astream + (size_t)(d * MT + mt) * 1024 + aoff);
+        for (int mt = 0; mt < MT; ++mt) ar[d][mt] = *(const v4f *)(astream + ((size_t)rot_of(U / SPD, wave, NW) * SPD * MT + d * MT + mt) * 1024 + aoff);
     const int NBLK = U / SPD;
+    const int rot = rot_of(NBLK, wave, NW);
+    const int tau0 = rot * SPD / NKQ, kq0 = rot * SPD - tau0 * NKQ, ta0 = tau0 / KW, tb0 = tau0 - ta0 * KW;
     v4f bias[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) bias[mt] = *(const v4f *)(biasv + (size_t)g * Cqp + (wave * MT + mt) * 16 + 4 * j);
@@ -194,8 +274,12 @@ finc_stream_kernel(const float *__restrict__ in, const float *__restrict__ bank,
     int cur = 0;                                       // ring slot of step t
     for (int t = 0; t < Tend; ++t) {
         // requests of the next step's operands
-        pos_step(pm, Wp);                              // slot t+1
-        load_main();
+        if constexpr (VEC) {
+            fetch_main_vec();                          // slot t+1
+        } else {
+            pos_step(pm, Wp);                          // slot t+1
+            load_main();
+        }
         if constexpr (INV) {
             load_halo();                               // halo rows of slot t (needed from step t+1 on)
             pos_step(ph, Wp);
@@ -214,19 +298,27 @@ finc_stream_kernel(const float *__restrict__ in, const float *__restrict__ bank,
         // threads the tap boundary into copies of the loop that rotate the ring through moves and drain it):
         // unit = (tap, quad of k-steps); tap 0 of the inverse is the z-term.  LDS offsets in 16-byte units.
         const int base0 = (INV ? ZOFF + (t & 1) * SLOTF + HALO * RS : cur * SLOTF + HALO * RS) >> 2;
-        int tau = 0, kq = 0, ta = 0, tb = 0;
-        v4f bcur = lds4[base0 + blane4];
-        for (int blk = 0; blk < NBLK; ++blk) {
-            const int nxt = blk + 1 == NBLK ? 0 : blk + 1;                     // (the last block prefetches the next step's first)
+        int tau = tau0, kq = kq0, ta = ta0, tb = tb0;
+        v4f bcur;
+        {
+            int slot = cur - ta - tb;
+            slot += slot < 0 ? NRING : 0;
+            const int ub = tau < NT ? ((slot * SLOTF + (HALO - ta) * RS) >> 2) : base0;
+            bcur = lds4[((INV && tau == 0) ? base0 : ub) + 4 * kq + blane4];
+        }
+        for (int bi = 0; bi < NBLK; ++bi) {
+            const int blk = bi + rot >= NBLK ? bi + rot - NBLK : bi + rot;
+            const int nxt = blk + 1 == NBLK ? 0 : blk + 1;                     // (a step's last block prefetches the next step's first)
             const char *pf = astream + (size_t)nxt * (SPD * MT * 1024);
 #pragma unroll
             for (int d = 0; d < SPD; ++d) {
+                const bool over = d == SPD - 1 && nxt == 0;                    // the unit behind the stream's last one is its first
                 const int wrap = (kq + 1 == NKQ) ? 1 : 0;
-                kq = wrap ? 0 : kq + 1;
-                tau += wrap;
+                kq = (wrap || over) ? 0 : kq + 1;
+                tau = over ? 0 : tau + wrap;
                 const int wrap2 = (tb + wrap == KW) ? 1 : 0;
-                tb = wrap2 ? 0 : tb + wrap;
-                ta += wrap2;
+                tb = (wrap2 || over) ? 0 : tb + wrap;
+                ta = over ? 0 : ta + wrap2;
                 int slot = cur - ta - tb;
                 slot += slot < 0 ? NRING : 0;
                 const int ub = tau < NT ? ((slot * SLOTF + (HALO - ta) * RS) >> 2) : base0;   // (padding units: zero fragments on finite operands)
@@ -236,14 +328,16 @@ finc_stream_kernel(const float *__restrict__ in, const float *__restrict__ bank,
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
                     a[mt] = ar[d][mt];
-                    ar[d][mt] = *(const v4f *)(pf + (size_t)(d * MT + mt) * 1024 + aoff);
+                    if constexpr (!(FINC_STREAM_ABLATE & 1)) ar[d][mt] = *(const v4f *)(pf + (size_t)(d * MT + mt) * 1024 + aoff);
                 }
                 __builtin_amdgcn_sched_barrier(0);     // the requests of later units go out BEFORE this unit's MFMAs
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int mt = 0; mt < MT; ++mt)
-                        acc[mt][i % AS] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][i], bcur[i], acc[mt][i % AS], 0, 0, 0);
+                    for (int mt = 0; mt < MT; ++mt) {
+                        if constexpr (FINC_STREAM_ABLATE & 2) acc[mt][i % AS][i] += a[mt][i] * bcur[i];
+                        else acc[mt][i % AS] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[mt][i], bcur[i], acc[mt][i % AS], 0, 0, 0);
+                    }
                 bcur = bnext;
             }
         }
@@ -265,13 +359,10 @@ finc_stream_kernel(const float *__restrict__ in, const float *__restrict__ bank,
             }
         }
         pos_step(pc, Wp);
-        if constexpr (INV) {
-            store_main(ZOFF + ((t + 1) & 1) * SLOTF);
-            store_halo(cur * SLOTF);
-        } else {
-            store_main(nslot * SLOTF);
-            store_halo(nslot * SLOTF);
-        }
+        const int moff = INV ? ZOFF + ((t + 1) & 1) * SLOTF : nslot * SLOTF;
+        if constexpr (VEC) store_main_vec(moff);
+        else store_main(moff);
+        store_halo(INV ? cur * SLOTF : nslot * SLOTF);
         lds_barrier();
         cur = nslot;
     }
@@ -309,10 +400,10 @@ __global__ void stream_solve_kernel(const float *__restrict__ wc, const float *_
 // fragments: [g][wave][unit][tile][lane (j, m)][i] = M_tau[row 16 tile + m][col 16 kq + 4 j + i]; bias [g][Cqp]
 __global__ void stream_frag_kernel(const float *__restrict__ wc, const double *__restrict__ scratch, const float *__restrict__ scale,
                                    const float *__restrict__ shift, float *__restrict__ bankp, float *__restrict__ biasp, int G, int Cq,
-                                   int KH, int KW, int MT, int U, int inverse, int transpose)
+                                   int KH, int KW, int MT, int NW, int U, int inverse, int transpose)
 {
-    const int NT = KH * KW, NKQ = 4 * MT, Cqp = 64 * MT;
-    const size_t per_g = (size_t)SNW * U * MT * 256;
+    const int NT = KH * KW, NKQ = NW * MT, Cqp = 16 * NW * MT;
+    const size_t per_g = (size_t)NW * U * MT * 256;
     const size_t total = per_g * G;
     for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
         const int g = (int)(idx / per_g);
@@ -349,26 +440,40 @@ __global__ void stream_frag_kernel(const float *__restrict__ wc, const double *_
 }
 
 typedef void (*stream_fn)(const float *, const float *, const float *, float *, int, int, int, int, int, int, unsigned, int, int, int);
-stream_fn pick(int MT, bool inv)
+template <int MT, int NW>
+stream_fn pick4(bool inv, bool vec)
 {
+    return inv ? (vec ? finc_stream_kernel<MT, NW, true, true> : finc_stream_kernel<MT, NW, true, false>)
+               : (vec ? finc_stream_kernel<MT, NW, false, true> : finc_stream_kernel<MT, NW, false, false>);
+}
+stream_fn pick(int MT, int NW, bool inv, bool vec)
+{
+    if (NW == 1) {
+        switch (MT) {
+        case 1: return pick4<1, 1>(inv, vec);
+        case 2: return pick4<2, 1>(inv, vec);
+        case 3: return pick4<3, 1>(inv, vec);
+        }
+        return nullptr;
+    }
     switch (MT) {
-    case 1: return inv ? finc_stream_kernel<1, true> : finc_stream_kernel<1, false>;
-    case 2: return inv ? finc_stream_kernel<2, true> : finc_stream_kernel<2, false>;
-    case 3: return inv ? finc_stream_kernel<3, true> : finc_stream_kernel<3, false>;
-    case 4: return inv ? finc_stream_kernel<4, true> : finc_stream_kernel<4, false>;
+    case 1: return pick4<1, 4>(inv, vec);
+    case 2: return pick4<2, 4>(inv, vec);
+    case 3: return pick4<3, 4>(inv, vec);
+    case 4: return pick4<4, 4>(inv, vec);
     }
     return nullptr;
 }
 
 size_t align256(size_t n) { return (n + 255) / 256 * 256; }
-size_t bank_bytes(const Geo &q, int G) { return align256((size_t)G * SNW * q.U * q.MT * 256 * sizeof(float)); }
+size_t bank_bytes(const Geo &q, int G) { return align256((size_t)G * q.NW * q.U * q.MT * 256 * sizeof(float)); }
 size_t bias_bytes(const Geo &q, int G) { return align256((size_t)G * q.Cqp * sizeof(float)); }
 
 } // namespace
 
 bool finc_stream_bank_ok(int Cq, int KH, int KW)
 {
-    return Cq >= 1 && Cq <= 64 * SMAXMT && KH >= 1 && KW >= 1 && KH <= SMAXK && KW <= SMAXK;
+    return Cq >= 1 && Cq <= SMAXCQ && KH >= 1 && KW >= 1 && KH <= SMAXK && KW <= SMAXK;
 }
 
 bool finc_stream_supported(int Cq, int H, int W, int KH, int KW, bool inverse)
@@ -404,20 +509,21 @@ int finc_stream_pack(const float *wc, const float *scale, const float *shift, vo
         hipLaunchKernelGGL(stream_solve_kernel, dim3((threads + 63) / 64), dim3(64), 0, st, wc, scale, shift, scratch, G, Cq, KH, KW);
         FINC_CHECK_LAUNCH();
     }
-    const size_t total = (size_t)G * SNW * q.U * q.MT * 256;
+    const size_t total = (size_t)G * q.NW * q.U * q.MT * 256;
     size_t blocks = (total + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(stream_frag_kernel, dim3((unsigned)blocks), dim3(256), 0, st, wc, (const double *)scratch, scale, shift, bankp, biasp,
-                       G, Cq, KH, KW, q.MT, q.U, inverse ? 1 : 0, transpose ? 1 : 0);
+                       G, Cq, KH, KW, q.MT, q.NW, q.U, inverse ? 1 : 0, transpose ? 1 : 0);
     FINC_CHECK_LAUNCH();
     return FINC_OK;
 }
 
-int finc_stream_info(const FincShape &s, bool inverse, int *cqp, int *lds, int *steps)
+int finc_stream_info(const FincShape &s, bool inverse, int *cqp, int *lds, int *steps, int *waves)
 {
     if (!finc_stream_supported(s.Cq, s.H, s.W, s.KH, s.KW, inverse)) return FINC_ERR_UNSUPPORTED;
     const Geo q = make_geo(s.Cq, s.W, s.KH, s.KW, inverse);
     if (cqp) *cqp = q.Cqp;
+    if (waves) *waves = q.NW;
     if (lds) *lds = (int)q.lds;
     if (steps) *steps = ((s.H + 15) / 16 - 1) * q.Wp + s.W + 15;
     return FINC_OK;
@@ -428,13 +534,15 @@ int finc_stream_launch(const float *in, const void *packed, float *out, const Fi
     if (!finc_stream_supported(s.Cq, s.H, s.W, s.KH, s.KW, inverse)) return FINC_ERR_UNSUPPORTED;
     if (((uintptr_t)packed & 15u) != 0) return FINC_ERR_ALIGNMENT;
     const Geo q = make_geo(s.Cq, s.W, s.KH, s.KW, inverse);
-    const stream_fn fn = pick(q.MT, inverse);
+    // the 16-byte operand loader needs whole groups of four columns and aligned rows
+    const bool vec = q.NW == 4 && s.W % 4 == 0 && ((uintptr_t)in & 15u) == 0;   // (one-wave problems: 12 of 64 lanes would hold a channel)
+    const stream_fn fn = pick(q.MT, q.NW, inverse, vec);
     if (!fn) return FINC_ERR_UNSUPPORTED;
     if (int e = finc_ensure_dynamic_lds((const void *)fn, q.lds)) return e;
     const float *bankp = (const float *)packed;
     const float *biasp = (const float *)((const char *)packed + bank_bytes(q, s.G));
     const int xcdmap = (s.G <= 8 && 8 % s.G == 0 && s.B % (8 / s.G) == 0) ? 1 : 0;
-    hipLaunchKernelGGL(fn, dim3(s.B * s.G), dim3(256), q.lds, st, in, bankp, biasp, out, s.G, s.Cq, s.H, s.W, s.KH, s.KW, s.orient, q.U,
+    hipLaunchKernelGGL(fn, dim3(s.B * s.G), dim3(64 * q.NW), q.lds, st, in, bankp, biasp, out, s.G, s.Cq, s.H, s.W, s.KH, s.KW, s.orient, q.U,
                        q.Wp, xcdmap);
     FINC_CHECK_LAUNCH();
     return FINC_OK;

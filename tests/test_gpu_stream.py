@@ -33,7 +33,7 @@ def orient_of(G):
     return ORIENT_FASTFLOW if G == 4 else (0x1B & ((1 << (2 * G)) - 1))
 
 
-# (B, G, Cq, H, W, KH, KW): every tile count (64, 128, 192, 256 padded channels), full and padded channel counts, one band / partial
+# (B, G, Cq, H, W, KH, KW): every tile count (16, 32, 48 padded channels on one wave; 64, 128, 192, 256 on four), full and padded channel counts, one band / partial
 # last band / several bands, maps narrower than a band's 16 rows and than the filter, a single row, widths that are no multiple of
 # four, G = 1 / 2 / 4 / 8 (the XCD-aware problem map and the plain one), every filter family the tables leave out
 STREAM_CASES = [
@@ -55,8 +55,9 @@ def test_streaming_bank_inverse(case, dev):
     B, G, Cq, H, W, KH, KW = case
     orient = orient_of(G)
     v = _lib.inverse_variant(B, G, Cq, H, W, KH, KW)
-    assert v is not None and v["sec"] == 7 and v["nw"] == 4 and v["workgroups"] == B * G and v["row"] == -3, v
-    assert v["cqp"] == (Cq + 63) // 64 * 64
+    nw = 1 if Cq <= 48 else 4              # one-wave problems up to 48 channels, a workgroup of four waves beyond
+    assert v is not None and v["sec"] == 7 and v["nw"] == nw and v["workgroups"] == B * G and v["row"] == -3, v
+    assert v["cqp"] == (Cq + 16 * nw - 1) // (16 * nw) * (16 * nw)
     e_max, _ = run_inverse_case(dev, B, G, orient, Cq, H, W, KH, KW, seed=13 * Cq + H + 3 * W + KH, tag="stream")
     assert e_max <= TOL
     rng = np.random.default_rng(3)
