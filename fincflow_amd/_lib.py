@@ -130,10 +130,10 @@ def backward_variant(B, G, Cq, H, W, KH, KW):
     waves per strip (0 = direct kernel, > 1 = K-split), whether grad-input takes the staged form, and `conv_form`: the kernel
     the forward and grad-input run ("scalar", "strip", "strip16" = 16-byte pieces, "winograd" = F(2,3) along W, "msplit" = the
     big banks' M-split over eight waves, "winograd4" = F(4,3) along W, "winograd25" = F(2,5) along W for the 5x5 banks, "winograd4m" = F(4,3) M-split over a workgroup's waves
-    for the 3x3 banks of 28 .. 64 channels)."""
+    for the 3x3 banks of 28 .. 64 channels, "stream" = the streaming-bank kernel of the banks beyond every table, finc_stream.hip)."""
     info = (ctypes.c_int * 3)()
     check(lib().finc_debug_backward_variant(B, G, Cq, H, W, KH, KW, info), "finc_debug_backward_variant")
-    form = "scalar" if info[1] == 0 else ("strip", "strip16", "winograd", "msplit", "winograd4", "winograd25", "winograd4m")[info[2]]
+    form = "scalar" if info[1] == 0 else ("strip", "strip16", "winograd", "msplit", "winograd4", "winograd25", "winograd4m", "stream")[info[2]]
     return {"gradw": ("direct", "dword", "staged", "tiled", "winograd", "winograd_tiled")[info[0]], "gradx_waves": info[1], "gradx_staged": bool(info[2]),
             "conv_form": form}
 

@@ -1350,12 +1350,36 @@ const GradwWinoInst *find_gradw_wino(const FincShape &s)
     return best;
 }
 // the smallest compiled bank that holds Cq channels (every kernel here tests `channel < CQ` per lane: any padding is fine)
+// the tile-pair kernels take any tile count: the filter shapes they are compiled for
+gradw_tiled_fn tiled_for(int KH, int KW)
+{
+    switch (KH * 8 + KW) {
+    case 2 * 8 + 2: return finc_gradw_tiled_kernel<2, 2>;
+    case 3 * 8 + 3: return finc_gradw_tiled_kernel<3, 3>;
+    case 4 * 8 + 4: return finc_gradw_tiled_kernel<4, 4>;
+    case 5 * 8 + 5: return finc_gradw_tiled_kernel<5, 5>;
+    case 2 * 8 + 3: return finc_gradw_tiled_kernel<2, 3>;
+    case 3 * 8 + 2: return finc_gradw_tiled_kernel<3, 2>;
+    case 3 * 8 + 5: return finc_gradw_tiled_kernel<3, 5>;
+    case 5 * 8 + 3: return finc_gradw_tiled_kernel<5, 3>;
+    }
+    return nullptr;
+}
+
 const GradwInst *find_gradw(int Cq, int KH, int KW)
 {
     const GradwInst *best = nullptr;
     for (const GradwInst &i : g_gradw)
         if (i.cqp >= Cq && i.kh == KH && i.kw == KW && (!best || i.cqp < best->cqp)) best = &i;
-    return best;
+    if (best) return best;
+    // banks beyond the table (the forward / grad-input of these run on the streaming-bank kernel, finc_stream.hip): one
+    // (o, i) tile pair per workgroup, whatever the number of tiles
+    const gradw_tiled_fn t = tiled_for(KH, KW);
+    if (!t || Cq < 1 || Cq > FINC_MAX_CQ) return nullptr;
+    static thread_local GradwInst gen;
+    const int cqp = (Cq + 15) / 16 * 16;
+    gen = GradwInst{cqp, KH, KW, cqp / 16, nullptr, nullptr, t};
+    return &gen;
 }
 
 } // namespace

@@ -7,5 +7,5 @@ NAME=$1; shift
 cd "$(dirname "$0")/../fincflow_amd/csrc"
 mkdir -p ../../ablate_build
 hipcc -O3 -fPIC --offload-arch=gfx950 -std=c++20 -mllvm -amdgpu-mfma-vgpr-form -DFINC_EXPERIMENT -DFINC_ONLY_C3 "$@" -c finc_chain.hip -o ../../ablate_build/chain_$NAME.o
-hipcc --offload-arch=gfx950 -shared -fPIC -o ../../ablate_build/libfinc_$NAME.so finc_abi.o finc_generic.o finc_f64.o finc_mfma.o finc_split.o finc_big.o finc_conv.o finc_wino.o finc_gradw.o finc_mix.o finc_probe.o finc_wino5.o finc_wino4m.o ../../ablate_build/chain_$NAME.o
+hipcc --offload-arch=gfx950 -shared -fPIC -o ../../ablate_build/libfinc_$NAME.so finc_abi.o finc_generic.o finc_f64.o finc_mfma.o finc_split.o finc_big.o finc_conv.o finc_wino.o finc_gradw.o finc_mix.o finc_probe.o finc_wino5.o finc_wino4m.o finc_stream.o ../../ablate_build/chain_$NAME.o
 echo built ablate_build/libfinc_$NAME.so

@@ -72,13 +72,20 @@ def test_streaming_bank_inverse(case, dev):
 @pytest.mark.parametrize("case", STREAM_CASES, ids=case_id)
 def test_streaming_bank_forward_and_input_gradient(case, dev):
     """Forward and grad-input (the same kernel on the transposed bank and the flipped image) against the oracle's fp64-accumulated
-    forward and CPU fp64 autograd; the weight gradient of these banks stays on the direct kernel and is checked with its mask."""
+    forward and CPU fp64 autograd; the weight gradient on the tile-pair kernels, checked entry by entry with its mask."""
     import torch.nn.functional as F
     from fincflow_amd import _lib, ops
     B, G, Cq, H, W, KH, KW = case
     orient = orient_of(G)
     L = _lib.lib()
     assert L.finc_forward_algo_for(Cq, H, W, KH, KW) == _lib.ALGO["mfma"]
+    bv = _lib.backward_variant(B, G, Cq, H, W, KH, KW)
+    assert bv["conv_form"] == "stream" and bv["gradx_waves"] == (1 if Cq <= 48 else 4), bv
+    # the weight gradient: the tile-pair kernels take any number of tiles (finc_gradw.hip) -- Winograd at 3x3 / 5x5 on maps of at least
+    # one strip, the direct tile-pair form for the other filters up to 5 columns wide; beyond that (6x6, 7x7, W % 4 != 0) the direct kernel
+    want_gw = ("direct" if (W % 4 or KW > 5 or (KH, KW) not in ((2, 2), (3, 3), (4, 4), (5, 5), (2, 3), (3, 2), (3, 5), (5, 3))) else
+               "winograd_tiled" if ((KH, KW) == (3, 3) and W >= 32) or ((KH, KW) == (5, 5) and W >= 16) else "tiled")
+    assert bv["gradw"] == want_gw, (bv, want_gw)
     rng = np.random.default_rng(11 * Cq + W)
     ws = oracle.make_stored_weights(G, Cq, KH, KW, orient=orient, seed=5, std=bank_std(Cq, max(KH, KW)))
     wco = oracle.canonicalize(ws, G, orient)

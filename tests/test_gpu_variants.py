@@ -578,7 +578,7 @@ def test_a_protocol_timeout_is_an_error_not_a_silent_wrong_answer(dev, tmp_path)
     if not shutil.which("hipcc"):
         pytest.skip("no hipcc on this box")
     csrc = os.path.join(REPO, "fincflow_amd", "csrc")
-    objs = [os.path.join(csrc, o) for o in ("finc_abi.o", "finc_generic.o", "finc_chain.o", "finc_f64.o", "finc_big.o", "finc_conv.o", "finc_wino.o", "finc_gradw.o", "finc_mix.o", "finc_probe.o", "finc_wino5.o", "finc_wino4m.o")]
+    objs = [os.path.join(csrc, o) for o in ("finc_abi.o", "finc_generic.o", "finc_chain.o", "finc_f64.o", "finc_big.o", "finc_conv.o", "finc_wino.o", "finc_gradw.o", "finc_mix.o", "finc_probe.o", "finc_wino5.o", "finc_wino4m.o", "finc_stream.o")]
     if not all(os.path.exists(o) for o in objs):
         pytest.skip("object files of the product build are not in the tree")
     lib = str(tmp_path / "libfinc_faulty.so")
