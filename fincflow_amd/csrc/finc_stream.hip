@@ -28,7 +28,7 @@ namespace {
 typedef float v4f __attribute__((ext_vector_type(4)));
 
 // FINC_STREAM_ABLATE (timing-only builds, wrong results): 1 = the bank is not re-read (the fragments of the first units stay),
-// 2 = no MFMAs, 4 = no operand loads (z / halo rows), 8 = every wave starts the bank stream at block 0;
+// 2 = no MFMAs, 4 = no operand loads (z / halo rows), 8 = every wave starts the bank stream at block 0, 16 = no stores;
 // FINC_STREAM_SPD overrides the prefetch depth
 #ifndef FINC_STREAM_ABLATE
 #define FINC_STREAM_ABLATE 0
@@ -60,7 +60,7 @@ Geo make_geo(int Cq, int W, int KH, int KW, bool inv)
     q.RS = q.Cqp + 4;
     q.SLOTF = (16 + q.HALO) * q.RS;
     const int smax = KH + KW - 2;
-    q.NRING = inv ? smax + 1 : smax + 2;
+    q.NRING = inv ? (smax + 1 > 5 ? smax + 1 : 5) : smax + 2;   // (inverse: at least the four steps a row's 16-byte store gathers)
     q.NSLOT = q.NRING + (inv ? 2 : 0);
     q.SPD = spd_of(q.MT);
     q.U = (q.NT * q.NKQ + q.SPD - 1) / q.SPD * q.SPD;
@@ -120,7 +120,7 @@ finc_stream_kernel(const float *__restrict__ in, const float *__restrict__ bank,
     const int j = lane >> 4, n = lane & 15;
     const int NT = KH * KW, HALO = KH - 1, SLOTF = (16 + HALO) * RS;
     const int smax = KH + KW - 2;
-    const int NRING = INV ? smax + 1 : smax + 2;
+    const int NRING = INV ? (smax + 1 > 5 ? smax + 1 : 5) : smax + 2;
     const int ZOFF = NRING * SLOTF;                    // (INV) the two z slots behind the ring
 
     int b, g;
@@ -215,6 +215,41 @@ finc_stream_kernel(const float *__restrict__ in, const float *__restrict__ bank,
             }
         }
     };
+    // the inverse's stores in the same form: a row's last four solved columns sit in the ring's last four slots; the wave that
+    // owns the row writes them as one 16-byte piece per channel the step after the group's last column was solved (a scalar
+    // branch per row; 4 MT stores of 1 KB per wave and step instead of 4 MT scattered dword stores that leave every line
+    // of the output 32 times)
+    Pos ps[RPW];
+    if constexpr (VEC && INV) {
+#pragma unroll
+        for (int k = 0; k < RPW; ++k) pos_init(ps[k], -(RPW * wave + k) - 1, Wp);   // the step BEFORE the current one
+    }
+    auto store_rows_vec = [&](int cur_slot) {
+#pragma unroll
+        for (int k = 0; k < RPW; ++k) {
+            const int rho = RPW * wave + k;
+            const int c = ps[k].col, h = ps[k].band * 16 + rho;
+            if ((c & 3) == 3 && c >= 0 && c < W && ps[k].band < NB && h < H) {
+                const int hh = (o & FINC_FLIP_H) ? H - 1 - h : h;
+                const int wc = (o & FINC_FLIP_W) ? W - 1 - c : c - 3;
+                int sl[4];                                                    // ring slots of the steps s-4 .. s-1 (columns c-3 .. c)
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    int t_ = cur_slot - 4 + d;
+                    sl[d] = (t_ < 0 ? t_ + NRING : t_) * SLOTF + (rho + HALO) * RS;
+                }
+#pragma unroll
+                for (int cg = 0; cg < CG; ++cg) {
+                    const int ch = lane + 64 * cg;
+                    if (ch < Cq && !(FINC_STREAM_ABLATE & 16)) {
+                        const float x0 = lds[sl[0] + ch], x1 = lds[sl[1] + ch], x2 = lds[sl[2] + ch], x3 = lds[sl[3] + ch];
+                        *(v4f *)(dst + (size_t)ch * HW + hh * W + wc) = (o & FINC_FLIP_W) ? v4f{x3, x2, x1, x0} : v4f{x0, x1, x2, x3};
+                    }
+                }
+            }
+            pos_step(ps[k], Wp);
+        }
+    };
     auto load_halo = [&]() {
         const int pix = hact ? pos_pix(ph, -1 - hidx, H, W, NB, o) : -1;
 #pragma unroll
@@ -273,6 +308,7 @@ finc_stream_kernel(const float *__restrict__ in, const float *__restrict__ bank,
 
     int cur = 0;                                       // ring slot of step t
     for (int t = 0; t < Tend; ++t) {
+        if constexpr (VEC && INV) store_rows_vec(cur);      // the groups of four columns the last step completed
         // requests of the next step's operands
         if constexpr (VEC) {
             fetch_main_vec();                          // slot t+1
@@ -352,10 +388,10 @@ finc_stream_kernel(const float *__restrict__ in, const float *__restrict__ bank,
             const int ch = (wave * MT + mt) * 16 + 4 * j;
             if (pix < 0) v = v4f{0.f, 0.f, 0.f, 0.f};
             if constexpr (INV) ((v4f *)lds)[((cur * SLOTF + (n + HALO) * RS) >> 2) + (ch >> 2)] = v;
-            if (pix >= 0) {
+            if (pix >= 0 && !(VEC && INV)) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
-                    if (ch + i < Cq) dst[(size_t)(ch + i) * HW + pix] = v[i];
+                    if (ch + i < Cq && !(FINC_STREAM_ABLATE & 16)) dst[(size_t)(ch + i) * HW + pix] = v[i];
             }
         }
         pos_step(pc, Wp);
@@ -366,6 +402,7 @@ finc_stream_kernel(const float *__restrict__ in, const float *__restrict__ bank,
         lds_barrier();
         cur = nslot;
     }
+    if constexpr (VEC && INV) store_rows_vec(cur);          // the groups the last step completed
 }
 
 // ---- packing ----
@@ -535,7 +572,7 @@ int finc_stream_launch(const float *in, const void *packed, float *out, const Fi
     if (((uintptr_t)packed & 15u) != 0) return FINC_ERR_ALIGNMENT;
     const Geo q = make_geo(s.Cq, s.W, s.KH, s.KW, inverse);
     // the 16-byte operand loader needs whole groups of four columns and aligned rows
-    const bool vec = q.NW == 4 && s.W % 4 == 0 && ((uintptr_t)in & 15u) == 0;   // (one-wave problems: 12 of 64 lanes would hold a channel)
+    const bool vec = q.NW == 4 && s.W % 4 == 0 && (((uintptr_t)in | (uintptr_t)out) & 15u) == 0;   // (one-wave problems: 12 of 64 lanes would hold a channel)
     const stream_fn fn = pick(q.MT, q.NW, inverse, vec);
     if (!fn) return FINC_ERR_UNSUPPORTED;
     if (int e = finc_ensure_dynamic_lds((const void *)fn, q.lds)) return e;

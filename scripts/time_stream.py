@@ -48,6 +48,9 @@ for (B, G, Cq, H, W, KH, KW, what) in SHAPES:
         t_inv = timed(lambda: cache.inverse(z, weights, G, orient, out=o), 5, 2)
         err = float((o - x).abs().max() / x.abs().max())
         t_fwd = timed(lambda: cache.forward(x, weights, G, orient, out=o), 5, 2)
+        gzr = torch.randn_like(x)
+        t_bwd = timed(lambda: ops.finc_backward(gzr, x, cache.w_canon, G, orient), 3, 1)
+        bv = _lib.backward_variant(B, G, Cq, H, W, KH, KW)
         nb = max(1, B // 16)                       # the reference-order kernels on a sixteenth of the batch (they scale with it)
         wc = cache.w_canon
         zs, xs = z[:nb].contiguous(), x[:nb].contiguous()
@@ -58,4 +61,4 @@ for (B, G, Cq, H, W, KH, KW, what) in SHAPES:
     af = 2.0 * KH * KW * Cq * Cq * H * W * B * G
     print(f"{what}: form {v['sec'] if v else None} inverse {t_inv:9.1f} us ({mf / t_inv * 1e-6:5.1f} TF executed, {af / t_inv * 1e-6:5.1f} algorithmic) "
           f"forward {t_fwd:9.1f} us ({mf / t_fwd * 1e-6:5.1f} TF) | strict inverse {t_sinv:11.1f} us (x{t_sinv / t_inv:6.1f}) strict forward {t_sfwd:10.1f} us "
-          f"(x{t_sfwd / t_fwd:5.1f}) | round trip err {err:.1e}", flush=True)
+          f"(x{t_sfwd / t_fwd:5.1f}) | backward (grad-input {bv['conv_form']} + grad-weight {bv['gradw']}) {t_bwd:9.1f} us | round trip err {err:.1e}", flush=True)
