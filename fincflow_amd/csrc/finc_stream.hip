@@ -45,7 +45,7 @@ constexpr int SMAXCQ = 256;
 
 struct Geo {
     int Cqp, MT, NW, NKQ, NT, HALO, RS, SLOTF, NRING, NSLOT, U, Wp, SPD;
-    size_t lds;
+    size_t lds, lds_vec;   // (lds_vec: with the forward's ring of outputs for its 16-byte stores)
 };
 
 Geo make_geo(int Cq, int W, int KH, int KW, bool inv)
@@ -66,6 +66,7 @@ Geo make_geo(int Cq, int W, int KH, int KW, bool inv)
     q.U = (q.NT * q.NKQ + q.SPD - 1) / q.SPD * q.SPD;
     q.Wp = W + KW - 1 > SMINWP ? W + KW - 1 : SMINWP;
     q.lds = (size_t)q.NSLOT * q.SLOTF * sizeof(float);
+    q.lds_vec = q.lds + (inv ? 0 : (size_t)5 * 16 * q.RS * sizeof(float));
     return q;
 }
 
@@ -121,7 +122,7 @@ finc_stream_kernel(const float *__restrict__ in, const float *__restrict__ bank,
     const int NT = KH * KW, HALO = KH - 1, SLOTF = (16 + HALO) * RS;
     const int smax = KH + KW - 2;
     const int NRING = INV ? (smax + 1 > 5 ? smax + 1 : 5) : smax + 2;
-    const int ZOFF = NRING * SLOTF;                    // (INV) the two z slots behind the ring
+    const int ZOFF = NRING * SLOTF;                    // (INV) the two z slots behind the ring; (forward, VEC) five slots of 16 output rows
 
     int b, g;
     {
@@ -143,7 +144,7 @@ finc_stream_kernel(const float *__restrict__ in, const float *__restrict__ bank,
     const int NB = (H + 15) >> 4;
     const int Tend = (NB - 1) * Wp + W + 15;
 
-    for (int e = tid; e < (NRING + (INV ? 2 : 0)) * SLOTF; e += NTHR) lds[e] = 0.f;
+    for (int e = tid; e < (NRING + (INV ? 2 : 0)) * SLOTF + ((VEC && !INV) ? 5 * 16 * RS : 0); e += NTHR) lds[e] = 0.f;
 
     // ---- loaders: the 16 rows of a slot (thread -> row, 4 MT channels), its halo rows (thread -> halo row, channels) ----
     const int mrow = tid & 15, mch = tid >> 4;          // channels mch + 4 NW i
@@ -220,7 +221,7 @@ finc_stream_kernel(const float *__restrict__ in, const float *__restrict__ bank,
     // branch per row; 4 MT stores of 1 KB per wave and step instead of 4 MT scattered dword stores that leave every line
     // of the output 32 times)
     Pos ps[RPW];
-    if constexpr (VEC && INV) {
+    if constexpr (VEC) {
 #pragma unroll
         for (int k = 0; k < RPW; ++k) pos_init(ps[k], -(RPW * wave + k) - 1, Wp);   // the step BEFORE the current one
     }
@@ -236,7 +237,8 @@ finc_stream_kernel(const float *__restrict__ in, const float *__restrict__ bank,
 #pragma unroll
                 for (int d = 0; d < 4; ++d) {
                     int t_ = cur_slot - 4 + d;
-                    sl[d] = (t_ < 0 ? t_ + NRING : t_) * SLOTF + (rho + HALO) * RS;
+                    if constexpr (INV) sl[d] = (t_ < 0 ? t_ + NRING : t_) * SLOTF + (rho + HALO) * RS;
+                    else sl[d] = ZOFF + (t_ < 0 ? t_ + 5 : t_) * (16 * RS) + rho * RS;          // (the forward's own ring of outputs)
                 }
 #pragma unroll
                 for (int cg = 0; cg < CG; ++cg) {
@@ -306,9 +308,9 @@ finc_stream_kernel(const float *__restrict__ in, const float *__restrict__ bank,
     const int blane4 = n * (RS / 4) + j;
     lds_barrier();
 
-    int cur = 0;                                       // ring slot of step t
+    int cur = 0, ocur = 0;                             // ring slot of step t (ocur: in the forward's ring of outputs)
     for (int t = 0; t < Tend; ++t) {
-        if constexpr (VEC && INV) store_rows_vec(cur);      // the groups of four columns the last step completed
+        if constexpr (VEC) store_rows_vec(INV ? cur : ocur);      // the groups of four columns the last step completed
         // requests of the next step's operands
         if constexpr (VEC) {
             fetch_main_vec();                          // slot t+1
@@ -388,7 +390,8 @@ finc_stream_kernel(const float *__restrict__ in, const float *__restrict__ bank,
             const int ch = (wave * MT + mt) * 16 + 4 * j;
             if (pix < 0) v = v4f{0.f, 0.f, 0.f, 0.f};
             if constexpr (INV) ((v4f *)lds)[((cur * SLOTF + (n + HALO) * RS) >> 2) + (ch >> 2)] = v;
-            if (pix >= 0 && !(VEC && INV)) {
+            else if constexpr (VEC) ((v4f *)lds)[((ZOFF + ocur * (16 * RS) + n * RS) >> 2) + (ch >> 2)] = v;
+            if (pix >= 0 && !VEC) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
                     if (ch + i < Cq && !(FINC_STREAM_ABLATE & 16)) dst[(size_t)(ch + i) * HW + pix] = v[i];
@@ -401,8 +404,9 @@ finc_stream_kernel(const float *__restrict__ in, const float *__restrict__ bank,
         store_halo(INV ? cur * SLOTF : nslot * SLOTF);
         lds_barrier();
         cur = nslot;
+        ocur = ocur == 4 ? 0 : ocur + 1;
     }
-    if constexpr (VEC && INV) store_rows_vec(cur);          // the groups the last step completed
+    if constexpr (VEC) store_rows_vec(INV ? cur : ocur);    // the groups the last step completed
 }
 
 // ---- packing ----
@@ -572,14 +576,15 @@ int finc_stream_launch(const float *in, const void *packed, float *out, const Fi
     if (((uintptr_t)packed & 15u) != 0) return FINC_ERR_ALIGNMENT;
     const Geo q = make_geo(s.Cq, s.W, s.KH, s.KW, inverse);
     // the 16-byte operand loader needs whole groups of four columns and aligned rows
-    const bool vec = q.NW == 4 && s.W % 4 == 0 && (((uintptr_t)in | (uintptr_t)out) & 15u) == 0;   // (one-wave problems: 12 of 64 lanes would hold a channel)
+    const bool vec = q.NW == 4 && s.W % 4 == 0 && (((uintptr_t)in | (uintptr_t)out) & 15u) == 0 && q.lds_vec <= 160 * 1024;
+    const size_t lds_bytes = vec ? q.lds_vec : q.lds;   // (one-wave problems: 12 of 64 lanes would hold a channel)
     const stream_fn fn = pick(q.MT, q.NW, inverse, vec);
     if (!fn) return FINC_ERR_UNSUPPORTED;
-    if (int e = finc_ensure_dynamic_lds((const void *)fn, q.lds)) return e;
+    if (int e = finc_ensure_dynamic_lds((const void *)fn, lds_bytes)) return e;
     const float *bankp = (const float *)packed;
     const float *biasp = (const float *)((const char *)packed + bank_bytes(q, s.G));
     const int xcdmap = (s.G <= 8 && 8 % s.G == 0 && s.B % (8 / s.G) == 0) ? 1 : 0;
-    hipLaunchKernelGGL(fn, dim3(s.B * s.G), dim3(64 * q.NW), q.lds, st, in, bankp, biasp, out, s.G, s.Cq, s.H, s.W, s.KH, s.KW, s.orient, q.U,
+    hipLaunchKernelGGL(fn, dim3(s.B * s.G), dim3(64 * q.NW), lds_bytes, st, in, bankp, biasp, out, s.G, s.Cq, s.H, s.W, s.KH, s.KW, s.orient, q.U,
                        q.Wp, xcdmap);
     FINC_CHECK_LAUNCH();
     return FINC_OK;

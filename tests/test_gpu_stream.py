@@ -40,7 +40,7 @@ STREAM_CASES = [
     (2, 1, 192, 24, 20, 3, 3), (1, 4, 100, 17, 33, 3, 3), (1, 1, 256, 16, 16, 3, 3), (8, 1, 130, 8, 8, 3, 3), (4, 2, 110, 8, 12, 3, 3),
     (1, 4, 129, 1, 50, 3, 3), (2, 4, 8, 20, 24, 4, 4), (1, 4, 4, 33, 18, 7, 7), (2, 2, 64, 16, 16, 5, 5), (3, 4, 40, 9, 40, 2, 2),
     (2, 4, 32, 12, 28, 3, 5), (2, 4, 20, 5, 3, 6, 6), (1, 8, 50, 35, 7, 5, 5), (2, 4, 24, 40, 19, 5, 3), (3, 3, 17, 18, 64, 1, 7),
-    (2, 4, 80, 20, 24, 3, 3), (1, 4, 56, 33, 36, 5, 5), (2, 4, 72, 18, 8, 2, 2),     # 16-byte loads and stores in all four orientations
+    (2, 4, 104, 20, 24, 3, 3), (1, 4, 56, 33, 36, 5, 5), (2, 4, 72, 18, 8, 2, 2),     # 16-byte loads and stores in all four orientations
 ]
 
 
