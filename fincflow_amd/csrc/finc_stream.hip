@@ -36,9 +36,13 @@ typedef float v4f __attribute__((ext_vector_type(4)));
 #ifndef FINC_STREAM_SPD
 #define FINC_STREAM_SPD 0
 #endif
-// units (one B quad x MT fragment quads) of bank a wave keeps in flight.  Two tiles per wave: 6, so that the kernel stays
-// within 256 registers and two workgroups share a compute unit (and its L1: the second one's bank reads hit)
-constexpr int spd_of(int MT) { return FINC_STREAM_SPD ? FINC_STREAM_SPD : MT == 2 ? 6 : 8; }
+// units (one B quad x MT fragment quads) of bank a wave keeps in flight: 12 .. 16 KB per wave at two tiles and more (measured at
+// 192 channels: 8 -> 12 units -5 %), in counts that divide a tap's units (no padding units at 3x3) and keep the two-tile
+// kernel within 256 registers (two workgroups per compute unit)
+constexpr int spd_of(int MT) { return FINC_STREAM_SPD ? FINC_STREAM_SPD : MT == 1 ? 8 : MT == 4 ? 16 : 12; }
+// (the dword-operand form of the four-tile kernel holds 8: its scattered accesses leave no registers for 16; a stream is padded
+// to spd_of units, which 8 divides)
+constexpr int spd_kernel(int MT, bool vec) { return (!FINC_STREAM_SPD && MT == 4 && !vec) ? 8 : spd_of(MT); }
 constexpr int SMAXK = 7;     // KH, KW <= 7
 constexpr int SMINWP = 20;   // period of a band in steps: >= 16 + 4 (the halo rows' distance to their producer)
 constexpr int SMAXCQ = 256;
@@ -114,7 +118,7 @@ finc_stream_kernel(const float *__restrict__ in, const float *__restrict__ bank,
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int NTHR = 64 * NW, Cqp = 16 * NW * MT, NKQ = NW * MT, RS = Cqp + 4;
     constexpr int AS = MT == 1 ? 2 : 1;     // accumulators per tile: no MFMA waits on the one before it
-    constexpr int SPD = spd_of(MT);
+    constexpr int SPD = spd_kernel(MT, VEC);
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = NW == 1 ? 0 : __builtin_amdgcn_readfirstlane(tid >> 6);

@@ -29,6 +29,8 @@ for f in glob.glob(os.path.join(root, "**", "*counter_collection.csv"), recursiv
             k = "gradw_staged"
         elif "finc_gradw_tiled_kernel" in k:
             k = "gradw_tiled"
+        elif "finc_stream_kernel" in k:
+            k = "stream_inverse" if "ELb1ELb" in k or "true, " in k.split("finc_stream_kernel")[1][:24] else "stream_forward"
         elif "finc_big_kernel" in k:
             k = "inverse_big"
         elif "finc_bigfwd_kernel" in k:
