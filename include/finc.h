@@ -245,6 +245,10 @@ int finc_mix_f32(const float *in, const float *mat, const float *bias, float *ou
  *   info[3] = 6: its short-step form for the banks of up to 16 channels (finc_chain.hip: one wave carries the recurrence on a
  *     16-row tile, one wave per tap with a + b == 2 prepares the rest, one wave owns the HBM side; row = -1);
  *   info[3] = 5: the big-bank kernel (3x3 banks with 64 < Cq <= 96, 8 waves per problem; row = -2).
+ *   info[3] = 7: the streaming-bank kernel (finc_stream.hip) of every bank no table holds -- 3x3 above 96 channels per group,
+ *     5x5 above 48, 2x2 above 32, 4x4, 6x6, 7x7, non-square filters above 16 channels; Cq <= 256, KH, KW <= 7: the bank
+ *     streams from the L2 once per step, the solved pixels of the last KH+KW-2 steps sit in an LDS ring; info[0] = Cq padded
+ *     to 16 (one-wave problems, Cq <= 48) or 64 (four waves per problem), info[1] = waves per problem; row = -3.
  *   FINC_ERR_UNSUPPORTED when the shape runs on the strict kernel.
  * finc_debug_attr_table_insert: the (device, kernel) table behind the once-per-device kernel attributes; returns 1 if
  *   the pair was new.  Host-only; exists so the key logic is testable without two GPUs.
@@ -258,7 +262,8 @@ int finc_inverse_kernel_variant(int B, int G, int Cq, int H, int W, int KH, int 
  * workgroup) / 4 Winograd (3x3 banks of 13..32 channels: F(4,3) transposed, half the multiplies) / 5 Winograd on one tile pair
  * per wave (3x3 above 32 channels: F(4,3) transposed; 5x5 above 12: F(2,5) transposed), grad-input: waves per strip of the MFMA strip kernel (0 = direct kernel; > 1 = K-split), grad-input: staged form
  * (1) or dword form (0); 2 = Winograd F(2,3) along W, 3 = the big banks' M-split, 4 = Winograd F(4,3) along W, 5 = Winograd
- * F(2,5) along W (5x5 banks), 6 = Winograd F(4,3) M-split over a workgroup's waves (3x3 banks of 25 .. 64 channels)}.  Lets a parity
+ * F(2,5) along W (5x5 banks), 6 = Winograd F(4,3) M-split over a workgroup's waves (3x3 banks of 25 .. 64 channels), 7 = the
+ * streaming-bank kernel in its forward form (the banks beyond every table; info[1] = its waves per problem)}.  Lets a parity
  * test assert WHICH kernel its numbers came from. */
 int finc_debug_backward_variant(int B, int G, int Cq, int H, int W, int KH, int KW, int *info);
 /* Pins the kernel family of the 3x3 forward / grad-input for this process (tests and A/B timing of each form on one shape):

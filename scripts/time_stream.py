@@ -13,6 +13,7 @@ quick = len(sys.argv) > 1 and sys.argv[1] == "quick"
 SHAPES = [
     (256, 1, 192, 64, 64, 3, 3, "CINCFlowUnit C=192 (cinc_flow.py:9-30), 64x64, B=256"),
     (256, 4, 128, 32, 32, 3, 3, "FastFlowUnit C=512, 32x32, B=256"),
+    (256, 4, 100, 32, 32, 3, 3, "FastFlowUnit C=400, 32x32, B=256"),
     (64, 4, 64, 32, 32, 5, 5, "FastFlowUnit 5x5 C=256, 32x32, B=64"),
     (64, 4, 12, 32, 32, 4, 4, "FastFlowUnit 4x4 C=48, 32x32, B=64"),
     (64, 4, 12, 32, 32, 7, 7, "FastFlowUnit 7x7 C=48, 32x32, B=64"),
