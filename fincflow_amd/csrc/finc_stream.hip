@@ -493,11 +493,11 @@ stream_fn pick4(bool inv, bool vec)
 }
 stream_fn pick(int MT, int NW, bool inv, bool vec)
 {
-    if (NW == 1) {
+    if (NW == 1) {                      // (one-wave problems have no 16-byte form: 12 of 64 lanes would hold a channel)
         switch (MT) {
-        case 1: return pick4<1, 1>(inv, vec);
-        case 2: return pick4<2, 1>(inv, vec);
-        case 3: return pick4<3, 1>(inv, vec);
+        case 1: return inv ? finc_stream_kernel<1, 1, true, false> : finc_stream_kernel<1, 1, false, false>;
+        case 2: return inv ? finc_stream_kernel<2, 1, true, false> : finc_stream_kernel<2, 1, false, false>;
+        case 3: return inv ? finc_stream_kernel<3, 1, true, false> : finc_stream_kernel<3, 1, false, false>;
         }
         return nullptr;
     }

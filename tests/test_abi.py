@@ -50,8 +50,13 @@ def test_algo_selection_is_host_side_and_consistent():
     # c5 (Cq=48, 5x5): 900 fragments do not fit one wave -> K-split over the 4 waves of a workgroup, still MFMA
     assert L.finc_inverse_algo_for(48, 128, 128, 5, 5) == MFMA
     assert L.finc_forward_algo_for(48, 128, 128, 5, 5) == MFMA
-    # no instantiation at all (Cq=64, 7x7) -> reference-order kernel
-    assert L.finc_inverse_algo_for(64, 32, 32, 7, 7) == STRICT
+    # outside the register-resident tables (Cq=64, 7x7; CINCFlowUnit's 192 channels in one group) -> the streaming-bank kernel, still MFMA
+    assert L.finc_inverse_algo_for(64, 32, 32, 7, 7) == MFMA and L.finc_forward_algo_for(64, 32, 32, 7, 7) == MFMA
+    assert L.finc_inverse_algo_for(192, 64, 64, 3, 3) == MFMA and L.finc_forward_algo_for(192, 64, 64, 3, 3) == MFMA
+    assert _lib.inverse_variant(256, 1, 192, 64, 64, 3, 3)["sec"] == 7 and _lib.inverse_variant(8, 4, 12, 32, 32, 4, 4)["nw"] == 1
+    # beyond that kernel's limits (9x9 filter; a 7x7 bank of 96 channels whose step ring exceeds the LDS) -> reference-order kernel
+    assert L.finc_inverse_algo_for(16, 32, 32, 9, 9) == STRICT and L.finc_forward_algo_for(16, 32, 32, 9, 9) == STRICT
+    assert L.finc_inverse_algo_for(96, 32, 32, 7, 7) == STRICT
     # W not a multiple of 4 -> reference-order kernel
     assert L.finc_inverse_algo_for(24, 64, 63, 3, 3) == STRICT
     assert L.finc_workspace_bytes(4, 24, 3, 3) >= 4 * 108 * 64 * 4
@@ -70,7 +75,7 @@ def test_argument_validation_without_touching_the_gpu():
     # MFMA algo without a workspace
     assert L.finc_inverse_f32(one, one, ctypes.c_void_p(32), 1, 4, 24, 64, 64, 3, 3, 0xE4, 2, None, 0, None) == 4
     # MFMA algo on a shape it has no instantiation for
-    assert L.finc_inverse_f32(one, one, ctypes.c_void_p(32), 1, 4, 64, 32, 32, 7, 7, 0xE4, 2, one, 1 << 30, None) == 3
+    assert L.finc_inverse_f32(one, one, ctypes.c_void_p(32), 1, 4, 16, 32, 32, 9, 9, 0xE4, 2, one, 1 << 30, None) == 3
 
 
 def test_a_measurement_knob_without_the_experiment_gate_does_not_compile():
@@ -251,7 +256,10 @@ def test_grad_weight_form_is_host_side_and_follows_the_documented_rules():
         (8, 4, 13, 8, 4, 3, 3): "winograd", (8, 4, 32, 8, 16, 3, 3): "winograd", (8, 4, 24, 8, 18, 3, 3): "dword",
         (8, 4, 33, 8, 32, 3, 3): "winograd_tiled", (8, 4, 33, 8, 28, 3, 3): "tiled", (8, 1, 96, 8, 64, 3, 3): "winograd_tiled",
         (8, 4, 16, 8, 16, 5, 5): "winograd_tiled", (8, 4, 12, 8, 16, 5, 5): "staged", (8, 4, 48, 8, 12, 5, 5): "tiled",
-        (8, 4, 24, 8, 32, 2, 2): "staged", (8, 4, 4, 8, 32, 3, 5): "staged", (8, 4, 128, 8, 32, 3, 3): "direct",
+        (8, 4, 24, 8, 32, 2, 2): "staged", (8, 4, 4, 8, 32, 3, 5): "staged",
+        # banks beyond the tables (forward / grad-input on the streaming-bank kernel): the tile-pair kernels take any tile count
+        (8, 4, 128, 8, 32, 3, 3): "winograd_tiled", (8, 1, 192, 8, 28, 3, 3): "tiled", (8, 4, 64, 8, 16, 5, 5): "winograd_tiled",
+        (8, 4, 40, 8, 16, 2, 2): "tiled", (8, 4, 8, 8, 16, 4, 4): "tiled", (8, 4, 8, 8, 16, 7, 7): "direct", (8, 4, 8, 8, 15, 4, 4): "direct",
     }
     got = {k: _lib.backward_variant(*k)["gradw"] for k in want}
     assert got == want, {k: (got[k], want[k]) for k in want if got[k] != want[k]}

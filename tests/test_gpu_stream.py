@@ -170,3 +170,40 @@ def test_streaming_bank_carries_the_affine_folds(case, dev):
     assert gotf is not None
     wantf = (cache.forward(y, weights, G, orient) - translation) * torch.exp(-log_scale)
     assert rel_err(gotf.cpu().numpy(), wantf.cpu().numpy()) <= TOL
+
+
+@pytest.mark.parametrize("case", [(3, 160, 12, 16, (2, 2)), (2, 32, 9, 12, (4, 4)), (2, 448, 8, 8, (3, 3))], ids=lambda c: "B%d_C%d_%dx%d_k%dx%d" % (c[0], c[1], c[2], c[3], c[4][0], c[4][1]))
+def test_fastflowunit_module_on_streaming_banks(case, dev):
+    """The layer API (fastflow.py:15-55) on banks that only the streaming-bank kernels hold: forward under autograd, backward (masked weight
+    gradients in the four stored orientations), reverse -- against CPU fp64 autograd of the reference's own formulation (pad + conv2d per chunk)."""
+    import torch.nn.functional as F
+    from fincflow_amd import FastFlowUnit, _lib
+    B, C, H, W, (KH, KW) = case
+    Cq = C // 4
+    assert _lib.inverse_variant(B, 4, Cq, H, W, KH, KW)["sec"] == 7
+    torch.manual_seed(C + H)
+    unit = FastFlowUnit(C, C, (KH, KW)).to(dev)
+    convs = (unit.conv_tl, unit.conv_tr, unit.conv_bl, unit.conv_br)
+    with torch.no_grad():          # the free taps at the bank's own scale (init std 0.05 has no stable inverse at these widths), corner tap kept
+        for m in convs:
+            m.conv.weight.mul_(1 - (1 - bank_std(Cq, max(KH, KW)) / 0.05) * m.get_mask().to(dev))
+    x = torch.randn(B, C, H, W, device=dev)
+    gz = torch.randn(B, C, H, W, device=dev)
+    xg = x.clone().requires_grad_(True)
+    z, logdet = unit(xg)
+    z.backward(gz)
+    assert logdet == 0.0
+    with torch.no_grad():
+        xr = unit.reverse(z.detach())
+    assert rel_err(xr.cpu().numpy(), x.cpu().numpy()) <= 5e-5
+    xd = x.cpu().double().requires_grad_(True)
+    wds = [m.conv.weight.detach().cpu().double().requires_grad_(True) for m in convs]
+    ref = torch.cat([F.conv2d(F.pad(c, m.pad), w) for m, c, w in zip(convs, torch.chunk(xd, 4, 1), wds)], 1)
+    ref.backward(gz.cpu().double())
+    assert rel_err(z.detach().cpu().numpy(), ref.detach().numpy()) <= TOL
+    assert rel_err(xg.grad.cpu().numpy(), xd.grad.numpy()) <= TOL
+    for m, w in zip(convs, wds):
+        want = (w.grad * m.get_mask().cpu().double()).numpy()
+        assert rel_err(m.conv.weight.grad.cpu().numpy(), want) <= 2e-5
+    x_ref = oracle.inverse_via_f64(z.detach().cpu().numpy(), oracle.canonicalize(torch.cat(unit._weights()).detach().cpu().numpy(), 4, ORIENT_FASTFLOW), 4, ORIENT_FASTFLOW)
+    assert rel_err(xr.cpu().numpy(), x_ref) <= TOL
