@@ -1,5 +1,7 @@
 """GPU helper: random-shape parity sweep of the streaming-bank kernels (finc_stream.hip) against the oracle: inverse (auto against the
-fp64 path, strict bit-exact with the fp32 order), forward.  Shapes are drawn until the library says form 7 (a bank outside every table).
+fp64 path, strict bit-exact with the fp32 order), forward, and -- every case -- both with a folded per-channel affine map (a non-zero
+accumulator start: the one thing that makes a wrong-zero operand near a row's first columns visible, profiles/r05/stream/ablations.txt
+item 6).  Shapes are drawn until the library says form 7 (a bank outside every table).
 Usage: python scripts/fuzz_stream.py [n_cases] [seed].  Exits non-zero on the first mismatch."""
 import os, sys
 import numpy as np
@@ -45,12 +47,28 @@ while done < n:
     e_fwd = np.abs(fwd - z).max() / max(np.abs(z).max(), 1e-30)
     exact = np.array_equal(strict, ref32)
     tol = max(1e-5, 2.0 * np.abs(ref32 - ref).max() / scale)
-    worst = max(worst, e_inv, e_fwd)
+    # the folds (layers/actnorm.py:39-52): inverse(exp(s) y + t) and (forward(y) - t) exp(-s), each one launch, against the two-step form
+    per = ws.shape[0] // G
+    wts = [torch.from_numpy(ws[i * per:(i + 1) * per]).to(dev) for i in range(G)]
+    ls = torch.from_numpy((0.1 * rng.standard_normal((1, G * Cq, 1, 1))).astype(np.float32)).to(dev)
+    tr = torch.from_numpy((0.3 * rng.standard_normal((1, G * Cq, 1, 1))).astype(np.float32)).to(dev)
+    cache = ops.PackedWeights()
+    ia = cache.inverse_affine(zt, wts, G, orient, ls, tr)
+    fa = cache.forward_affine(xt, wts, G, orient, ls, tr)
+    e_ia = e_fa = 0.0
+    if ia is not None:           # (None: activations not 16-byte aligned -- never here -- or no fused form)
+        want = cache.inverse(torch.exp(ls) * zt + tr, wts, G, orient)
+        e_ia = float((ia - want).abs().max() / want.abs().max().clamp_min(1e-30))
+    if fa is not None:
+        want = (cache.forward(xt, wts, G, orient) - tr) * torch.exp(-ls)
+        e_fa = float((fa - want).abs().max() / want.abs().max().clamp_min(1e-30))
+    folds_ok = ia is not None and fa is not None and e_ia <= tol and e_fa <= 1e-5
+    worst = max(worst, e_inv, e_fwd, e_ia, e_fa)
     key = (v["nw"], v["cqp"] // (16 * v["nw"]))
     forms[key] = forms.get(key, 0) + 1
-    tag = "ok" if (e_inv <= tol and e_fwd <= 1e-5 and exact) else "MISMATCH"
+    tag = "ok" if (e_inv <= tol and e_fwd <= 1e-5 and exact and folds_ok) else "MISMATCH"
     print(f"{done:3d} B{B} G{G} Cq{Cq} {H}x{W} k{KH}x{KW} orient {orient:#x} waves {v['nw']} tiles {key[1]}: inv {e_inv:.1e} fwd {e_fwd:.1e} "
-          f"strict-exact {exact} {tag}", flush=True)
+          f"folded inv {e_ia:.1e} fwd {e_fa:.1e} strict-exact {exact} {tag}", flush=True)
     if tag != "ok":
         sys.exit(1)
     done += 1
