@@ -188,7 +188,36 @@ finc_stream_kernel(const float *__restrict__ in, const float *__restrict__ bank,
             for (int cg = 0; cg < CG; ++cg) zp[k][cg] = v4f{0.f, 0.f, 0.f, 0.f};
         }
     }
+    // one-wave problems: the same 16-byte pieces per LANE.  Lane (row mrow, block mch) keeps the dword loader's channels mch + 4 i
+    // and requests four columns when ITS row's column count passes a multiple of four -- an exec mask, not a branch: 16 rows at 16
+    // phases, four of them per step -- and stores a row's last four columns the same way.  (Lanes = channels, as above, would leave
+    // 12 .. 48 of 64 lanes without one.)  At a full chip the dword accesses were 2.7x .. 5.4x the kernel's floor
+    // (profiles/r05/stream/one_wave_ablations.txt).
+    Pos pl, pq;
+    v4f zq[4 * MT];
+    if constexpr (VEC && NW == 1) {
+        pos_init(pl, -mrow - 1, Wp);
+        pos_init(pq, -mrow - 1, Wp);
+#pragma unroll
+        for (int i = 0; i < 4 * MT; ++i) zq[i] = v4f{0.f, 0.f, 0.f, 0.f};
+    }
     auto fetch_main_vec = [&]() {
+        if constexpr (NW == 1) {
+            pos_step(pl, Wp);
+            if ((pl.col & 3) == 0) {
+                const int h = pl.band * 16 + mrow;
+                const bool ok = pl.col >= 0 && pl.col < W && pl.band < NB && h < H;
+                const int hh = (o & FINC_FLIP_H) ? H - 1 - h : h;
+                const int wc = (o & FINC_FLIP_W) ? W - 4 - pl.col : pl.col;
+#pragma unroll
+                for (int i = 0; i < 4 * MT; ++i) {
+                    const int ch = mch + 4 * i;
+                    zq[i] = (ok && ch < Cq && !(FINC_STREAM_ABLATE & 4)) ? *(const v4f *)(src + (size_t)ch * HW + hh * W + wc)
+                                                                        : v4f{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < RPW; ++k) {
             pos_step(pv[k], Wp);
@@ -207,6 +236,17 @@ finc_stream_kernel(const float *__restrict__ in, const float *__restrict__ bank,
         }
     };
     auto store_main_vec = [&](int slot_off) {
+        if constexpr (NW == 1) {
+            int comp = pl.col & 3;                                             // (before a row's first column the pieces are zeros)
+            if (o & FINC_FLIP_W) comp = 3 - comp;
+#pragma unroll
+            for (int i = 0; i < 4 * MT; ++i) {
+                const v4f pcs = zq[i];
+                const float v = comp == 0 ? pcs.x : comp == 1 ? pcs.y : comp == 2 ? pcs.z : pcs.w;
+                lds[slot_off + (mrow + HALO) * RS + mch + 4 * i] = v;
+            }
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < RPW; ++k) {
             int comp = pv[k].col & 3;                                          // (before a row's first column the pieces are zeros)
@@ -230,6 +270,30 @@ finc_stream_kernel(const float *__restrict__ in, const float *__restrict__ bank,
         for (int k = 0; k < RPW; ++k) pos_init(ps[k], -(RPW * wave + k) - 1, Wp);   // the step BEFORE the current one
     }
     auto store_rows_vec = [&](int cur_slot) {
+        if constexpr (NW == 1) {
+            const int c = pq.col, h = pq.band * 16 + mrow;
+            if ((c & 3) == 3 && c >= 0 && c < W && pq.band < NB && h < H) {
+                const int hh = (o & FINC_FLIP_H) ? H - 1 - h : h;
+                const int wc = (o & FINC_FLIP_W) ? W - 1 - c : c - 3;
+                int sl[4];
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    int t_ = cur_slot - 4 + d;
+                    if constexpr (INV) sl[d] = (t_ < 0 ? t_ + NRING : t_) * SLOTF + (mrow + HALO) * RS;
+                    else sl[d] = ZOFF + (t_ < 0 ? t_ + 5 : t_) * (16 * RS) + mrow * RS;
+                }
+#pragma unroll
+                for (int i = 0; i < 4 * MT; ++i) {
+                    const int ch = mch + 4 * i;
+                    if (ch < Cq && !(FINC_STREAM_ABLATE & 16)) {
+                        const float x0 = lds[sl[0] + ch], x1 = lds[sl[1] + ch], x2 = lds[sl[2] + ch], x3 = lds[sl[3] + ch];
+                        *(v4f *)(dst + (size_t)ch * HW + hh * W + wc) = (o & FINC_FLIP_W) ? v4f{x3, x2, x1, x0} : v4f{x0, x1, x2, x3};
+                    }
+                }
+            }
+            pos_step(pq, Wp);
+            return;
+        }
 #pragma unroll
         for (int k = 0; k < RPW; ++k) {
             const int rho = RPW * wave + k;
@@ -493,11 +557,11 @@ stream_fn pick4(bool inv, bool vec)
 }
 stream_fn pick(int MT, int NW, bool inv, bool vec)
 {
-    if (NW == 1) {                      // (one-wave problems have no 16-byte form: 12 of 64 lanes would hold a channel)
+    if (NW == 1) {
         switch (MT) {
-        case 1: return inv ? finc_stream_kernel<1, 1, true, false> : finc_stream_kernel<1, 1, false, false>;
-        case 2: return inv ? finc_stream_kernel<2, 1, true, false> : finc_stream_kernel<2, 1, false, false>;
-        case 3: return inv ? finc_stream_kernel<3, 1, true, false> : finc_stream_kernel<3, 1, false, false>;
+        case 1: return pick4<1, 1>(inv, vec);
+        case 2: return pick4<2, 1>(inv, vec);
+        case 3: return pick4<3, 1>(inv, vec);
         }
         return nullptr;
     }
@@ -580,7 +644,11 @@ int finc_stream_launch(const float *in, const void *packed, float *out, const Fi
     if (((uintptr_t)packed & 15u) != 0) return FINC_ERR_ALIGNMENT;
     const Geo q = make_geo(s.Cq, s.W, s.KH, s.KW, inverse);
     // the 16-byte operand loader needs whole groups of four columns and aligned rows
-    const bool vec = q.NW == 4 && s.W % 4 == 0 && (((uintptr_t)in | (uintptr_t)out) & 15u) == 0 && q.lds_vec <= 160 * 1024;
+    // One-wave problems take the 16-byte form only from more than two problems per compute unit on: measured at 256 problems (one
+    // per unit, latency-bound) the dword form is 7 .. 16 % faster, at 1,024 the 16-byte form is 13 .. 61 % faster; 512 is the midpoint
+    // of those two measurements, not a measured crossover (profiles/r05/stream/one_wave_ablations.txt).
+    const bool vec = s.W % 4 == 0 && (((uintptr_t)in | (uintptr_t)out) & 15u) == 0 && q.lds_vec <= 160 * 1024 &&
+                     (q.NW == 4 || (long long)s.B * s.G > 512);
     const size_t lds_bytes = vec ? q.lds_vec : q.lds;   // (one-wave problems: 12 of 64 lanes would hold a channel)
     const stream_fn fn = pick(q.MT, q.NW, inverse, vec);
     if (!fn) return FINC_ERR_UNSUPPORTED;

@@ -41,6 +41,8 @@ STREAM_CASES = [
     (1, 4, 129, 1, 50, 3, 3), (2, 4, 8, 20, 24, 4, 4), (1, 4, 4, 33, 18, 7, 7), (2, 2, 64, 16, 16, 5, 5), (3, 4, 40, 9, 40, 2, 2),
     (2, 4, 32, 12, 28, 3, 5), (2, 4, 20, 5, 3, 6, 6), (1, 8, 50, 35, 7, 5, 5), (2, 4, 24, 40, 19, 5, 3), (3, 3, 17, 18, 64, 1, 7),
     (2, 4, 104, 20, 24, 3, 3), (1, 4, 56, 33, 36, 5, 5), (2, 4, 72, 18, 8, 2, 2),     # 16-byte loads and stores in all four orientations
+    # more than 512 one-wave problems: their per-lane 16-byte form (the launch keeps the dword form below that), 1 / 2 / 3 tiles
+    (130, 4, 12, 8, 8, 4, 4), (129, 4, 20, 20, 8, 3, 5), (65, 8, 40, 5, 12, 2, 2),
 ]
 
 
@@ -146,7 +148,7 @@ def test_cinc_unit_at_192_channels(dev):
     assert rel_err(xr.cpu().numpy(), x.cpu().numpy()) <= 1e-4
 
 
-@pytest.mark.parametrize("case", [(2, 4, 40, 18, 24, 2, 2), (2, 1, 160, 20, 16, 3, 3)], ids=case_id)
+@pytest.mark.parametrize("case", [(2, 4, 40, 18, 24, 2, 2), (2, 1, 160, 20, 16, 3, 3), (130, 4, 12, 8, 8, 4, 4), (129, 4, 36, 18, 8, 2, 2)], ids=case_id)
 def test_streaming_bank_carries_the_affine_folds(case, dev):
     """ActNorm folded into the streaming banks: scale into the z-term's columns and Linv * shift as the accumulators' start (inverse,
     layers/actnorm.py:39-52), filter rows scaled and accumulators started from the shift (forward)."""
