@@ -108,7 +108,7 @@ def test_streaming_bank_kernels_spill_outside_their_mfma_loop():
                            "-S", src, "-o", out], stderr=subprocess.DEVNULL, timeout=600)
     lines = open(out).read().split("\n")
     starts = [i for i, l in enumerate(lines) if re.match(r"^_ZN.*finc_stream_kernel.*:", l)]
-    assert len(starts) == 22, len(starts)          # 3 one-wave tile counts x 2 directions + 4 four-wave tile counts x 2 directions x 2 I/O forms
+    assert len(starts) == 28, len(starts)          # (3 one-wave + 4 four-wave tile counts) x 2 directions x 2 I/O forms
     for st in starts:
         end = next(i for i in range(st, len(lines)) if "s_endpgm" in lines[i])
         body = lines[st:end + 1]

@@ -200,14 +200,17 @@ def test_cache_key_survives_a_rebind_through_data(monkeypatch):
     address out again -- the entry holds the old storage alive, so the new tensor cannot land on the cached address."""
     cache, calls = _host_cache(monkeypatch)
     p = torch.nn.Parameter(torch.eye(4).reshape(4, 4, 1, 1).clone())
-    seen = set()
+    prev = None
     for i in range(20):
         bank = cache._get([p], 1, 0)
         assert bank.keep is not None and bank.keep[0].data_ptr() == p.untyped_storage().data_ptr()
         assert calls["canon"] == i + 1, "a rebound weight must rebuild the entry"
         key = (p.data_ptr(), p._version)
-        assert key not in seen
-        seen.add(key)
+        # what the entry guarantees: the new tensor is not at the CACHED address (the entry keeps that storage alive).  An address
+        # from two rebinds ago is free again and may come back -- asserting that no address ever repeats made this test depend on
+        # the allocator's state, i.e. on the tests that ran before it (1 failure in 4 suite runs, none alone)
+        assert key != prev
+        prev = key
         fresh = torch.eye(4).reshape(4, 4, 1, 1) * 1.0    # new storage, same shape, version counter of `p` unchanged
         v = p._version
         p.data = fresh
