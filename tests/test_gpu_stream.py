@@ -209,3 +209,41 @@ def test_fastflowunit_module_on_streaming_banks(case, dev):
         assert rel_err(m.conv.weight.grad.cpu().numpy(), want) <= 2e-5
     x_ref = oracle.inverse_via_f64(z.detach().cpu().numpy(), oracle.canonicalize(torch.cat(unit._weights()).detach().cpu().numpy(), 4, ORIENT_FASTFLOW), 4, ORIENT_FASTFLOW)
     assert rel_err(xr.cpu().numpy(), x_ref) <= TOL
+
+
+@pytest.mark.parametrize("case", [(3, 448, 20, 24, (3, 3)), (140, 32, 8, 8, (4, 4))], ids=lambda c: "B%d_C%d_%dx%d_k%dx%d" % (c[0], c[1], c[2], c[3], c[4][0], c[4][1]))
+def test_streaming_bank_launch_in_a_captured_graph_and_repeated(case, dev):
+    """A sampling loop captures its launches (fincflow_amd/glow.py): the streaming-bank inverse replayed from a HIP graph
+    gives the eager result bit for bit, and 200 eager launches give it every time (the kernel has no state between launches: no
+    progress words, no workspace) -- four-wave problems with 16-byte I/O and more than 512 one-wave problems in their per-lane form."""
+    from fincflow_amd import FastFlowUnit, _lib
+    B, C, H, W, (KH, KW) = case
+    Cq = C // 4
+    assert _lib.inverse_variant(B, 4, Cq, H, W, KH, KW)["sec"] == 7
+    torch.manual_seed(3 * C + H)
+    unit = FastFlowUnit(C, C, (KH, KW)).to(dev)
+    with torch.no_grad():
+        for m in (unit.conv_tl, unit.conv_tr, unit.conv_bl, unit.conv_br):
+            m.conv.weight.mul_(1 - (1 - bank_std(Cq, max(KH, KW)) / 0.05) * m.get_mask().to(dev))
+    y = torch.randn(B, C, H, W, device=dev)                  # the sampling distribution (train/losses.py:42-45)
+    with torch.no_grad():
+        ref = unit.reverse(y)
+        wco = oracle.canonicalize(torch.cat(unit._weights()).detach().cpu().numpy(), 4, ORIENT_FASTFLOW)
+        want = oracle.inverse_via_f64(y[:2].cpu().numpy(), wco, 4, ORIENT_FASTFLOW)
+        assert rel_err(ref[:2].cpu().numpy(), want) <= TOL
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = unit.reverse(y)
+        for _ in range(5):
+            out.zero_()
+            g.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(out, ref)
+        o2 = torch.empty_like(ref)
+        for i in range(200):
+            o2.fill_(float("nan"))
+            unit._cache.inverse(y, unit._weights(), 4, ORIENT_FASTFLOW, out=o2)
+            if i % 20 == 19:
+                assert torch.equal(o2, ref), i
+    assert _lib.hlp_timeouts() == 0 and not _lib.fault_pending()
