@@ -71,10 +71,14 @@ WORKLOADS = {
     # the per-GPU work of an 8-way STRONG split of configs[2] (256 images over 8 GPUs): 128 problems, fewer than compute units --
     # the role-split kernel's regime (profiles, A/B runs; `--scaling strong --gpus 8` runs exactly this on every rank)
     "c3_share8": (32, 96, 64, 64, 3, 0.05),
+    # NOT a BASELINE config: a bank outside every register-resident table (4 groups x 128 channels, 3x3), i.e. the streaming-bank
+    # kernel of finc_stream.hip through the unchanged FastFlowUnit path, so that this kernel has a line in the judged
+    # format too -- roofline and CPU baseline beside it.  std = 0.05 * sqrt(24 / 128): the operator norm of c3's bank.
+    "w512": (256, 512, 32, 32, 3, 0.02165),
 }
-CONFIG_INDEX = {"c3": 2, "c2": 1, "c5": 4, "c3_share8": 2}
+CONFIG_INDEX = {"c3": 2, "c2": 1, "c5": 4, "c3_share8": 2, "w512": None}
 # single-thread CPU sample sizes (images): about 10-20 s of host work per workload
-CPU_SAMPLE_1T = {"c3": 160, "c2": 64, "c5": 3, "c3_share8": 32}
+CPU_SAMPLE_1T = {"c3": 160, "c2": 64, "c5": 3, "c3_share8": 32, "w512": 8}
 
 
 def parse(argv=None):
@@ -709,6 +713,9 @@ def inverse_kernel_name(B, Cq, H, W, K):
     v = _lib.inverse_variant(B, 4, Cq, H, W, K, K)
     if v is None:
         return "inverse_strict_kernel<float> (inverse, scalar)"
+    if v["sec"] == 7:
+        return (f"finc_stream_kernel<MT={v['cqp'] // (16 * v['nw'])},NW={v['nw']}> (inverse, streaming bank: the bank read from the L2 once per "
+                f"step, the pixels of the last steps in an LDS ring; {v['workgroups']} workgroups of {v['nw']} waves, {v['lds_bytes']} B LDS)")
     if v["sec"] == 4:
         per = v["workgroups"] // (B * 4)
         bands = "" if per == 1 else (f"; the bands of a problem dealt out to {per} workgroups on different compute units, the rows "
@@ -880,7 +887,9 @@ def bench_unit(args):
             "vs_baseline": None,
             "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[{CONFIG_INDEX[args.workload]}]: FastFlowUnit {K}x{K}, C={C} "
+            "config": {"workload": (f"BASELINE configs[{CONFIG_INDEX[args.workload]}]" if CONFIG_INDEX[args.workload] is not None
+                                    else "not a BASELINE config (a bank outside the register-resident tables: the streaming-bank kernel)")
+                                   + f": FastFlowUnit {K}x{K}, C={C} "
                                    f"(4 groups x Cq={Cq}), {H}x{W}, batch {B} per GPU"
                                    + (f" (strong split of the workload's {Bw})" if args.scaling == "strong" else "")
                                    + f"; step = unit.reverse(z), "
