@@ -647,8 +647,10 @@ int finc_stream_launch(const float *in, const void *packed, float *out, const Fi
     // One-wave problems take the 16-byte form only from more than two problems per compute unit on: measured at 256 problems (one
     // per unit, latency-bound) the dword form is 7 .. 16 % faster, at 1,024 the 16-byte form is 13 .. 61 % faster; 512 is the midpoint
     // of those two measurements, not a measured crossover (profiles/r05/stream/one_wave_ablations.txt).
+    static const char *force1 = finc_env("FINC_STREAM_ONE_WAVE_VEC");   // experiment switch ("0" / "1"): the one-wave form whatever the count
+    const bool one_wave_vec = force1 ? force1[0] == '1' : (long long)s.B * s.G > 512;
     const bool vec = s.W % 4 == 0 && (((uintptr_t)in | (uintptr_t)out) & 15u) == 0 && q.lds_vec <= 160 * 1024 &&
-                     (q.NW == 4 || (long long)s.B * s.G > 512);
+                     (q.NW == 4 || one_wave_vec);
     const size_t lds_bytes = vec ? q.lds_vec : q.lds;   // (one-wave problems: 12 of 64 lanes would hold a channel)
     const stream_fn fn = pick(q.MT, q.NW, inverse, vec);
     if (!fn) return FINC_ERR_UNSUPPORTED;
