@@ -1729,10 +1729,10 @@ int finc_mfma_variant(int B, int G, int Cq, int H, int W, int KH, int KW, int *i
 {
     if (!finc_mfma_supported(Cq, H, W, KH, KW)) return FINC_ERR_UNSUPPORTED;
     if (stream_bank(Cq, KH, KW)) {             // form 7: the streaming-bank kernel, one workgroup of info[1] waves per problem
-        int cqp = 0, lds = 0, waves = 0;
-        if (int e = finc_stream_info(FincShape{B, G, Cq, H, W, KH, KW, 0}, true, &cqp, &lds, nullptr, &waves)) return e;
+        int cqp = 0, lds = 0, waves = 0, owv = 0;
+        if (int e = finc_stream_info(FincShape{B, G, Cq, H, W, KH, KW, 0}, true, &cqp, &lds, nullptr, &waves, &owv)) return e;
         info[0] = cqp; info[1] = waves; info[2] = 1; info[3] = 7; info[4] = lds; info[5] = B * G;
-        info[6] = -3; info[7] = (int)(sizeof(g_insts) / sizeof(g_insts[0]));
+        info[6] = owv ? -4 : -3;               // (-4: one-wave problems in their per-lane 16-byte form) info[7] = (int)(sizeof(g_insts) / sizeof(g_insts[0]));
         return FINC_OK;
     }
     if (finc_big_bank(Cq, KH, KW) || wide_takeover(FincShape{B, G, Cq, H, W, KH, KW, 0})) {   // form 5: the big-bank kernel, one workgroup of info[1] waves per problem

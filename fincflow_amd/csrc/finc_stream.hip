@@ -627,7 +627,20 @@ int finc_stream_pack(const float *wc, const float *scale, const float *shift, vo
     return FINC_OK;
 }
 
-int finc_stream_info(const FincShape &s, bool inverse, int *cqp, int *lds, int *steps, int *waves)
+// One-wave problems (banks of up to 48 channels): which I/O form the launch takes.  The dword form (lanes = pixels) is latency-bound
+// and wins while the chip has few problems; its time grows with problems x channels, the per-lane 16-byte form's hardly at all.
+// Measured crossovers at 32x32, G = 4 (profiles/r05/stream/one_wave_crossover.txt; 256 .. 1,024 problems in both forms): a 4x4 and a
+// 7x7 bank of 12 channels (one tile) between 640 and 768 problems, a 2x2 bank of 40 channels (three tiles) between 256 and 384 -- the
+// rule below is the product problems x padded channels that separates all 36 timings, never below one problem per compute unit.
+// (Two-tile banks: interpolated, not measured.)
+static bool one_wave_vec_form(long long problems, int Cqp)
+{
+    static const char *force1 = finc_env("FINC_STREAM_ONE_WAVE_VEC");   // experiment switch ("0" / "1"): the one-wave form whatever the count
+    if (force1) return force1[0] == '1';
+    return problems > 256 && problems * Cqp > 10240;
+}
+
+int finc_stream_info(const FincShape &s, bool inverse, int *cqp, int *lds, int *steps, int *waves, int *one_wave_vec)
 {
     if (!finc_stream_supported(s.Cq, s.H, s.W, s.KH, s.KW, inverse)) return FINC_ERR_UNSUPPORTED;
     const Geo q = make_geo(s.Cq, s.W, s.KH, s.KW, inverse);
@@ -635,6 +648,8 @@ int finc_stream_info(const FincShape &s, bool inverse, int *cqp, int *lds, int *
     if (waves) *waves = q.NW;
     if (lds) *lds = (int)q.lds;
     if (steps) *steps = ((s.H + 15) / 16 - 1) * q.Wp + s.W + 15;
+    // (what the launch does with 16-byte aligned tensors)
+    if (one_wave_vec) *one_wave_vec = q.NW == 1 && s.W % 4 == 0 && q.lds_vec <= 160 * 1024 && one_wave_vec_form((long long)s.B * s.G, q.Cqp);
     return FINC_OK;
 }
 
@@ -644,13 +659,8 @@ int finc_stream_launch(const float *in, const void *packed, float *out, const Fi
     if (((uintptr_t)packed & 15u) != 0) return FINC_ERR_ALIGNMENT;
     const Geo q = make_geo(s.Cq, s.W, s.KH, s.KW, inverse);
     // the 16-byte operand loader needs whole groups of four columns and aligned rows
-    // One-wave problems take the 16-byte form only from more than two problems per compute unit on: measured at 256 problems (one
-    // per unit, latency-bound) the dword form is 7 .. 16 % faster, at 1,024 the 16-byte form is 13 .. 61 % faster; 512 is the midpoint
-    // of those two measurements, not a measured crossover (profiles/r05/stream/one_wave_ablations.txt).
-    static const char *force1 = finc_env("FINC_STREAM_ONE_WAVE_VEC");   // experiment switch ("0" / "1"): the one-wave form whatever the count
-    const bool one_wave_vec = force1 ? force1[0] == '1' : (long long)s.B * s.G > 512;
     const bool vec = s.W % 4 == 0 && (((uintptr_t)in | (uintptr_t)out) & 15u) == 0 && q.lds_vec <= 160 * 1024 &&
-                     (q.NW == 4 || one_wave_vec);
+                     (q.NW == 4 || one_wave_vec_form((long long)s.B * s.G, q.Cqp));
     const size_t lds_bytes = vec ? q.lds_vec : q.lds;   // (one-wave problems: 12 of 64 lanes would hold a channel)
     const stream_fn fn = pick(q.MT, q.NW, inverse, vec);
     if (!fn) return FINC_ERR_UNSUPPORTED;

@@ -54,6 +54,12 @@ def test_algo_selection_is_host_side_and_consistent():
     assert L.finc_inverse_algo_for(64, 32, 32, 7, 7) == MFMA and L.finc_forward_algo_for(64, 32, 32, 7, 7) == MFMA
     assert L.finc_inverse_algo_for(192, 64, 64, 3, 3) == MFMA and L.finc_forward_algo_for(192, 64, 64, 3, 3) == MFMA
     assert _lib.inverse_variant(256, 1, 192, 64, 64, 3, 3)["sec"] == 7 and _lib.inverse_variant(8, 4, 12, 32, 32, 4, 4)["nw"] == 1
+    # one-wave streaming-bank problems: the dword form (row -3) while problems x padded channels <= 10,240 or the chip has at most one
+    # problem per compute unit, the per-lane 16-byte form (row -4) beyond -- the crossovers of profiles/r05/stream/one_wave_crossover.txt;
+    # a width that is no multiple of four and the four-wave problems never report it
+    for (B, Cq, W, row) in ((160, 12, 32, -3), (161, 12, 32, -4), (64, 40, 32, -3), (65, 40, 32, -4), (80, 20, 32, -3), (81, 20, 32, -4),
+                            (256, 12, 30, -3), (256, 100, 32, -3)):
+        assert _lib.inverse_variant(B, 4, Cq, 32, W, 4 if Cq < 100 else 3, 4 if Cq < 100 else 3)["row"] == row, (B, Cq, W, row)
     # beyond that kernel's limits (9x9 filter; a 7x7 bank of 96 channels whose step ring exceeds the LDS) -> reference-order kernel
     assert L.finc_inverse_algo_for(16, 32, 32, 9, 9) == STRICT and L.finc_forward_algo_for(16, 32, 32, 9, 9) == STRICT
     assert L.finc_inverse_algo_for(96, 32, 32, 7, 7) == STRICT

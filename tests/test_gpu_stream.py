@@ -41,9 +41,11 @@ STREAM_CASES = [
     (1, 4, 129, 1, 50, 3, 3), (2, 4, 8, 20, 24, 4, 4), (1, 4, 4, 33, 18, 7, 7), (2, 2, 64, 16, 16, 5, 5), (3, 4, 40, 9, 40, 2, 2),
     (2, 4, 32, 12, 28, 3, 5), (2, 4, 20, 5, 3, 6, 6), (1, 8, 50, 35, 7, 5, 5), (2, 4, 24, 40, 19, 5, 3), (3, 3, 17, 18, 64, 1, 7),
     (2, 4, 104, 20, 24, 3, 3), (1, 4, 56, 33, 36, 5, 5), (2, 4, 72, 18, 8, 2, 2),     # 16-byte loads and stores in all four orientations
-    # more than 512 one-wave problems: their per-lane 16-byte form (the launch keeps the dword form below that), 1 / 2 / 3 tiles
-    (130, 4, 12, 8, 8, 4, 4), (129, 4, 20, 20, 8, 3, 5), (65, 8, 40, 5, 12, 2, 2),
+    # one-wave problems in their per-lane 16-byte form (problems x padded channels > 10,240 and more than one problem per compute
+    # unit; the launch keeps the dword form below that), 1 / 2 / 3 tiles -- and the dword form just below the rule's edge
+    (161, 4, 12, 8, 8, 4, 4), (129, 4, 20, 20, 8, 3, 5), (65, 8, 40, 5, 12, 2, 2), (160, 4, 12, 8, 8, 4, 4), (64, 4, 40, 8, 8, 2, 2),
 ]
+ONE_WAVE_VEC = {(161, 4, 12, 8, 8, 4, 4), (129, 4, 20, 20, 8, 3, 5), (65, 8, 40, 5, 12, 2, 2)}
 
 
 def case_id(c):
@@ -59,7 +61,8 @@ def test_streaming_bank_inverse(case, dev):
     orient = orient_of(G)
     v = _lib.inverse_variant(B, G, Cq, H, W, KH, KW)
     nw = 1 if Cq <= 48 else 4              # one-wave problems up to 48 channels, a workgroup of four waves beyond
-    assert v is not None and v["sec"] == 7 and v["nw"] == nw and v["workgroups"] == B * G and v["row"] == -3, v
+    assert v is not None and v["sec"] == 7 and v["nw"] == nw and v["workgroups"] == B * G, v
+    assert v["row"] == (-4 if case in ONE_WAVE_VEC else -3), v          # -4: one-wave problems in their per-lane 16-byte form
     assert v["cqp"] == (Cq + 16 * nw - 1) // (16 * nw) * (16 * nw)
     e_max, _ = run_inverse_case(dev, B, G, orient, Cq, H, W, KH, KW, seed=13 * Cq + H + 3 * W + KH, tag="stream")
     assert e_max <= TOL
@@ -211,15 +214,16 @@ def test_fastflowunit_module_on_streaming_banks(case, dev):
     assert rel_err(xr.cpu().numpy(), x_ref) <= TOL
 
 
-@pytest.mark.parametrize("case", [(3, 448, 20, 24, (3, 3)), (140, 32, 8, 8, (4, 4))], ids=lambda c: "B%d_C%d_%dx%d_k%dx%d" % (c[0], c[1], c[2], c[3], c[4][0], c[4][1]))
+@pytest.mark.parametrize("case", [(3, 448, 20, 24, (3, 3)), (164, 32, 8, 8, (4, 4))], ids=lambda c: "B%d_C%d_%dx%d_k%dx%d" % (c[0], c[1], c[2], c[3], c[4][0], c[4][1]))
 def test_streaming_bank_launch_in_a_captured_graph_and_repeated(case, dev):
     """A sampling loop captures its launches (fincflow_amd/glow.py): the streaming-bank inverse replayed from a HIP graph
     gives the eager result bit for bit, and 200 eager launches give it every time (the kernel has no state between launches: no
-    progress words, no workspace) -- four-wave problems with 16-byte I/O and more than 512 one-wave problems in their per-lane form."""
+    progress words, no workspace) -- four-wave problems with 16-byte I/O and 656 one-wave problems in their per-lane form."""
     from fincflow_amd import FastFlowUnit, _lib
     B, C, H, W, (KH, KW) = case
     Cq = C // 4
-    assert _lib.inverse_variant(B, 4, Cq, H, W, KH, KW)["sec"] == 7
+    v = _lib.inverse_variant(B, 4, Cq, H, W, KH, KW)
+    assert v["sec"] == 7 and v["row"] == (-4 if Cq <= 48 else -3), v
     torch.manual_seed(3 * C + H)
     unit = FastFlowUnit(C, C, (KH, KW)).to(dev)
     with torch.no_grad():
