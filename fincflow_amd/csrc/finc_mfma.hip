@@ -1558,6 +1558,25 @@ int padded_cq(int Cq, int KH, int KW)
     return best;
 }
 
+// A bank without a two-wave form of its own borrows the next bank's: the 28-channel 3x3 bank (7 k-steps do not split over two
+// waves) the packed two-wave kernel of the 32-channel one, whose K-split takes any number of padded channels.  The borrowed bank is
+// packed BEHIND the bank's own (finc_mfma_pack), so which kernel runs stays a per-launch choice.
+int borrowed_cqp(int cqp, int KH, int KW) { return cqp == 28 && KH == 3 && KW == 3 ? 32 : 0; }
+
+// One-wave problems run n1 to a compute unit (four SIMDs; fewer once their rings outgrow a quarter of the LDS), borrowed two-wave
+// problems two (a packed pair = four waves), and the chip works through a problem set in rounds of that many per unit.  Measured at
+// C = 112 against C = 128 (profiles/r05/notes/c28_borrowed_bank.txt): a round of one-wave 28-channel problems takes 540 us at 64x64
+// (170 at 32x32), a round of two-wave problems 437 (138) -- 0.81 of it, whatever the map.  The borrowed form is taken when its
+// rounds are the shorter sum: up to 512 problems (-19 %), and at 64x64 again from 769 to 1,024 (1,080 -> 876 us).
+static bool borrowed_form_wins(long long problems, size_t lds_one_wave)
+{
+    const long long CUS = 256;                                  // MI355X
+    long long n1 = (long long)((160 * 1024 - 64) / lds_one_wave);
+    n1 = n1 > 4 ? 4 : n1 < 1 ? 1 : n1;
+    const long long r1 = (problems + n1 * CUS - 1) / (n1 * CUS), r2 = (problems + 2 * CUS - 1) / (2 * CUS);
+    return r2 * 13 < r1 * 16;                                   // (437 / 540 = 0.81 = 13 / 16)
+}
+
 const Inst *find_inst(int Cq, int KH, int KW, long long problems = -1, int W = 0)
 {
     const int cqp = padded_cq(Cq, KH, KW);
@@ -1569,6 +1588,13 @@ const Inst *find_inst(int Cq, int KH, int KW, long long problems = -1, int W = 0
             if (problems % i.npw != 0) continue;
             const int P = W < 16 ? W : 16;
             if (lds_bytes(i, W, P) > 160 * 1024) continue;
+        }
+        if (problems >= 0 && W > 0 && i.nw == 1 && i.npw == 1 && problems % 2 == 0 && borrowed_cqp(cqp, KH, KW)) {
+            const int P = W < 16 ? W : 16;
+            if (borrowed_form_wins(problems, lds_bytes(i, W, P)))
+                for (const Inst &k : g_insts)
+                    if (k.cqp == borrowed_cqp(cqp, KH, KW) && k.kh == KH && k.kw == KW && k.nw == 2 && k.npw == 2 && lds_bytes(k, W, P) <= 160 * 1024)
+                        return &k;
         }
         // Wide maps: the band hand-over FIFO grows with W, and once four one-wave problems no longer fit a CU's LDS (W >= 80
         // at Cq = 24) the helper-wave form is out and only three SIMDs of a CU have a problem.  The packed two-wave form
@@ -1646,11 +1672,31 @@ int finc_mfma_packed_cqp(int Cq, int KH, int KW)
     return a ? a->cqp : 0;
 }
 
-// bytes of this table's own bank (behind it: the bank of finc_big.hip for the banks it takes over on wide maps)
-static size_t wave_bank_bytes(int G, int Cq, int KH, int KW)
+// bytes of this table's own bank
+static size_t own_bank_bytes(int G, int Cq, int KH, int KW)
 {
     const Inst *a = find_inst(Cq, KH, KW);
     return a ? (size_t)(a->nfrag + 8 * a->mt) * 64 * sizeof(float) * (size_t)G : 0;
+}
+// the borrowed bank's row of the table (nullptr: the bank borrows none) and its bytes
+static const Inst *borrowed_inst(int Cq, int KH, int KW)
+{
+    const int b = borrowed_cqp(padded_cq(Cq, KH, KW), KH, KW);
+    if (b)
+        for (const Inst &k : g_insts)
+            if (k.cqp == b && k.kh == KH && k.kw == KW && k.nw == 2 && k.npw == 2) return &k;
+    return nullptr;
+}
+static size_t borrowed_bank_bytes(int G, int Cq, int KH, int KW)
+{
+    const Inst *k = borrowed_inst(Cq, KH, KW);
+    return k ? (size_t)(k->nfrag + 8 * k->mt) * 64 * sizeof(float) * (size_t)G : 0;
+}
+// bytes of this table's banks: its own, then the borrowed one (behind them: the bank of finc_big.hip for the banks it takes over on
+// wide maps)
+static size_t wave_bank_bytes(int G, int Cq, int KH, int KW)
+{
+    return own_bank_bytes(G, Cq, KH, KW) + borrowed_bank_bytes(G, Cq, KH, KW);
 }
 // (which problem sets of such a bank go to finc_big.hip: those no variant of this table can hold)
 static bool wide_takeover(const FincShape &s)
@@ -1714,6 +1760,12 @@ int finc_mfma_pack(const float *wc, const float *scale, const float *shift, void
     hipLaunchKernelGGL(pack_kernel, dim3(G), dim3(256), sizeof(double) * Cq * Cq, st, wc, scale, shift, (float *)packed, Cq,
                        KH, KW, i->mt, i->nkz, i->nkd, i->mtb, i->nfrag);
     FINC_CHECK_LAUNCH();
+    if (const Inst *k = borrowed_inst(Cq, KH, KW)) {      // the borrowed two-wave bank, same fold, behind the bank's own
+        float *behind = (float *)((char *)packed + own_bank_bytes(G, Cq, KH, KW));
+        hipLaunchKernelGGL(pack_kernel, dim3(G), dim3(256), sizeof(double) * Cq * Cq, st, wc, scale, shift, behind, Cq, KH, KW, k->mt,
+                           k->nkz, k->nkd, k->mtb, k->nfrag);
+        FINC_CHECK_LAUNCH();
+    }
     // (a folded shift is the one thing finc_big.hip does not carry: such a bank has no wide-map form -- the launch refuses
     // it, finc_inverse_affine_supported() says so beforehand, and the region holds NaNs, never a plausible bank)
     if (finc_big_wide_bank(Cq, KH, KW)) {
@@ -1809,6 +1861,8 @@ int finc_mfma_launch(const float *in, const void *packed, float *out, const Finc
     const size_t lds_hlp = 4 * lds + 64;
     const bool hlp = s64 && i->fn_hlp && ((long long)s.B * s.G) % 4 == 0 && lds_hlp <= 160 * 1024 && !finc_no_hlp();
     const wave_fn fn = zpre ? i->fn_zpre : hlp ? i->fn_hlp : s64 ? i->fn_s64 : (s.W % 8 == 0) ? i->fn_sec : i->fn;
+    if (i == borrowed_inst(s.Cq, s.KH, s.KW))              // the borrowed two-wave form reads the bank packed behind the bank's own
+        packed = (const char *)packed + own_bank_bytes(s.G, s.Cq, s.KH, s.KW);
     if (int e = finc_ensure_dynamic_lds((const void *)fn, hlp ? lds_hlp : lds)) return e;
     if (hlp) {
         if (int e = finc_fault_gate(true, st)) return e;   // (arms the device's fault word if no packing call has: never inside a capture)

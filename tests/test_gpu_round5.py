@@ -305,3 +305,60 @@ def test_fp64_matrix_core_inverse_on_the_reference_fixtures(name, dev):
     want = g["x_rev_cython"]
     assert rel_err(x32, want) <= 1e-7, rel_err(x32, want)
     assert np.mean(x32 == want) >= 0.999             # (the same fp32 value wherever the fp64 results do not straddle a rounding boundary)
+
+
+# (B, G, Cq, H, W): the 28-channel 3x3 bank -- and the counts 25 .. 27 that pad to it -- on the 32-channel bank's packed two-wave kernel
+# (finc_mfma.hip, borrowed_cqp): even problem counts up to 512 on narrow and wide maps (16-byte, 32-byte and sector I/O), G = 1, 2, 4, 8
+BORROWED_CASES = [(65, 4, 28, 20, 24), (65, 4, 25, 9, 20), (130, 2, 26, 18, 32), (258, 1, 27, 5, 16), (33, 8, 28, 33, 40), (128, 4, 28, 7, 64)]
+
+
+@pytest.mark.parametrize("case", BORROWED_CASES, ids=lambda c: "B%d_G%d_Cq%d_%dx%d" % c)
+def test_the_28_channel_bank_on_the_borrowed_two_wave_kernel(case, dev):
+    """The library says it runs the 32-channel bank's packed two-wave kernel (its own bank holds 7 k-steps: no two-wave form), the
+    result is the oracle's (<= 1e-5, strict kernel bit-exact beside it), and the next odd count runs the bank's own one-wave kernel
+    on the same packed buffer -- both banks live in it."""
+    from fincflow_amd import _lib
+    B, G, Cq, H, W = case
+    orient = ORIENT_FASTFLOW if G == 4 else (0x1B & ((1 << (2 * G)) - 1)) if G < 4 else 0x1BE4
+    v = _lib.inverse_variant(B, G, Cq, H, W, 3, 3)
+    assert v["cqp"] == 32 and v["nw"] == 2 and v["npw"] == 2 and v["workgroups"] == B * G // 2, v
+    run_inverse_case(dev, B, G, orient, Cq, H, W, 3, 3, seed=7 * Cq + H + W, tag="borrowed")
+    if G == 1:
+        own = _lib.inverse_variant(B + 1, G, Cq, H, W, 3, 3)
+        assert own["cqp"] == 28 and own["nw"] == 1, own
+        run_inverse_case(dev, B + 1, G, orient, Cq, H, W, 3, 3, seed=5, tag="borrowed_own")
+
+
+def test_borrowed_bank_through_the_module_with_the_affine_fold(dev):
+    """FastFlowUnit at C = 112 (28 channels per group), 64x64: B = 128 runs the borrowed two-wave kernel, B = 129 the bank's own -- one
+    cached packed buffer serves both; reverse(forward(x)) = x, the first images against the oracle, and ActNorm folded into the
+    borrowed bank (scale and shift) gives what the two layers give."""
+    from fincflow_amd import FastFlowUnit, _lib, glow
+    C, H, W = 112, 64, 64
+    torch.manual_seed(5)
+    unit = FastFlowUnit(C, C, 3).to(dev)
+    with torch.no_grad():
+        for m in (unit.conv_tl, unit.conv_tr, unit.conv_bl, unit.conv_br):
+            m.conv.weight.mul_(1 - (1 - bank_std(28, 3) / 0.05) * m.get_mask().to(dev))
+    an = glow.ActNorm(C).to(dev)
+    with torch.no_grad():
+        an.log_scale.copy_(0.3 * torch.randn(C, device=dev))
+        an.translation.copy_(torch.randn(C, device=dev))
+        an.initialized.fill_(1)
+    assert _lib.inverse_variant(128, 4, 28, H, W, 3, 3)["cqp"] == 32 and _lib.inverse_variant(129, 4, 28, H, W, 3, 3)["cqp"] == 28
+    assert _lib.inverse_variant(192, 4, 28, H, W, 3, 3)["cqp"] == 28 and _lib.inverse_variant(256, 4, 28, H, W, 3, 3)["cqp"] == 32
+    x = torch.randn(129, C, H, W, device=dev)
+    wco = oracle.canonicalize(torch.cat(unit._weights()).detach().cpu().numpy(), 4, ORIENT_FASTFLOW)
+    with torch.no_grad():
+        z = unit(x)[0]
+        a = unit.reverse(z[:128])                      # borrowed
+        b = unit.reverse(z)                            # own
+        assert rel_err(a.cpu().numpy(), x[:128].cpu().numpy()) <= 1e-4 and rel_err(b.cpu().numpy(), x.cpu().numpy()) <= 1e-4
+        want = oracle.inverse_via_f64(z[:2].cpu().numpy(), wco, 4, ORIENT_FASTFLOW)
+        assert rel_err(a[:2].cpu().numpy(), want) <= TOL and rel_err(b[:2].cpu().numpy(), want) <= TOL
+        y = torch.randn(128, C, H, W, device=dev)
+        two = unit.reverse(an.reverse(y))
+        fused = unit.reverse_affine(y, an.log_scale, an.translation)
+        assert fused is not None and rel_err(fused.cpu().numpy(), two.cpu().numpy()) <= TOL
+        zz = (y[:2] * torch.exp(an.log_scale).view(1, -1, 1, 1) + an.translation.view(1, -1, 1, 1)).cpu().numpy()
+        assert rel_err(fused[:2].cpu().numpy(), oracle.inverse_via_f64(zz, wco, 4, ORIENT_FASTFLOW)) <= TOL
