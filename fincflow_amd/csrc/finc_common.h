@@ -48,6 +48,27 @@ int finc_mfma_arm_fault_word(unsigned *device_ptr_to_host_word);
 const char *finc_env(const char *name);
 int finc_wino_form_override();   // 0 = the library's choice (finc_debug_set_forward_form)
 
+// Row chunks of the forward kernels that run ONE wave per SIMD (F(4,3), its M-split, F(2,5)): a launch of `units` strips (waves or
+// workgroups), of which the chip holds `slots` at a time, is cut into row chunks so that every slot has work; a chunk walks its rows
+// plus `extra` rows of operands above them.  All units take the same time, so the chip works through units x chunks in ROUNDS of
+// `slots`, and the cost of a split is rounds x (rows per chunk + extra).  The count that minimises it is returned (the smallest one
+// among equals; chunks of at least `min_rows` rows).  Measured on the F(4,3) forward of c3, 64x64 (profiles/r05/notes/row_chunks.txt):
+// B = 96 (384 strips): 3 chunks = 1,152 waves = two rounds of 24 rows 133 us, 5 chunks = two rounds of 15 rows 97 us; B = 160: 2 chunks
+// 203 us, 3 chunks 155; B = 384: 1 chunk (two rounds of 66 rows) 395 us, 2 chunks (three rounds of 34) 355.
+inline int finc_row_chunks(long long units, long long slots, int H, int min_rows, int extra)
+{
+    const int maxc = H / min_rows > 0 ? H / min_rows : 1;
+    long long best = -1;
+    int nrc = 1;
+    for (int c = 1; c <= maxc; ++c) {
+        const int rc = (H + c - 1) / c;
+        if ((H + rc - 1) / rc != c) continue;                     // (the same split as a smaller count)
+        const long long rounds = (units * c + slots - 1) / slots, cost = rounds * (rc + extra);
+        if (best < 0 || cost < best) { best = cost; nrc = c; }
+    }
+    return nrc;
+}
+
 // the measurement knobs each kernel translation unit was built with (finc_experiment.h); finc_build_flags() ORs them
 unsigned finc_build_flags_mfma();
 unsigned finc_build_flags_split();

@@ -739,8 +739,7 @@ int finc_wino_launch(const float *in, const void *packed, float *out, const Finc
     int nrc;
     if (f4) {
         const long long fill4 = i->cqp <= 8 ? 2048 : 1024;                 // (the small banks: two waves per SIMD)
-        nrc = waves >= fill4 ? 1 : (int)((fill4 + waves - 1) / waves);
-        if (nrc > s.H / 8) nrc = s.H / 8 > 0 ? s.H / 8 : 1;
+        nrc = finc_row_chunks(waves, fill4, s.H, 8, 2);                    // (rounds x rows per chunk: finc_common.h)
     } else {
         nrc = waves >= 2048 ? 1 : waves >= 1024 ? 2 : (int)((1024 + waves - 1) / waves);
     }

@@ -269,8 +269,7 @@ int finc_wino4m_launch(const float *in, const void *packed, float *out, const Fi
     const long long wgs = (long long)s.B * s.G * NS;
     const long long fill = 256 * (4 / i->nw);                              // workgroups of one wave per SIMD that a chip holds at once (every
                                                                            // chunk recomputes two rows of operands)
-    int nrc = wgs >= fill ? 1 : (int)((fill + wgs - 1) / wgs);
-    if (nrc > s.H / 8) nrc = s.H / 8 > 0 ? s.H / 8 : 1;
+    int nrc = finc_row_chunks(wgs, fill, s.H, 8, 2);                       // (rounds x rows per chunk: finc_common.h)
     const int RC = (s.H + nrc - 1) / nrc;
     nrc = (s.H + RC - 1) / RC;
     if (int e = finc_ensure_dynamic_lds((const void *)i->fn, i->lds)) return e;

@@ -436,8 +436,7 @@ int finc_wino5_launch(const float *in, const void *packed, float *out, const Fin
     // one workgroup per CU at a time (its waves hold 1/NW of the bank each: one wave per SIMD); row chunks when the strips
     // alone do not fill the chip (every chunk recomputes 4 rows of operands)
     const long long wgs = (long long)s.B * s.G * NS;
-    int nrc = wgs >= 256 ? 1 : (int)((256 + wgs - 1) / wgs);
-    if (nrc > s.H / 8) nrc = s.H / 8 > 0 ? s.H / 8 : 1;
+    int nrc = finc_row_chunks(wgs, 256, s.H, 8, 4);                        // (rounds x rows per chunk: finc_common.h)
     const int RC = (s.H + nrc - 1) / nrc;
     nrc = (s.H + RC - 1) / RC;
     if (int e = finc_ensure_dynamic_lds((const void *)i->fn, i->lds)) return e;

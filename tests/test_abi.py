@@ -282,3 +282,20 @@ def test_grad_weight_form_is_host_side_and_follows_the_documented_rules():
     }
     got = {k: _lib.backward_variant(*k)["gradw"] for k in want}
     assert got == want, {k: (got[k], want[k]) for k in want if got[k] != want[k]}
+
+
+def test_row_chunks_minimise_rounds_times_rows():
+    """finc_common.h finc_row_chunks (the launch rule of the one-wave-per-SIMD forward kernels): the measured cases of
+    profiles/r05/notes/row_chunks.txt -- c3's F(4,3) forward at B = 96 / 160 / 384 takes 5 / 3 / 2 chunks (the old fill-the-chip rule: 3 / 2 / 1,
+    up to 27 % slower) -- and the shapes every bench line launches keep theirs."""
+    rc = _lib.lib().finc_debug_row_chunks
+    assert rc(384, 1024, 64, 8, 2) == 5 and rc(640, 1024, 64, 8, 2) == 3 and rc(1536, 1024, 64, 8, 2) == 2
+    assert rc(1024, 1024, 64, 8, 2) == 1 and rc(512, 1024, 64, 8, 2) == 2 and rc(256, 1024, 64, 8, 2) == 4 and rc(128, 1024, 64, 8, 2) == 8
+    assert rc(2048, 1024, 64, 8, 2) == 1 and rc(4096, 1024, 64, 8, 2) == 1
+    assert rc(1, 1024, 64, 8, 2) == 8 and rc(1, 1024, 7, 8, 2) == 1 and rc(1, 1024, 16, 8, 2) == 2      # never chunks below min_rows
+    assert rc(192, 256, 128, 8, 4) == 4 and rc(48, 256, 128, 8, 4) == 5 and rc(1024, 256, 128, 8, 4) == 1  # F(2,5): c5 at B = 12 (192 strips: three rounds of 32+4 rows), B = 3, and its full batch
+    for units in (1, 7, 100, 383, 1000, 1025, 5000):
+        for H in (1, 8, 9, 33, 64, 100, 128):
+            c = rc(units, 1024, H, 8, 2)
+            assert 1 <= c <= max(1, H // 8) and -(-H // -(-H // c)) == c                                  # a count its own row split reproduces
+    assert rc(0, 1024, 64, 8, 2) == 0 and rc(1, 0, 64, 8, 2) == 0
