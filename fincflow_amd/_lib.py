@@ -97,7 +97,7 @@ def lib():
     L.finc_debug_inverse_table_row.argtypes = [i, ctypes.POINTER(ctypes.c_int)]
     L.finc_debug_hlp_timeouts.argtypes = [ctypes.POINTER(ctypes.c_uint)]
     L.finc_debug_backward_variant.argtypes = [i, i, i, i, i, i, i, ctypes.POINTER(ctypes.c_int)]
-    L.finc_debug_row_chunks.argtypes = [ctypes.c_longlong, ctypes.c_longlong, i, i, i]
+    L.finc_debug_row_chunks.argtypes = [ctypes.c_longlong, ctypes.c_longlong, i, i, i, i]
     L.finc_debug_set_forward_form.argtypes = [i]
     L.finc_mix_supported_f32.argtypes = [i]
     L.finc_mix_f32.argtypes = [vp, vp, vp, vp, i, i, i, vp]

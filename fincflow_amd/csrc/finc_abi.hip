@@ -572,10 +572,10 @@ int finc_debug_backward_variant(int B, int G, int Cq, int H, int W, int KH, int 
 
 int finc_debug_set_forward_form(int form) { return finc_wino_set_form(form); }
 
-int finc_debug_row_chunks(long long units, long long slots, int H, int min_rows, int extra)
+int finc_debug_row_chunks(long long units, long long slots, int H, int min_rows, int extra, int second_tenant)
 {
-    if (units < 1 || slots < 1 || H < 1 || min_rows < 1 || extra < 0) return 0;
-    return finc_row_chunks(units, slots, H, min_rows, extra);
+    if (units < 1 || slots < 1 || H < 1 || min_rows < 1 || extra < 0 || second_tenant < 1 || second_tenant > 16) return 0;
+    return finc_row_chunks(units, slots, H, min_rows, extra, second_tenant);
 }
 
 int finc_debug_hlp_timeouts(unsigned *h_count)

@@ -55,7 +55,11 @@ int finc_wino_form_override();   // 0 = the library's choice (finc_debug_set_for
 // among equals; chunks of at least `min_rows` rows).  Measured on the F(4,3) forward of c3, 64x64 (profiles/r05/notes/row_chunks.txt):
 // B = 96 (384 strips): 3 chunks = 1,152 waves = two rounds of 24 rows 133 us, 5 chunks = two rounds of 15 rows 97 us; B = 160: 2 chunks
 // 203 us, 3 chunks 155; B = 384: 1 chunk (two rounds of 66 rows) 395 us, 2 chunks (three rounds of 34) 355.
-inline int finc_row_chunks(long long units, long long slots, int H, int min_rows, int extra)
+// `second_tenant`: the kernels that run TWO waves per SIMD (strip kernel, F(2,3)) pass 14 -- once a launch has more waves than SIMDs the
+// tenants fill each other's issue gaps, a row costs 14/16 of what it costs a lone wave (F(2,3), c3 shape, B = 24: 5 chunks = 960 lone
+// waves 34.5 us, 10 chunks = 1,920 waves in pairs 34.4; 4 against 8 chunks: 39.8 both) -- and count their rounds in SIMDs all the same:
+// two tenants share one SIMD's MFMA pipe.  16 = no such effect (one wave per SIMD is all the registers allow).
+inline int finc_row_chunks(long long units, long long slots, int H, int min_rows, int extra, int second_tenant = 16)
 {
     const int maxc = H / min_rows > 0 ? H / min_rows : 1;
     long long best = -1;
@@ -63,7 +67,8 @@ inline int finc_row_chunks(long long units, long long slots, int H, int min_rows
     for (int c = 1; c <= maxc; ++c) {
         const int rc = (H + c - 1) / c;
         if ((H + rc - 1) / rc != c) continue;                     // (the same split as a smaller count)
-        const long long rounds = (units * c + slots - 1) / slots, cost = rounds * (rc + extra);
+        const long long rounds = (units * c + slots - 1) / slots;
+        const long long cost = rounds * (rc + extra) * (units * c > slots ? second_tenant : 16);
         if (best < 0 || cost < best) { best = cost; nrc = c; }
     }
     return nrc;

@@ -679,10 +679,10 @@ int finc_conv_launch(const float *in, const void *packed, float *out, const Finc
     if (finc_wino4m_packed_bytes(s.G, s.Cq, s.KH, s.KW) && finc_wino4m_takes(in, out, s))
         return finc_wino4m_launch(in, (const char *)packed + conv_bank_bytes(i, s.G), out, s, st);
     const int NS = (s.W + 15) / 16;
-    // about one wave per SIMD (measured: more chunks than that cost more in per-wave bank loads than they gain; 2 chunks
-    // still pay up to 2 waves per SIMD), in chunks of at least 4 rows (every chunk recomputes KH-1 rows of operands)
+    // row chunks of at least 4 rows: the count that minimises rounds x (rows per chunk + KH: every chunk recomputes KH-1 rows of operands
+    // and loads the bank once more), two waves per SIMD (finc_common.h finc_row_chunks; profiles/r05/notes/row_chunks.txt)
     const long long waves = (long long)s.B * s.G * NS * i->nw;
-    int nrc = waves >= 2048 ? 1 : waves >= 1024 ? 2 : (int)((1024 + waves - 1) / waves);
+    int nrc = finc_row_chunks(waves, 1024, s.H, 4, s.KH, 14);
     static const int force_chunks = finc_env("FINC_CONV_CHUNKS") ? atoi(finc_env("FINC_CONV_CHUNKS")) : 0;   // experiment switch
     if (force_chunks > 0) nrc = force_chunks;
     if (nrc > s.H / 4) nrc = s.H / 4 > 0 ? s.H / 4 : 1;

@@ -741,7 +741,7 @@ int finc_wino_launch(const float *in, const void *packed, float *out, const Finc
         const long long fill4 = i->cqp <= 8 ? 2048 : 1024;                 // (the small banks: two waves per SIMD)
         nrc = finc_row_chunks(waves, fill4, s.H, 8, 2);                    // (rounds x rows per chunk: finc_common.h)
     } else {
-        nrc = waves >= 2048 ? 1 : waves >= 1024 ? 2 : (int)((1024 + waves - 1) / waves);
+        nrc = finc_row_chunks(waves, 1024, s.H, 4, 2, 14);                 // (two waves per SIMD: finc_common.h)
     }
     if (force_chunks > 0) nrc = force_chunks;
     if (nrc > s.H / 4) nrc = s.H / 4 > 0 ? s.H / 4 : 1;

@@ -272,9 +272,11 @@ int finc_debug_backward_variant(int B, int G, int Cq, int H, int W, int KH, int 
 int finc_debug_set_forward_form(int form);
 /* The row-chunk count the one-wave-per-SIMD forward kernels (F(4,3), its M-split, F(2,5)) launch with: `units` strips of which the chip
  * holds `slots` at a time, maps of H rows, chunks of at least `min_rows` rows that each recompute `extra` rows of operands -- the count
- * that minimises rounds x (rows per chunk + extra).  Host-only; 0 for arguments out of range.  (No reference counterpart: the
- * reference's forward is one cuDNN call, layers/conv.py:98-107.) */
-int finc_debug_row_chunks(long long units, long long slots, int H, int min_rows, int extra);
+ * that minimises rounds x (rows per chunk + extra).  `second_tenant` (1 .. 16): sixteenths a row costs once the launch has more units
+ * than slots -- 14 for the kernels that run two waves per SIMD (strip kernel, F(2,3): slots = SIMDs, min_rows 4), 16 otherwise.
+ * Host-only; 0 for arguments out of range.  (No reference counterpart: the reference's forward is one cuDNN call,
+ * layers/conv.py:98-107.) */
+int finc_debug_row_chunks(long long units, long long slots, int H, int min_rows, int extra, int second_tenant);
 int finc_debug_inverse_table_row(int row, int *info);
 int finc_debug_attr_table_insert(int device, size_t kernel_token);
 /* SYNCHRONOUS.  The helper-wave form of the inverse (form 3 of finc_inverse_kernel_variant) pairs each compute wave with a

@@ -288,7 +288,8 @@ def test_row_chunks_minimise_rounds_times_rows():
     """finc_common.h finc_row_chunks (the launch rule of the one-wave-per-SIMD forward kernels): the measured cases of
     profiles/r05/notes/row_chunks.txt -- c3's F(4,3) forward at B = 96 / 160 / 384 takes 5 / 3 / 2 chunks (the old fill-the-chip rule: 3 / 2 / 1,
     up to 27 % slower) -- and the shapes every bench line launches keep theirs."""
-    rc = _lib.lib().finc_debug_row_chunks
+    f = _lib.lib().finc_debug_row_chunks
+    rc = lambda units, slots, H, min_rows, extra: f(units, slots, H, min_rows, extra, 16)
     assert rc(384, 1024, 64, 8, 2) == 5 and rc(640, 1024, 64, 8, 2) == 3 and rc(1536, 1024, 64, 8, 2) == 2
     assert rc(1024, 1024, 64, 8, 2) == 1 and rc(512, 1024, 64, 8, 2) == 2 and rc(256, 1024, 64, 8, 2) == 4 and rc(128, 1024, 64, 8, 2) == 8
     assert rc(2048, 1024, 64, 8, 2) == 1 and rc(4096, 1024, 64, 8, 2) == 1
@@ -298,4 +299,11 @@ def test_row_chunks_minimise_rounds_times_rows():
         for H in (1, 8, 9, 33, 64, 100, 128):
             c = rc(units, 1024, H, 8, 2)
             assert 1 <= c <= max(1, H // 8) and -(-H // -(-H // c)) == c                                  # a count its own row split reproduces
-    assert rc(0, 1024, 64, 8, 2) == 0 and rc(1, 0, 64, 8, 2) == 0
+    assert rc(0, 1024, 64, 8, 2) == 0 and rc(1, 0, 64, 8, 2) == 0 and f(1, 1024, 64, 8, 2, 0) == 0
+    # the two-waves-per-SIMD kernels (strip, F(2,3)): rounds in SIMDs, a row at 14/16 once waves outnumber them -- F(2,3) at c3's shape,
+    # B = 24 (192 strips of 32 columns): 5 chunks (34.5 us; 6, the old rule's count: 43.2); the 2x2 strip kernel at B = 24 / 40 / 96
+    # (384 / 640 / 1,536 waves): 5 / 3 / 2 (23.1 / 37.0 / 93.7 us, the fastest or within 5 % of it); full chips keep the old rule's counts
+    t2 = lambda units, H, extra: f(units, 1024, H, 4, extra, 14)
+    assert t2(192, 64, 2) == 5 and t2(384, 64, 2) == 5 and t2(640, 64, 2) == 3 and t2(1536, 64, 2) == 2
+    assert t2(1024, 64, 3) == 2 and t2(2048, 64, 3) == 1 and t2(8192, 64, 3) == 1 and t2(256, 64, 3) == 4
+    assert t2(512, 64, 2) == 4                                       # (2x2 strip kernel at B = 32: 4 chunks 26.9 us, the old rule's 2 chunks 29.1)
