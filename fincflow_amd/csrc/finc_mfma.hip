@@ -1861,6 +1861,28 @@ int finc_mfma_launch(const float *in, const void *packed, float *out, const Finc
     const size_t lds_hlp = 4 * lds + 64;
     const bool hlp = s64 && i->fn_hlp && ((long long)s.B * s.G) % 4 == 0 && lds_hlp <= 160 * 1024 && !finc_no_hlp();
     const wave_fn fn = zpre ? i->fn_zpre : hlp ? i->fn_hlp : s64 ? i->fn_s64 : (s.W % 8 == 0) ? i->fn_sec : i->fn;
+    // A problem set that is not a whole number of ROUNDS.  One-wave problems run n1 to a compute unit and every problem is the same chain
+    // of steps, so 1,025 problems take as long as 2,048 -- unless the remainder goes to the kernel the library would pick for it on its
+    // own (role-split / short-step kernel up to 256 / 512 problems, the two-wave variants), which is faster than a round of this one or
+    // it would not be picked.  The images are independent: the remainder is a second launch on the images behind the whole rounds
+    // (c3, 64x64: B = 320 = 1,024 + 256 problems 768 -> 578 us, B = 288 768 -> 565; profiles/r05/notes/remainder_launch.txt).
+    static const bool no_remainder = finc_env("FINC_NO_REMAINDER_LAUNCH") != nullptr;   // experiment switch (A/B timing)
+    if (!zpre && i->nw == 1 && i->npw == 1 && !no_remainder) {
+        const long long problems = (long long)s.B * s.G;
+        long long n1 = hlp ? 4 : (long long)((160 * 1024 - 64) / lds);
+        n1 = n1 > 4 ? 4 : n1 < 1 ? 1 : n1;
+        const long long round = n1 * 256, r = problems % round;
+        if (problems > round && r > 0 && r <= 512 && r % s.G == 0) {
+            FincShape head = s, tail = s;
+            tail.B = (int)(r / s.G);
+            head.B = s.B - tail.B;
+            if (finc_split_takes(tail) || find_inst(s.Cq, s.KH, s.KW, r, s.W) != i) {
+                const size_t off = (size_t)head.B * s.G * s.Cq * s.H * s.W;
+                if (int e = finc_mfma_launch(in, packed, out, head, st, false)) return e;
+                return finc_mfma_launch(in + off, packed, out + off, tail, st, false);
+            }
+        }
+    }
     if (i == borrowed_inst(s.Cq, s.KH, s.KW))              // the borrowed two-wave form reads the bank packed behind the bank's own
         packed = (const char *)packed + own_bank_bytes(s.G, s.Cq, s.KH, s.KW);
     if (int e = finc_ensure_dynamic_lds((const void *)fn, hlp ? lds_hlp : lds)) return e;

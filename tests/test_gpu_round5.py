@@ -362,3 +362,32 @@ def test_borrowed_bank_through_the_module_with_the_affine_fold(dev):
         assert fused is not None and rel_err(fused.cpu().numpy(), two.cpu().numpy()) <= TOL
         zz = (y[:2] * torch.exp(an.log_scale).view(1, -1, 1, 1) + an.translation.view(1, -1, 1, 1)).cpu().numpy()
         assert rel_err(fused[:2].cpu().numpy(), oracle.inverse_via_f64(zz, wco, 4, ORIENT_FASTFLOW)) <= TOL
+
+
+# (B, G, Cq, H, W, K): problem sets of whole rounds of one-wave problems plus a remainder that the library hands to the kernel it would
+# pick for the remainder alone (finc_mfma.hip finc_mfma_launch) -- role-split kernel (16 and 256 problems behind 1,024), short-step
+# kernel (12 channels: 40 and 512 behind), the small-batch two-wave variant (24 channels: 260 .. 512 behind), G = 1, 2, 4, two rounds
+REMAINDER_CASES = [(260, 4, 24, 8, 16, 3), (320, 4, 24, 5, 16, 3), (330, 4, 24, 4, 16, 3), (384, 4, 24, 4, 16, 3), (266, 4, 12, 8, 16, 3), (384, 4, 12, 4, 16, 3),
+                   (1100, 1, 24, 4, 16, 3), (650, 2, 20, 3, 16, 3), (522, 4, 24, 3, 16, 3), (300, 4, 16, 6, 16, 2)]
+
+
+@pytest.mark.parametrize("case", REMAINDER_CASES, ids=lambda c: "B%d_G%d_Cq%d_%dx%d_k%d" % c)
+def test_remainder_of_a_round_runs_on_the_remainders_own_kernel(case, dev):
+    """The images behind the whole rounds come from a second launch on another kernel: every image against the oracle (<= 1e-5), the
+    strict kernel bit-exact, and the images on either side of the seam equal to what the same images give in a call of their own."""
+    from fincflow_amd import _lib, ops
+    B, G, Cq, H, W, K = case
+    orient = ORIENT_FASTFLOW if G == 4 else (0x1B & ((1 << (2 * G)) - 1))
+    v = _lib.inverse_variant(B, G, Cq, H, W, K, K)
+    assert v["nw"] == 1 and v["npw"] == 1 and v["sec"] in (2, 3), v          # the one-wave kernel is the call's main kernel
+    run_inverse_case(dev, B, G, orient, Cq, H, W, K, K, seed=B + Cq, tag="remainder")
+    rng = np.random.default_rng(B)
+    ws = oracle.make_stored_weights(G, Cq, K, K, orient=orient, seed=3, std=bank_std(Cq, K))
+    wc = ops.canonicalize(t(ws, dev), G, orient)
+    z = t(rng.standard_normal((B, G * Cq, H, W)).astype(np.float32), dev)
+    whole = ops.finc_inverse(z, wc, G, orient)
+    r = (B * G) % 1024 // G
+    tail = ops.finc_inverse(z[B - r:].contiguous(), wc, G, orient)
+    assert 0 < r <= 512 // G and torch.equal(whole[B - r:], tail)             # the remainder's kernel, on the remainder's images
+    head = ops.finc_inverse(z[:B - r].contiguous(), wc, G, orient)
+    assert torch.equal(whole[:B - r], head)
