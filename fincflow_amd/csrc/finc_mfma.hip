@@ -1566,13 +1566,17 @@ int borrowed_cqp(int cqp, int KH, int KW) { return cqp == 28 && KH == 3 && KW ==
 // One-wave problems run n1 to a compute unit (four SIMDs; fewer once their rings outgrow a quarter of the LDS), borrowed two-wave
 // problems two (a packed pair = four waves), and the chip works through a problem set in rounds of that many per unit.  Measured at
 // C = 112 against C = 128 (profiles/r05/notes/c28_borrowed_bank.txt): a round of one-wave 28-channel problems takes 540 us at 64x64
-// (170 at 32x32), a round of two-wave problems 437 (138) -- 0.81 of it, whatever the map.  The borrowed form is taken when its
-// rounds are the shorter sum: up to 512 problems (-19 %), and at 64x64 again from 769 to 1,024 (1,080 -> 876 us).
+// (170 at 32x32), a round of two-wave problems 437 (138) -- 0.81 of it, whatever the map.  Up to 512 problems the borrowed form is one
+// round against one: -19 %.  Beyond, with three or four one-wave problems to a unit, the bank's own kernel has the better rate (0.70
+// against 0.85 us per problem) and hands a remainder to the role-split kernel (finc_mfma_launch: 1,024 problems = 768 + 256 in
+// 540 + 205 us, where two borrowed rounds take 876); with two or fewer to a unit (maps of about 100 columns and more) the borrowed
+// form's rounds are never the longer sum.
 static bool borrowed_form_wins(long long problems, size_t lds_one_wave)
 {
     const long long CUS = 256;                                  // MI355X
     long long n1 = (long long)((160 * 1024 - 64) / lds_one_wave);
     n1 = n1 > 4 ? 4 : n1 < 1 ? 1 : n1;
+    if (n1 >= 3 && problems > 2 * CUS) return false;
     const long long r1 = (problems + n1 * CUS - 1) / (n1 * CUS), r2 = (problems + 2 * CUS - 1) / (2 * CUS);
     return r2 * 13 < r1 * 16;                                   // (437 / 540 = 0.81 = 13 / 16)
 }
@@ -1867,9 +1871,12 @@ int finc_mfma_launch(const float *in, const void *packed, float *out, const Finc
     // it would not be picked.  The images are independent: the remainder is a second launch on the images behind the whole rounds
     // (c3, 64x64: B = 320 = 1,024 + 256 problems 768 -> 578 us, B = 288 768 -> 565; profiles/r05/notes/remainder_launch.txt).
     static const bool no_remainder = finc_env("FINC_NO_REMAINDER_LAUNCH") != nullptr;   // experiment switch (A/B timing)
-    if (!zpre && i->nw == 1 && i->npw == 1 && !no_remainder) {
+    // (The packed two-wave kernels -- a pair of problems on a unit's four SIMDs -- work in rounds of 512 the same way: 32 channels,
+    // B = 160: 865 -> 642 us.)
+    const bool one_wave = i->nw == 1 && i->npw == 1, packed_pair = i->nw == 2 && i->npw == 2;
+    if (!zpre && (one_wave || packed_pair) && !no_remainder) {
         const long long problems = (long long)s.B * s.G;
-        long long n1 = hlp ? 4 : (long long)((160 * 1024 - 64) / lds);
+        long long n1 = packed_pair ? 2 : hlp ? 4 : (long long)((160 * 1024 - 64) / lds);
         n1 = n1 > 4 ? 4 : n1 < 1 ? 1 : n1;
         const long long round = n1 * 256, r = problems % round;
         if (problems > round && r > 0 && r <= 512 && r % s.G == 0) {

@@ -19,3 +19,9 @@ run 384 48 32 32 3
 run 320 80 64 64 3
 run 300 64 64 64 2
 run 224 112 64 64 3 0.02
+run 160 128 64 64 3 0.03
+run 192 128 64 64 3 0.03
+run 320 128 64 64 3 0.03
+run 160 128 64 64 2
+run 64 112 64 64 3 0.02
+run 32 112 64 64 3 0.02

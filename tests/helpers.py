@@ -158,10 +158,12 @@ def pick_row(rows, cqp, kh, kw, problems, H=10, W=32):
 def borrowed_form_wins(problems, W):
     """The 28-channel 3x3 bank on the 32-channel bank's packed two-wave kernel (finc_mfma.hip, borrowed_form_wins): the chip takes
     one-wave problems n1 to a compute unit (as many of their rings as fit 160 KB, at most four), two-wave problems two; a two-wave
-    round takes 13/16 of a one-wave round."""
+    round takes 13/16 of a one-wave round; beyond 512 problems only where at most two one-wave problems fit a unit."""
     P = min(W, 16)
     lds = 4 * (7 * 12 * 64 + 7 * 8 * 64 + (W - P + 1) * 56 + 56 + 64)
     n1 = max(1, min(4, (160 * 1024 - 64) // lds))
+    if n1 >= 3 and problems > 512:          # (the bank's own kernel has the better rate and hands a remainder to the role-split kernel)
+        return False
     r1, r2 = -(-problems // (n1 * 256)), -(-problems // 512)
     return r2 * 13 < r1 * 16
 

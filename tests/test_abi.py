@@ -60,16 +60,17 @@ def test_algo_selection_is_host_side_and_consistent():
     for (B, Cq, W, row) in ((160, 12, 32, -3), (161, 12, 32, -4), (64, 40, 32, -3), (65, 40, 32, -4), (80, 20, 32, -3), (81, 20, 32, -4),
                             (256, 12, 30, -3), (256, 100, 32, -3)):
         assert _lib.inverse_variant(B, 4, Cq, 32, W, 4 if Cq < 100 else 3, 4 if Cq < 100 else 3)["row"] == row, (B, Cq, W, row)
-    # the 28-channel 3x3 bank (no two-wave form of its own) borrows the 32-channel bank's packed two-wave kernel where its rounds are
-    # the shorter sum: up to 512 even problem counts, and on maps whose rings let three one-wave problems onto a unit again at 769 .. 1,024
-    # (profiles/r05/notes/c28_borrowed_bank.txt); channel counts 25 .. 27 pad to the 28-channel bank and follow it
+    # the 28-channel 3x3 bank (no two-wave form of its own) borrows the 32-channel bank's packed two-wave kernel at even problem counts up
+    # to 512 (one round against one, 0.81 of the time: profiles/r05/notes/c28_borrowed_bank.txt) -- beyond that only on maps so wide that at
+    # most two one-wave problems fit a compute unit; channel counts 25 .. 27 pad to the 28-channel bank and follow it
     own = _lib.inverse_variant(257, 1, 28, 64, 64, 3, 3)
     assert own["cqp"] == 28 and own["nw"] == 1 and own["npw"] == 1
-    for (B, G, Cq, HW, borrowed) in ((128, 4, 28, 64, True), (129, 4, 28, 64, False), (192, 4, 28, 64, False), (193, 4, 28, 64, True), (256, 4, 28, 64, True),
-                                     (257, 4, 28, 64, False), (512, 4, 28, 64, False), (515, 1, 28, 64, False), (128, 4, 25, 64, True), (65, 4, 28, 32, True),
-                                     (129, 4, 28, 32, False), (256, 4, 28, 32, False), (128, 4, 32, 64, False), (128, 4, 24, 64, False)):
-        v = _lib.inverse_variant(B, G, Cq, HW, HW, 3, 3)
-        assert (v["cqp"] == 32 and v["nw"] == 2 and v["npw"] == 2 and Cq < 29) == borrowed, (B, G, Cq, HW, v)
+    for (B, G, Cq, H, W, borrowed) in ((128, 4, 28, 64, 64, True), (129, 4, 28, 64, 64, False), (192, 4, 28, 64, 64, False), (193, 4, 28, 64, 64, False),
+                                       (256, 4, 28, 64, 64, False), (512, 4, 28, 64, 64, False), (515, 1, 28, 64, 64, False), (128, 4, 25, 64, 64, True),
+                                       (65, 4, 28, 32, 32, True), (129, 4, 28, 32, 32, False), (256, 4, 28, 32, 32, False), (128, 4, 32, 64, 64, False),
+                                       (128, 4, 24, 64, 64, False), (256, 4, 28, 16, 128, True), (384, 4, 28, 16, 128, True), (256, 4, 28, 64, 80, False)):
+        v = _lib.inverse_variant(B, G, Cq, H, W, 3, 3)
+        assert (v["cqp"] == 32 and v["nw"] == 2 and v["npw"] == 2 and Cq < 29) == borrowed, (B, G, Cq, H, W, v)
         assert v["row"] != own["row"] if borrowed else True
     # beyond that kernel's limits (9x9 filter; a 7x7 bank of 96 channels whose step ring exceeds the LDS) -> reference-order kernel
     assert L.finc_inverse_algo_for(16, 32, 32, 9, 9) == STRICT and L.finc_forward_algo_for(16, 32, 32, 9, 9) == STRICT
@@ -188,9 +189,9 @@ def test_wide_maps_take_the_packed_two_wave_form():
         assert (v["nw"], v["npw"]) == (2, 2) and v["lds_bytes"] <= 160 * 1024, (H, W, v)
     assert _lib.inverse_variant(256, 4, 24, 64, 56, 3, 3)["nw"] == 1        # four problems still fit: one wave each
     assert _lib.inverse_variant(131, 1, 24, 8, 80, 3, 3)["nw"] == 1         # an odd count cannot be packed in pairs: one wave each
-    v = _lib.inverse_variant(256, 4, 28, 64, 80, 3, 3)                      # no two-wave row for this bank: it borrows the 32-channel bank's
-    assert (v["nw"], v["npw"], v["cqp"]) == (2, 2, 32)                      # where that form's rounds are the shorter sum (1,024 problems: 2 x 0.81 against 2)
-    assert _lib.inverse_variant(384, 4, 28, 64, 80, 3, 3)["nw"] == 1        # ... and not where they are not (1,536: 3 x 0.81 against 2)
+    assert _lib.inverse_variant(256, 4, 28, 64, 80, 3, 3)["nw"] == 1        # no two-wave row for this bank; three one-wave problems to a unit: its own kernel
+    v = _lib.inverse_variant(256, 4, 28, 64, 128, 3, 3)                     # ... two to a unit: it borrows the 32-channel bank's packed two-wave kernel
+    assert (v["nw"], v["npw"], v["cqp"]) == (2, 2, 32)
 
 
 def test_kernel_attribute_table_is_keyed_by_device_and_kernel():

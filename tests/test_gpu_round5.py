@@ -346,7 +346,7 @@ def test_borrowed_bank_through_the_module_with_the_affine_fold(dev):
         an.translation.copy_(torch.randn(C, device=dev))
         an.initialized.fill_(1)
     assert _lib.inverse_variant(128, 4, 28, H, W, 3, 3)["cqp"] == 32 and _lib.inverse_variant(129, 4, 28, H, W, 3, 3)["cqp"] == 28
-    assert _lib.inverse_variant(192, 4, 28, H, W, 3, 3)["cqp"] == 28 and _lib.inverse_variant(256, 4, 28, H, W, 3, 3)["cqp"] == 32
+    assert _lib.inverse_variant(192, 4, 28, H, W, 3, 3)["cqp"] == 28 and _lib.inverse_variant(256, 4, 28, H, W, 3, 3)["cqp"] == 28
     x = torch.randn(129, C, H, W, device=dev)
     wco = oracle.canonicalize(torch.cat(unit._weights()).detach().cpu().numpy(), 4, ORIENT_FASTFLOW)
     with torch.no_grad():
@@ -368,7 +368,9 @@ def test_borrowed_bank_through_the_module_with_the_affine_fold(dev):
 # pick for the remainder alone (finc_mfma.hip finc_mfma_launch) -- role-split kernel (16 and 256 problems behind 1,024), short-step
 # kernel (12 channels: 40 and 512 behind), the small-batch two-wave variant (24 channels: 260 .. 512 behind), G = 1, 2, 4, two rounds
 REMAINDER_CASES = [(260, 4, 24, 8, 16, 3), (320, 4, 24, 5, 16, 3), (330, 4, 24, 4, 16, 3), (384, 4, 24, 4, 16, 3), (266, 4, 12, 8, 16, 3), (384, 4, 12, 4, 16, 3),
-                   (1100, 1, 24, 4, 16, 3), (650, 2, 20, 3, 16, 3), (522, 4, 24, 3, 16, 3), (300, 4, 16, 6, 16, 2)]
+                   (1100, 1, 24, 4, 16, 3), (650, 2, 20, 3, 16, 3), (522, 4, 24, 3, 16, 3), (300, 4, 16, 6, 16, 2),
+                   # the packed two-wave kernels (32 channels): rounds of 512
+                   (140, 4, 32, 4, 16, 3), (192, 4, 32, 3, 16, 2), (150, 4, 30, 5, 16, 3)]
 
 
 @pytest.mark.parametrize("case", REMAINDER_CASES, ids=lambda c: "B%d_G%d_Cq%d_%dx%d_k%d" % c)
@@ -379,14 +381,15 @@ def test_remainder_of_a_round_runs_on_the_remainders_own_kernel(case, dev):
     B, G, Cq, H, W, K = case
     orient = ORIENT_FASTFLOW if G == 4 else (0x1B & ((1 << (2 * G)) - 1))
     v = _lib.inverse_variant(B, G, Cq, H, W, K, K)
-    assert v["nw"] == 1 and v["npw"] == 1 and v["sec"] in (2, 3), v          # the one-wave kernel is the call's main kernel
+    assert (v["nw"], v["npw"]) == ((2, 2) if Cq > 28 else (1, 1)) and v["sec"] in (1, 2, 3), v   # the call's main kernel
+    rnd = 512 if Cq > 28 else 1024
     run_inverse_case(dev, B, G, orient, Cq, H, W, K, K, seed=B + Cq, tag="remainder")
     rng = np.random.default_rng(B)
     ws = oracle.make_stored_weights(G, Cq, K, K, orient=orient, seed=3, std=bank_std(Cq, K))
     wc = ops.canonicalize(t(ws, dev), G, orient)
     z = t(rng.standard_normal((B, G * Cq, H, W)).astype(np.float32), dev)
     whole = ops.finc_inverse(z, wc, G, orient)
-    r = (B * G) % 1024 // G
+    r = (B * G) % rnd // G
     tail = ops.finc_inverse(z[B - r:].contiguous(), wc, G, orient)
     assert 0 < r <= 512 // G and torch.equal(whole[B - r:], tail)             # the remainder's kernel, on the remainder's images
     head = ops.finc_inverse(z[:B - r].contiguous(), wc, G, orient)
