@@ -1831,15 +1831,39 @@ int finc_mfma_table_row(int row, int *info)
     return FINC_OK;
 }
 
+// A problem set that is not a whole number of ROUNDS.  One-wave problems run n1 to a compute unit and every problem is the same chain
+// of steps, so 1,025 problems take as long as 2,048 -- unless the remainder goes to the kernel the library would pick for it on its
+// own (role-split / short-step kernel up to 256 / 512 problems, the two-wave variants), which is faster than a round of this one or
+// it would not be picked.  The images are independent: the remainder is a second launch on the images behind the whole rounds
+// (c3, 64x64: B = 320 = 1,024 + 256 problems 765 -> 591 us, B = 264 761 -> 522; profiles/r05/notes/remainder_launch.txt).
+// The packed two-wave kernels -- a pair of problems on a unit's four SIMDs -- work in rounds of 512 the same way (32 channels,
+// B = 160: 865 -> 642 us).  Returns the number of images of the remainder launch (0: one launch).
+static int remainder_images(const FincShape &s, const Inst *i, bool hlp, size_t lds)
+{
+    static const bool no_remainder = finc_env("FINC_NO_REMAINDER_LAUNCH") != nullptr;   // experiment switch (A/B timing)
+    const bool one_wave = i->nw == 1 && i->npw == 1, packed_pair = i->nw == 2 && i->npw == 2;
+    if (no_remainder || !(one_wave || packed_pair)) return 0;
+    const long long problems = (long long)s.B * s.G;
+    long long n1 = packed_pair ? 2 : hlp ? 4 : (long long)((160 * 1024 - 64) / lds);
+    n1 = n1 > 4 ? 4 : n1 < 1 ? 1 : n1;
+    const long long round = n1 * 256, r = problems % round;
+    if (problems <= round || r == 0 || r > 512 || r % s.G != 0) return 0;
+    FincShape tail = s;
+    tail.B = (int)(r / s.G);
+    return (finc_split_takes(tail) || find_inst(s.Cq, s.KH, s.KW, r, s.W) != i) ? tail.B : 0;
+}
+
 // the premultiplied-input form exists for the shapes the helper-wave kernel takes (a full chip: the role-split kernel's
-// small problem sets and the forms without helper waves keep their z-term)
+// small problem sets and the forms without helper waves keep their z-term) -- in ONE launch: a problem set with a remainder launch
+// (above) keeps the plain chain, whose remainder runs on kernels without that form (c3, B = 264: 522 us against 0.93 x 761)
 bool finc_mfma_zpre_takes(const FincShape &s)
 {
     if (!finc_mfma_supported(s.Cq, s.H, s.W, s.KH, s.KW) || stream_bank(s.Cq, s.KH, s.KW) || finc_split_takes(s)) return false;
     const Inst *i = find_inst(s.Cq, s.KH, s.KW, (long long)s.B * s.G, s.W);
     if (!i || !i->fn_zpre || s.W % 16 != 0 || finc_no_s64() || finc_no_hlp()) return false;
     const int P = 16;
-    return ((long long)s.B * s.G) % 4 == 0 && 4 * lds_bytes(*i, s.W, P) + 64 <= 160 * 1024;
+    if (!(((long long)s.B * s.G) % 4 == 0 && 4 * lds_bytes(*i, s.W, P) + 64 <= 160 * 1024)) return false;
+    return remainder_images(s, i, true, lds_bytes(*i, s.W, P)) == 0;
 }
 
 int finc_mfma_launch(const float *in, const void *packed, float *out, const FincShape &s, hipStream_t st, bool zpre)
@@ -1865,29 +1889,14 @@ int finc_mfma_launch(const float *in, const void *packed, float *out, const Finc
     const size_t lds_hlp = 4 * lds + 64;
     const bool hlp = s64 && i->fn_hlp && ((long long)s.B * s.G) % 4 == 0 && lds_hlp <= 160 * 1024 && !finc_no_hlp();
     const wave_fn fn = zpre ? i->fn_zpre : hlp ? i->fn_hlp : s64 ? i->fn_s64 : (s.W % 8 == 0) ? i->fn_sec : i->fn;
-    // A problem set that is not a whole number of ROUNDS.  One-wave problems run n1 to a compute unit and every problem is the same chain
-    // of steps, so 1,025 problems take as long as 2,048 -- unless the remainder goes to the kernel the library would pick for it on its
-    // own (role-split / short-step kernel up to 256 / 512 problems, the two-wave variants), which is faster than a round of this one or
-    // it would not be picked.  The images are independent: the remainder is a second launch on the images behind the whole rounds
-    // (c3, 64x64: B = 320 = 1,024 + 256 problems 768 -> 578 us, B = 288 768 -> 565; profiles/r05/notes/remainder_launch.txt).
-    static const bool no_remainder = finc_env("FINC_NO_REMAINDER_LAUNCH") != nullptr;   // experiment switch (A/B timing)
-    // (The packed two-wave kernels -- a pair of problems on a unit's four SIMDs -- work in rounds of 512 the same way: 32 channels,
-    // B = 160: 865 -> 642 us.)
-    const bool one_wave = i->nw == 1 && i->npw == 1, packed_pair = i->nw == 2 && i->npw == 2;
-    if (!zpre && (one_wave || packed_pair) && !no_remainder) {
-        const long long problems = (long long)s.B * s.G;
-        long long n1 = packed_pair ? 2 : hlp ? 4 : (long long)((160 * 1024 - 64) / lds);
-        n1 = n1 > 4 ? 4 : n1 < 1 ? 1 : n1;
-        const long long round = n1 * 256, r = problems % round;
-        if (problems > round && r > 0 && r <= 512 && r % s.G == 0) {
+    if (!zpre) {                                            // whole rounds + a remainder on the remainder's own kernel (remainder_images)
+        if (const int tb = remainder_images(s, i, hlp, lds)) {
             FincShape head = s, tail = s;
-            tail.B = (int)(r / s.G);
-            head.B = s.B - tail.B;
-            if (finc_split_takes(tail) || find_inst(s.Cq, s.KH, s.KW, r, s.W) != i) {
-                const size_t off = (size_t)head.B * s.G * s.Cq * s.H * s.W;
-                if (int e = finc_mfma_launch(in, packed, out, head, st, false)) return e;
-                return finc_mfma_launch(in + off, packed, out + off, tail, st, false);
-            }
+            tail.B = tb;
+            head.B = s.B - tb;
+            const size_t off = (size_t)head.B * s.G * s.Cq * s.H * s.W;
+            if (int e = finc_mfma_launch(in, packed, out, head, st, false)) return e;
+            return finc_mfma_launch(in + off, packed, out + off, tail, st, false);
         }
     }
     if (i == borrowed_inst(s.Cq, s.KH, s.KW))              // the borrowed two-wave form reads the bank packed behind the bank's own

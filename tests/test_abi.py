@@ -308,3 +308,14 @@ def test_row_chunks_minimise_rounds_times_rows():
     assert t2(192, 64, 2) == 5 and t2(384, 64, 2) == 5 and t2(640, 64, 2) == 3 and t2(1536, 64, 2) == 2
     assert t2(1024, 64, 3) == 2 and t2(2048, 64, 3) == 1 and t2(8192, 64, 3) == 1 and t2(256, 64, 3) == 4
     assert t2(512, 64, 2) == 4                                       # (2x2 strip kernel at B = 32: 4 chunks 26.9 us, the old rule's 2 chunks 29.1)
+
+
+def test_premultiplied_form_only_where_the_call_is_one_launch():
+    """finc_mfma.hip remainder_images: a problem set of whole rounds plus a remainder of at most 512 problems is two launches, and the
+    remainder's kernels (role-split, short-step, two-wave variants) have no premultiplied-input form -- the query says so, and a flow stack
+    then keeps the plain chain (c3, B = 264: 522 us in two launches against 0.93 x 761 in one)."""
+    q = _lib.lib().finc_inverse_premultiplied_supported
+    assert q(256, 4, 24, 64, 64, 3, 3) == 1 and q(512, 4, 24, 64, 64, 3, 3) == 1          # whole rounds
+    assert q(264, 4, 24, 64, 64, 3, 3) == 0 and q(320, 4, 24, 64, 64, 3, 3) == 0 and q(384, 4, 24, 64, 64, 3, 3) == 0
+    assert q(400, 4, 24, 64, 64, 3, 3) == 1                                               # remainder 576 > 512: one launch of two rounds
+    assert q(132, 4, 24, 64, 64, 3, 3) == 1 and q(64, 4, 24, 64, 64, 3, 3) == 0           # (a single partial round; the role-split kernel's 256 problems)

@@ -394,3 +394,30 @@ def test_remainder_of_a_round_runs_on_the_remainders_own_kernel(case, dev):
     assert 0 < r <= 512 // G and torch.equal(whole[B - r:], tail)             # the remainder's kernel, on the remainder's images
     head = ops.finc_inverse(z[:B - r].contiguous(), wc, G, orient)
     assert torch.equal(whole[:B - r], head)
+
+
+def test_a_flow_stack_at_a_batch_with_a_remainder_keeps_the_plain_chain(dev):
+    """[unit, ActNorm, Conv1x1] reversed at B = 260 (1,040 problems = a round + 16): the premultiplied-input form is one launch or nothing
+    (finc_mfma.hip remainder_images), so the container runs the plain inverse -- two launches -- and gives what the layer-by-layer
+    chain gives and what went in; at B = 256 it takes the fused path as before."""
+    from fincflow_amd import FastFlowUnit, FlowSequential, glow, _lib
+    from fincflow_amd.layers import StandardNormal
+    C, H, W = 96, 4, 16
+    q = _lib.lib().finc_inverse_premultiplied_supported
+    assert q(256, 4, 24, H, W, 3, 3) == 1 and q(260, 4, 24, H, W, 3, 3) == 0
+    torch.manual_seed(11)
+    unit = FastFlowUnit(C, C, 3).to(dev)
+    an, mix = glow.ActNorm(C).to(dev), glow.Conv1x1(C).to(dev)
+    with torch.no_grad():
+        an.log_scale.copy_(0.2 * torch.randn(C, device=dev))
+        an.translation.copy_(torch.randn(C, device=dev))
+        an.mark_initialized()
+    seq = FlowSequential(StandardNormal((C, H, W)), unit, an, mix)
+    for B in (256, 260):
+        x = torch.randn(B, C, H, W, device=dev)
+        with torch.no_grad():
+            zz = seq(x)[0]
+            a = seq._reverse_chain(zz, None)
+            b = seq._reverse_chain(zz, None, fuse=False)
+        assert rel_err(a.cpu().numpy(), b.cpu().numpy()) <= TOL and rel_err(a.cpu().numpy(), x.cpu().numpy()) <= 1e-4
+    assert _lib.hlp_timeouts() == 0
