@@ -28,7 +28,7 @@ SYMBOLS = [
     "finc_inverse_kernel_variant", "finc_debug_attr_table_insert", "finc_debug_inverse_table_row",
     "finc_mix_supported_f32", "finc_mix_f32", "finc_pack_forward_weights_affine_f32", "finc_debug_hlp_timeouts",
     "finc_build_flags", "finc_inverse_packed_premultiplied_f32", "finc_inverse_premultiplied_supported", "finc_clear_fault", "finc_debug_backward_variant", "finc_debug_set_forward_form",
-    "finc_debug_row_chunks",
+    "finc_debug_row_chunks", "finc_debug_inverse_remainder_images",
     "finc_inverse_affine_supported", "finc_fault_pending", "finc_runtime_switches",
     "finc_debug_clock_probe_begin", "finc_debug_clock_probe_end",
 ]
@@ -97,6 +97,7 @@ def lib():
     L.finc_debug_inverse_table_row.argtypes = [i, ctypes.POINTER(ctypes.c_int)]
     L.finc_debug_hlp_timeouts.argtypes = [ctypes.POINTER(ctypes.c_uint)]
     L.finc_debug_backward_variant.argtypes = [i, i, i, i, i, i, i, ctypes.POINTER(ctypes.c_int)]
+    L.finc_debug_inverse_remainder_images.argtypes = [i, i, i, i, i, i, i]
     L.finc_debug_row_chunks.argtypes = [ctypes.c_longlong, ctypes.c_longlong, i, i, i, i]
     L.finc_debug_set_forward_form.argtypes = [i]
     L.finc_mix_supported_f32.argtypes = [i]
@@ -125,6 +126,11 @@ def inverse_variant(B, G, Cq, H, W, KH, KW):
     check(st, "finc_inverse_kernel_variant")
     keys = ("cqp", "nw", "npw", "sec", "lds_bytes", "workgroups", "row", "rows")
     return dict(zip(keys, list(info)))
+
+
+def inverse_remainder_images(B, G, Cq, H, W, KH, KW):
+    """Images of an inverse call that go to a second launch on the remainder's own kernel (0: one launch)."""
+    return int(lib().finc_debug_inverse_remainder_images(B, G, Cq, H, W, KH, KW))
 
 
 def backward_variant(B, G, Cq, H, W, KH, KW):

@@ -572,6 +572,12 @@ int finc_debug_backward_variant(int B, int G, int Cq, int H, int W, int KH, int 
 
 int finc_debug_set_forward_form(int form) { return finc_wino_set_form(form); }
 
+int finc_debug_inverse_remainder_images(int B, int G, int Cq, int H, int W, int KH, int KW)
+{
+    if (B < 1 || G < 1 || Cq < 1 || H < 1 || W < 1 || KH < 1 || KW < 1) return 0;
+    return finc_mfma_remainder_images(FincShape{B, G, Cq, H, W, KH, KW, 0});
+}
+
 int finc_debug_row_chunks(long long units, long long slots, int H, int min_rows, int extra, int second_tenant)
 {
     if (units < 1 || slots < 1 || H < 1 || min_rows < 1 || extra < 0 || second_tenant < 1 || second_tenant > 16) return 0;

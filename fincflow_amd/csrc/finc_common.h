@@ -157,6 +157,7 @@ bool finc_stream_supported(int Cq, int H, int W, int KH, int KW, bool inverse);
 size_t finc_stream_packed_bytes(int G, int Cq, int KH, int KW, bool inverse);
 int finc_stream_pack(const float *wc, const float *scale, const float *shift, void *packed, int G, int Cq, int KH, int KW, bool inverse,
                      bool transpose, hipStream_t st);
+int finc_mfma_remainder_images(const FincShape &s);
 int finc_stream_info(const FincShape &s, bool inverse, int *cqp, int *lds, int *steps, int *waves = nullptr, int *one_wave_vec = nullptr);
 int finc_stream_launch(const float *in, const void *packed, float *out, const FincShape &s, bool inverse, hipStream_t st);
 unsigned finc_build_flags_stream();

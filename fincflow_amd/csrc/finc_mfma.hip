@@ -1866,6 +1866,21 @@ bool finc_mfma_zpre_takes(const FincShape &s)
     return remainder_images(s, i, true, lds_bytes(*i, s.W, P)) == 0;
 }
 
+// images of the remainder launch of an inverse call (0: the call is one launch) -- the launch's own decision, for tests and bench.py
+int finc_mfma_remainder_images(const FincShape &s)
+{
+    if (!finc_mfma_supported(s.Cq, s.H, s.W, s.KH, s.KW) || finc_big_bank(s.Cq, s.KH, s.KW) || stream_bank(s.Cq, s.KH, s.KW) || wide_takeover(s) ||
+        finc_split_takes(s))
+        return 0;
+    const Inst *i = find_inst(s.Cq, s.KH, s.KW, (long long)s.B * s.G, s.W);
+    if (!i) return 0;
+    const int P = s.W < 16 ? s.W : 16;
+    const size_t lds = lds_bytes(*i, s.W, P);
+    const bool s64 = s.W % 16 == 0 && i->fn_s64 && !finc_no_s64();
+    const bool hlp = s64 && i->fn_hlp && ((long long)s.B * s.G) % 4 == 0 && 4 * lds + 64 <= 160 * 1024 && !finc_no_hlp();
+    return remainder_images(s, i, hlp, lds);
+}
+
 int finc_mfma_launch(const float *in, const void *packed, float *out, const FincShape &s, hipStream_t st, bool zpre)
 {
     if (!finc_mfma_supported(s.Cq, s.H, s.W, s.KH, s.KW)) return FINC_ERR_UNSUPPORTED;

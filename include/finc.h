@@ -270,6 +270,12 @@ int finc_debug_backward_variant(int B, int G, int Cq, int H, int W, int KH, int 
  * 0 = the library's choice (default), 1 = the direct strip kernels (3x3 and 5x5), 2 = Winograd F(2,3), 4 = Winograd F(4,3).  A form a call
  * cannot take (width not a multiple of 4, unaligned activations, bank too large) still falls back to the strip kernel. */
 int finc_debug_set_forward_form(int form);
+/* How many images of an fp32 inverse call (FINC_ALGO_AUTO / the packed entry points) go to a SECOND launch: a problem set of whole
+ * rounds of one-wave problems (1,024: four to a compute unit; 512 for the packed two-wave kernels) plus a remainder of at most 512
+ * problems runs the rounds on that kernel and the remainder's images -- the last ones of the batch -- on the kernel the library picks
+ * for them alone (`finc_inverse_kernel_variant` of that image count).  0: the call is one launch.  Host-only.  (The reference's
+ * counterpart is the host loop of cinc_cuda_level2.cpp:19-32: 3,048 launches whatever the batch.) */
+int finc_debug_inverse_remainder_images(int B, int G, int Cq, int H, int W, int KH, int KW);
 /* The row-chunk count the one-wave-per-SIMD forward kernels (F(4,3), its M-split, F(2,5)) launch with: `units` strips of which the chip
  * holds `slots` at a time, maps of H rows, chunks of at least `min_rows` rows that each recompute `extra` rows of operands -- the count
  * that minimises rounds x (rows per chunk + extra).  `second_tenant` (1 .. 16): sixteenths a row costs once the launch has more units

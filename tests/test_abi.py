@@ -315,6 +315,14 @@ def test_premultiplied_form_only_where_the_call_is_one_launch():
     remainder's kernels (role-split, short-step, two-wave variants) have no premultiplied-input form -- the query says so, and a flow stack
     then keeps the plain chain (c3, B = 264: 522 us in two launches against 0.93 x 761 in one)."""
     q = _lib.lib().finc_inverse_premultiplied_supported
+    rem = _lib.inverse_remainder_images
+    # (the launch's own decision: images of the second launch)
+    assert [rem(B, 4, 24, 64, 64, 3, 3) for B in (64, 160, 256, 260, 264, 320, 384, 400, 512, 576)] == [0, 0, 0, 4, 8, 64, 128, 0, 0, 64]
+    assert rem(160, 4, 32, 64, 64, 3, 3) == 32 and rem(128, 4, 32, 64, 64, 3, 3) == 0     # the packed two-wave kernels: rounds of 512
+    assert rem(256, 4, 28, 64, 64, 3, 3) == 64 and rem(192, 4, 28, 64, 64, 3, 3) == 0     # 28 channels at 64x64: rounds of 768 (three one-wave problems to a unit)
+    assert rem(1100, 1, 24, 4, 16, 3, 3) == 76 and rem(341, 3, 24, 4, 16, 3, 3) == 0      # G = 1; a remainder (1,023 problems: none) / off an image boundary
+    assert rem(342, 3, 24, 4, 16, 3, 3) == 0                                               # 1,026 problems, G = 3: 2 problems are no whole image
+    assert rem(256, 4, 192, 64, 64, 3, 3) == 0 and rem(320, 4, 48, 64, 64, 5, 5) == 0     # streaming-bank / four-wave kernels: one launch
     assert q(256, 4, 24, 64, 64, 3, 3) == 1 and q(512, 4, 24, 64, 64, 3, 3) == 1          # whole rounds
     assert q(264, 4, 24, 64, 64, 3, 3) == 0 and q(320, 4, 24, 64, 64, 3, 3) == 0 and q(384, 4, 24, 64, 64, 3, 3) == 0
     assert q(400, 4, 24, 64, 64, 3, 3) == 1                                               # remainder 576 > 512: one launch of two rounds

@@ -367,31 +367,38 @@ def test_borrowed_bank_through_the_module_with_the_affine_fold(dev):
 # (B, G, Cq, H, W, K): problem sets of whole rounds of one-wave problems plus a remainder that the library hands to the kernel it would
 # pick for the remainder alone (finc_mfma.hip finc_mfma_launch) -- role-split kernel (16 and 256 problems behind 1,024), short-step
 # kernel (12 channels: 40 and 512 behind), the small-batch two-wave variant (24 channels: 260 .. 512 behind), G = 1, 2, 4, two rounds
-REMAINDER_CASES = [(260, 4, 24, 8, 16, 3), (320, 4, 24, 5, 16, 3), (330, 4, 24, 4, 16, 3), (384, 4, 24, 4, 16, 3), (266, 4, 12, 8, 16, 3), (384, 4, 12, 4, 16, 3),
-                   (1100, 1, 24, 4, 16, 3), (650, 2, 20, 3, 16, 3), (522, 4, 24, 3, 16, 3), (300, 4, 16, 6, 16, 2),
+REMAINDER_CASES = [(260, 4, 24, 8, 16, 3, 4), (320, 4, 24, 5, 16, 3, 64), (330, 4, 24, 4, 16, 3, 74), (384, 4, 24, 4, 16, 3, 128), (266, 4, 12, 8, 16, 3, 10),
+                   (384, 4, 12, 4, 16, 3, 128), (1100, 1, 24, 4, 16, 3, 76), (522, 4, 24, 3, 16, 3, 10), (300, 4, 16, 6, 16, 2, 44),
+                   # 20 channels, 276 problems behind a round: no other kernel would take them (above the role-split kernel's 256, no two-wave
+                   # variant, the short-step kernel ends at 16 channels) -- one launch
+                   (650, 2, 20, 3, 16, 3, 0),
                    # the packed two-wave kernels (32 channels): rounds of 512
-                   (140, 4, 32, 4, 16, 3), (192, 4, 32, 3, 16, 2), (150, 4, 30, 5, 16, 3)]
+                   (140, 4, 32, 4, 16, 3, 12), (192, 4, 32, 3, 16, 2, 64), (150, 4, 30, 5, 16, 3, 22)]
+# (the last number: the images the library says it hands to the second launch)
 
 
-@pytest.mark.parametrize("case", REMAINDER_CASES, ids=lambda c: "B%d_G%d_Cq%d_%dx%d_k%d" % c)
+@pytest.mark.parametrize("case", REMAINDER_CASES, ids=lambda c: "B%d_G%d_Cq%d_%dx%d_k%d" % c[:6])
 def test_remainder_of_a_round_runs_on_the_remainders_own_kernel(case, dev):
     """The images behind the whole rounds come from a second launch on another kernel: every image against the oracle (<= 1e-5), the
     strict kernel bit-exact, and the images on either side of the seam equal to what the same images give in a call of their own."""
     from fincflow_amd import _lib, ops
-    B, G, Cq, H, W, K = case
+    B, G, Cq, H, W, K, r = case
     orient = ORIENT_FASTFLOW if G == 4 else (0x1B & ((1 << (2 * G)) - 1))
     v = _lib.inverse_variant(B, G, Cq, H, W, K, K)
     assert (v["nw"], v["npw"]) == ((2, 2) if Cq > 28 else (1, 1)) and v["sec"] in (1, 2, 3), v   # the call's main kernel
     rnd = 512 if Cq > 28 else 1024
+    assert _lib.inverse_remainder_images(B, G, Cq, H, W, K, K) == r and r in (0, (B * G) % rnd // G)          # the launch's own answer
+    assert _lib.inverse_remainder_images(B - r, G, Cq, H, W, K, K) == 0 or r == 0
     run_inverse_case(dev, B, G, orient, Cq, H, W, K, K, seed=B + Cq, tag="remainder")
     rng = np.random.default_rng(B)
     ws = oracle.make_stored_weights(G, Cq, K, K, orient=orient, seed=3, std=bank_std(Cq, K))
     wc = ops.canonicalize(t(ws, dev), G, orient)
     z = t(rng.standard_normal((B, G * Cq, H, W)).astype(np.float32), dev)
     whole = ops.finc_inverse(z, wc, G, orient)
-    r = (B * G) % rnd // G
+    if r == 0:
+        return
     tail = ops.finc_inverse(z[B - r:].contiguous(), wc, G, orient)
-    assert 0 < r <= 512 // G and torch.equal(whole[B - r:], tail)             # the remainder's kernel, on the remainder's images
+    assert r <= 512 // G and torch.equal(whole[B - r:], tail)                 # the remainder's kernel, on the remainder's images
     head = ops.finc_inverse(z[:B - r].contiguous(), wc, G, orient)
     assert torch.equal(whole[:B - r], head)
 
